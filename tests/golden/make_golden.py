@@ -1,0 +1,274 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by RUNNING THE REFERENCE'S OWN
+CLASSES (imported from /root/reference) in the build container.
+
+Runs only where /root/reference exists; never on the GPU box.  Nothing of the
+reference is copied: this script imports its modules behind a test-only
+``tensorflow`` facade (TF is not installable here),
+drives them with deterministic torch-CPU networks (the oracle's restated ops),
+and stores inputs + outputs as small .npz fixtures.
+
+    python tests/golden/make_golden.py
+
+Fixtures:
+  g1_refiner_cpu.npz   refiner_cpu.Refiner.manipulate_sample, BASELINE config 1
+  g2_policy.npz        PolicyAdaptive sgd / momentum / ladam(numpy) traces
+  g3_collab_<arch>_K<k>_<mode>.npz   collaborator.Refiner.build_refiner
+  g6_rejector.npz      Rejector.sampling accept behaviour over 3 calls
+  g7_mh.npz            IndependenceSampler.sampling over 2 calls
+  g8_toy.npz           ToyDataset.next_batch draws
+"""
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+np.float = float      # removed in numpy>=1.24; reference rejector.py:12,18 uses it
+np.int = int
+
+from oracle import nets_ref as N          # noqa: E402  (deterministic D / G-tail for the harness)
+from oracle import sampling_ref as S      # noqa: E402  (only mlp_* helpers: the harness' D)
+
+
+# --------------------------------------------------------------------------- TF facade
+class T:
+    """Immutable value wrapper with TF1 tensor semantics (``-=`` rebinds)."""
+    __array_priority__ = 1000
+
+    def __init__(self, t):
+        self.t = t
+
+    @staticmethod
+    def un(x):
+        return x.t if isinstance(x, T) else x
+
+    def _new(self, r):
+        if r.is_floating_point():
+            r = r.detach().requires_grad_(True)
+        return T(r)
+
+    def get_shape(self):
+        return types.SimpleNamespace(as_list=lambda: list(self.t.shape))
+
+    @property
+    def shape(self):
+        return tuple(self.t.shape)
+
+    def __add__(self, o): return self._new(self.t + T.un(o))
+    __radd__ = __add__
+    def __sub__(self, o): return self._new(self.t - T.un(o))
+    def __rsub__(self, o): return self._new(T.un(o) - self.t)
+    def __isub__(self, o): return self._new(self.t - T.un(o))
+    def __mul__(self, o): return self._new(self.t * T.un(o))
+    __rmul__ = __mul__
+    def __truediv__(self, o): return self._new(self.t / T.un(o))
+    def __pow__(self, o): return self._new(self.t ** T.un(o))
+
+
+def make_tf():
+    tf = types.ModuleType("tensorflow")
+    tf.identity = lambda x: T(T.un(x).detach().clone().requires_grad_(True))
+    tf.gradients = lambda ys, xs: [T(torch.autograd.grad(T.un(ys).sum(), T.un(xs), retain_graph=True)[0])]
+    tf.reshape = lambda x, s: T(T.un(x).reshape(tuple(s)))
+    tf.reduce_mean = lambda x, axis=None: T(T.un(x).mean() if axis is None else T.un(x).mean(dim=axis))
+    tf.squeeze = lambda x: T(T.un(x).squeeze())
+    tf.ones_like = lambda x: T(torch.ones_like(T.un(x).detach()))
+    tf.greater = lambda a, b: T(T.un(a).detach() > T.un(b).detach())
+    tf.sqrt = lambda x: T(torch.sqrt(T.un(x)))
+    tf.clip_by_value = lambda x, clip_value_min, clip_value_max: T(
+        torch.clamp(T.un(x).detach(), clip_value_min, clip_value_max).requires_grad_(True))
+    tf.shape = lambda x: types.SimpleNamespace(eval=lambda: np.array(T.un(x).shape))
+
+    def where(c, a, b):
+        c = T.un(c)
+        if isinstance(c, np.ndarray):
+            c = torch.from_numpy(c)
+        a, b = T.un(a).detach(), T.un(b).detach()
+        c = c.view(-1, *([1] * (a.dim() - 1)))
+        r = torch.where(c, a, b)
+        return T(r.requires_grad_(True) if r.is_floating_point() else r)
+    tf.where = where
+    return tf
+
+
+sys.modules["tensorflow"] = make_tf()
+sys.path.insert(0, os.path.join(REF, "sampling"))
+sys.path.insert(0, os.path.join(REF, "synthetic"))
+import collaborator            # noqa: E402  reference sampling/collaborator.py
+import refiner_cpu             # noqa: E402  reference sampling/refiner_cpu.py
+import policy                  # noqa: E402  reference sampling/policy.py
+import rejector                # noqa: E402  reference sampling/rejector.py
+import idpsampler              # noqa: E402  reference sampling/idpsampler.py
+import Datasets                # noqa: E402  reference synthetic/Datasets.py
+
+
+def save(name, **kw):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **kw)
+    print(f"{name}: {os.path.getsize(path)/1024:.1f} kB")
+
+
+def params_checksum(P):
+    return np.array([float(sum(v.double().abs().sum() for v in P.values()))])
+
+
+# --------------------------------------------------------------------------- G1
+def g1_refiner_cpu():
+    """BASELINE config 1: Imbal-8Gaussians, B=512, K=10, ladam rate 0.1."""
+    Ws, bs = S.mlp_init(64, 6, seed=2019, scale=2.0)
+    calls = []
+
+    class Gan:
+        fake_samples, fake_sigmoid, fake_saliency = "fake_samples", "fake_sigmoid", "fake_saliency"
+
+    class Sess:
+        def run(self, fetches, feed_dict):
+            sig, sal = S.mlp_sigmoid_and_saliency(Ws, bs, feed_dict[Gan.fake_samples])
+            calls.append(1)
+            return [{"fake_sigmoid": sig, "fake_saliency": sal}[f] for f in fetches]
+
+    args = types.SimpleNamespace(rollout_steps=10, rollout_rate=0.1, rollout_method="ladam")
+    data = Datasets.ToyDataset(distr="Imbal-8Gaussians", scale=10.0, ratio=0.9)
+    fake = (3.0 * np.random.RandomState(7).randn(512, 2)).astype(np.float32)
+    out = {}
+    for mode in ("deterministic", "probabilistic"):
+        ref = refiner_cpu.Refiner(args)
+        ref.set_env(Gan, Sess(), data)
+        np.random.seed(2019)
+        calls.clear()
+        fake_in = fake.copy()
+        res = ref.manipulate_sample(fake_in, mode)
+        assert np.array_equal(fake_in, fake)
+        out[mode] = res
+        out[mode + "_calls"] = np.array([len(calls)])
+        out[mode + "_dtype"] = np.array([str(res.dtype)])
+    save("g1_refiner_cpu.npz", fake=fake, mlp_seed=np.array([2019]), mlp_scale=np.array([2.0]),
+         W=np.array([w.numpy() for w in Ws], dtype=object), b=np.array([b.numpy() for b in bs], dtype=object),
+         **out)
+
+
+# --------------------------------------------------------------------------- G2
+def g2_policy():
+    rs = np.random.RandomState(3)
+    th0 = rs.randn(16, 2).astype(np.float32)
+    grads = rs.randn(3, 16, 2).astype(np.float32) * 0.1
+    losses = rs.randn(3, 16).astype(np.float32) * 0.3
+    out = dict(theta0=th0, grads=grads, losses=losses)
+    for method in ("sgd", "momentum", "ladam"):
+        p = policy.PolicyAdaptive(0.1, method)
+        th = th0.copy()
+        tr = []
+        for i in range(3):
+            th = p.apply_gradient(th, grads[i], losses[i])
+            tr.append(th.copy())
+        out[method] = np.stack(tr)
+        p.reset_moving_average()
+        assert p.momentum is None and p.mean_square is None and p.loss is None
+    # map-shaped momentum through the facade tensors (collaborator path)
+    th0m = rs.randn(4, 3, 3, 8).astype(np.float32)
+    gm = rs.randn(3, 4, 3, 3, 8).astype(np.float32)
+    p = policy.PolicyAdaptive(0.5, "momentum")
+    th = T(torch.from_numpy(th0m))
+    tr = []
+    for i in range(3):
+        th = p.apply_gradient(th, T(torch.from_numpy(gm[i])))
+        tr.append(th.t.detach().numpy().copy())
+    out.update(theta0_map=th0m, grads_map=gm, momentum_map=np.stack(tr))
+    save("g2_policy.npz", **out)
+
+
+# --------------------------------------------------------------------------- G3/G4
+def collab_case(arch, B, K, mode, rate, seed, constraints=None):
+    torch.manual_seed(0)
+    P = N.init_params(arch, seed=2019, perturb=True)
+    A = N.ARCHS[arch]
+    rs = np.random.RandomState(seed)
+    z = rs.uniform(-1, 1, (B, A["z_dim"])).astype(np.float32)
+    real = rs.uniform(-1, 1, (B,) + tuple(A["img"])).astype(np.float32)
+    with torch.no_grad():
+        feat0 = N.input_to_feature(arch, P, torch.from_numpy(z))
+
+    disc = lambda x: T(N.discriminator(arch, P, T.un(x)))
+    g_tail = lambda f: T(N.feature_to_data(arch, P, T.un(f)))
+    loss = lambda l: T(torch.nn.functional.softplus(-T.un(l)))
+
+    ref = collaborator.Refiner(rollout_steps=K, rollout_rate=rate)      # default method "momentum"
+    ref.set_env(disc, g_tail, loss)
+    if constraints is not None:
+        ref.set_constraints(*constraints)
+    np.random.seed(seed)
+    state = np.random.get_state()
+    img = ref.build_refiner(T(feat0), T(torch.from_numpy(real)), mode)
+    np.random.set_state(state)
+    idx = np.random.randint(K + 1, size=B) if mode == "probabilistic" else np.zeros(0, dtype=np.int64)
+    assert ref.optimizer.momentum is None
+    tag = f"g3_collab_{arch}_K{K}_{mode}" + ("_clip" if constraints else "")
+    save(tag + ".npz", arch=np.array([arch]), z=z, real=real, feature0=feat0.numpy(), K=np.array([K]),
+         rate=np.array([rate]), mode=np.array([mode]), indices=idx, np_seed=np.array([seed]),
+         constraints=np.array(constraints if constraints else [np.nan, np.nan]),
+         images=img.t.detach().numpy(), default_logit=ref.default_logit.t.detach().numpy(),
+         optimal_logit=ref.optimal_logit.t.detach().numpy(), optimal_step=ref.optimal_step.t.detach().numpy(),
+         optimal_feature=ref.optimal_feature.t.detach().numpy(), params_checksum=params_checksum(P))
+
+
+# --------------------------------------------------------------------------- G6/G7/G8
+def g6_rejector():
+    rs = np.random.RandomState(11)
+    out = {}
+    for tag, pct in (("p60", 60.0), ("p100", 100.0), ("none", None)):
+        rej = rejector.Rejector()
+        np.random.seed(2019)
+        for c in range(3):
+            sig = rs.beta(2, 2 + c, size=(257, 1)).astype(np.float32)
+            samples = np.arange(257, dtype=np.float32).reshape(-1, 1)
+            good = rej.sampling(samples, sig, shift_percent=pct)
+            mask = np.zeros(257, dtype=bool); mask[good[:, 0].astype(int)] = True
+            out[f"{tag}_sig{c}"] = sig; out[f"{tag}_mask{c}"] = mask; out[f"{tag}_M{c}"] = np.array([rej.D_tilde_M])
+    rej = rejector.Rejector(); rej.set_score_max(np.array(0.93, dtype=np.float32))
+    out["set_score_max_M"] = np.array([rej.D_tilde_M])
+    save("g6_rejector.npz", **out)
+
+
+def g7_mh():
+    rs = np.random.RandomState(5)
+    mh = idpsampler.IndependenceSampler(T=20)
+    mh.set_score_curr(0.4)
+    np.random.seed(2019)
+    out = {}
+    for c in range(2):
+        sig = rs.beta(2, 2, size=(400, 1))
+        samples = np.arange(400, dtype=np.float32).reshape(-1, 1)
+        good = mh.sampling(samples, sig)
+        out[f"sig{c}"] = sig; out[f"accepted{c}"] = good[:, 0].astype(np.int64) if len(good) else np.zeros(0, np.int64)
+        out[f"dtype{c}"] = np.array([str(good.dtype)])
+    save("g7_mh.npz", **out)
+
+
+def g8_toy():
+    out = {}
+    for distr, ratio, B in (("Imbal-8Gaussians", 0.9, 512), ("8Gaussians", 0.5, 100), ("25Gaussians", 0.5, 60)):
+        np.random.seed(2019)
+        d = Datasets.ToyDataset(distr=distr, scale=10.0, ratio=ratio)
+        out[distr] = d.next_batch(B)
+    np.random.seed(2019)
+    out["noise"] = Datasets.NoiseDataset().next_batch(33)
+    save("g8_toy.npz", **out)
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    g1_refiner_cpu(); g2_policy(); g6_rejector(); g7_mh(); g8_toy()
+    for K in (1, 5, 20):
+        collab_case("mnist", 8, K, "deterministic", 0.1, seed=100 + K)
+    collab_case("mnist", 8, 5, "probabilistic", 0.1, seed=7)
+    collab_case("mnist", 8, 5, "deterministic", 0.5, seed=9, constraints=(0.05, 1.5))
+    collab_case("dcgan32", 4, 5, "deterministic", 0.1, seed=21)      # 5x5 kernels: asymmetric SAME
+    collab_case("dcgan32", 4, 5, "probabilistic", 0.1, seed=22)
