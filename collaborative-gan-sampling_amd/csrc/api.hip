@@ -1,0 +1,191 @@
+// extern "C" entry points of libcgs_hip.so (declared in include/cgs_hip.h): argument checking,
+// geometry, weight packing and kernel dispatch.  No allocation, no synchronisation.
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "cgs_internal.h"
+
+static thread_local char g_err[512] = "";
+
+int cgs_set_error(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+extern "C" {
+
+int cgs_version(void) { return 100; }
+const char* cgs_last_error(void) { return g_err; }
+
+}  // extern "C"
+
+static bool smalln_ok(const CgsLayer& L, int epilogue) {
+    return L.Cb <= 4 && L.sh == 2 && L.sw == 2 && L.Hb == 2 * L.Hs && L.Wb == 2 * L.Ws && (L.Cs % 4) == 0 &&
+           epilogue != CGS_EPI_AFFINE_RELU;
+}
+
+static int make_layer(CgsLayer& L, int kh, int kw, int sh, int sw, int Hb, int Wb, int Cb, int Hs, int Ws, int Cs,
+                      const char* who) {
+    if (kh <= 0 || kw <= 0 || sh <= 0 || sw <= 0 || Hb <= 0 || Wb <= 0 || Cb <= 0 || Cs <= 0)
+        return cgs_set_error(CGS_EINVAL, "%s: non-positive dimension", who);
+    if (Hs != cgs_ceil_div(Hb, sh) || Ws != cgs_ceil_div(Wb, sw))
+        return cgs_set_error(CGS_EINVAL, "%s: 'SAME' geometry mismatch: big %dx%d stride %dx%d needs small %dx%d, got %dx%d", who,
+                             Hb, Wb, sh, sw, cgs_ceil_div(Hb, sh), cgs_ceil_div(Wb, sw), Hs, Ws);
+    L.kh = kh; L.kw = kw; L.sh = sh; L.sw = sw; L.Hb = Hb; L.Wb = Wb; L.Cb = Cb; L.Hs = Hs; L.Ws = Ws; L.Cs = Cs;
+    return CGS_OK;
+}
+
+static int run_dir(const CgsLayer& L, bool dirT, int B, const float* in, const float* w, const float* bias, float* out,
+                   int epilogue, const float* ep_a, const float* ep_b, void* ws, size_t ws_bytes, int prepacked,
+                   hipStream_t s, const char* who) {
+    if (B <= 0) return cgs_set_error(CGS_EINVAL, "%s: B=%d", who, B);
+    if (!in || !w || !out) return cgs_set_error(CGS_EINVAL, "%s: null tensor", who);
+    if (epilogue < CGS_EPI_NONE || epilogue > CGS_EPI_TANH) return cgs_set_error(CGS_EINVAL, "%s: epilogue %d", who, epilogue);
+    if (epilogue == CGS_EPI_AFFINE_RELU && (!ep_a || !ep_b)) return cgs_set_error(CGS_EINVAL, "%s: affine epilogue needs a,b", who);
+    if (dirT && (L.sh > 2 || L.sw > 2)) return cgs_set_error(CGS_EINVAL, "%s: transposed direction supports stride <= 2", who);
+    if (dirT && smalln_ok(L, epilogue)) return cgs_convt_smalln_launch(L, B, in, w, bias, out, epilogue, s);
+    IgemmParams p;
+    p.in = in; p.bias = bias; p.ep_a = ep_a; p.ep_b = ep_b; p.out = out; p.B = B; p.epilogue = epilogue;
+    if (dirT) cgs_geom_T(L, p); else cgs_geom_F(L, p);
+    const size_t need = cgs_packed_floats(p) * sizeof(float);
+    if (!ws || ws_bytes < need) return cgs_set_error(CGS_EWORKSPACE, "%s: workspace %zu < %zu bytes", who, ws_bytes, need);
+    if (((uintptr_t)ws & 15) || ((uintptr_t)in & 15) || ((uintptr_t)out & 3))
+        return cgs_set_error(CGS_EINVAL, "%s: pointers must be 16-byte aligned", who);
+    p.wp = (const float*)ws;
+    if (!prepacked) {
+        int rc = cgs_pack_weights(p, L, dirT, w, (float*)ws, s);
+        if (rc) return rc;
+    }
+    return cgs_igemm_launch(p, s);
+}
+
+extern "C" {
+
+size_t cgs_conv_ws_bytes(int op, int kh, int kw, int sh, int sw, int Cin, int Cout) {
+    if (kh <= 0 || kw <= 0 || sh <= 0 || sw <= 0 || Cin <= 0 || Cout <= 0) return 0;
+    // weights are [kh][kw][Cb][Cs]: conv Cb=Cin,Cs=Cout; deconv Cb=Cout,Cs=Cin
+    const bool deconv = (op == CGS_DECONV_FWD || op == CGS_DECONV_BWD_DATA);
+    const bool dirT = (op == CGS_CONV_BWD_DATA || op == CGS_DECONV_FWD);
+    const int Cb = deconv ? Cout : Cin, Cs = deconv ? Cin : Cout;
+    if (!dirT) return (size_t)cgs_round_up(kh * kw * Cb, CGS_BK) * cgs_round_up(Cs, 64) * sizeof(float);
+    // T: per parity class, taps of that class (independent of the spatial size: pads only permute classes)
+    size_t n = 0;
+    for (int a = 0; a < sh; ++a)
+        for (int b = 0; b < sw; ++b) {
+            const int nty = a < kh ? (kh - a + sh - 1) / sh : 0, ntx = b < kw ? (kw - b + sw - 1) / sw : 0;
+            n += (size_t)cgs_round_up(nty * ntx * Cs, CGS_BK) * cgs_round_up(Cb, 64);
+        }
+    return n * sizeof(float);
+}
+
+int cgs_conv2d_nhwc_fwd(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int Cin,
+                        int Cout, int kh, int kw, int sh, int sw, int epilogue, const float* ep_a, const float* ep_b,
+                        void* ws, size_t ws_bytes, int ws_prepacked, void* stream) {
+    CgsLayer L;
+    int rc = make_layer(L, kh, kw, sh, sw, H, W, Cin, cgs_ceil_div(H, sh > 0 ? sh : 1), cgs_ceil_div(W, sw > 0 ? sw : 1), Cout, "conv2d_nhwc_fwd");
+    if (rc) return rc;
+    return run_dir(L, false, B, x, w, bias, y, epilogue, ep_a, ep_b, ws, ws_bytes, ws_prepacked, (hipStream_t)stream, "conv2d_nhwc_fwd");
+}
+
+int cgs_conv2d_nhwc_bwd_data(const float* dy, const float* w, float* dx, int B, int H, int W, int Cin, int Cout, int kh,
+                             int kw, int sh, int sw, void* ws, size_t ws_bytes, int ws_prepacked, void* stream) {
+    CgsLayer L;
+    int rc = make_layer(L, kh, kw, sh, sw, H, W, Cin, cgs_ceil_div(H, sh > 0 ? sh : 1), cgs_ceil_div(W, sw > 0 ? sw : 1), Cout, "conv2d_nhwc_bwd_data");
+    if (rc) return rc;
+    return run_dir(L, true, B, dy, w, nullptr, dx, CGS_EPI_NONE, nullptr, nullptr, ws, ws_bytes, ws_prepacked, (hipStream_t)stream, "conv2d_nhwc_bwd_data");
+}
+
+int cgs_deconv2d_nhwc_fwd(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int Cin,
+                          int Ho, int Wo, int Cout, int kh, int kw, int sh, int sw, int epilogue, const float* ep_a,
+                          const float* ep_b, void* ws, size_t ws_bytes, int ws_prepacked, void* stream) {
+    CgsLayer L;
+    int rc = make_layer(L, kh, kw, sh, sw, Ho, Wo, Cout, H, W, Cin, "deconv2d_nhwc_fwd");
+    if (rc) return rc;
+    return run_dir(L, true, B, x, w, bias, y, epilogue, ep_a, ep_b, ws, ws_bytes, ws_prepacked, (hipStream_t)stream, "deconv2d_nhwc_fwd");
+}
+
+int cgs_deconv2d_nhwc_bwd_data(const float* dy, const float* w, float* dx, int B, int H, int W, int Cin, int Ho, int Wo,
+                               int Cout, int kh, int kw, int sh, int sw, void* ws, size_t ws_bytes, int ws_prepacked,
+                               void* stream) {
+    CgsLayer L;
+    int rc = make_layer(L, kh, kw, sh, sw, Ho, Wo, Cout, H, W, Cin, "deconv2d_nhwc_bwd_data");
+    if (rc) return rc;
+    return run_dir(L, false, B, dy, w, nullptr, dx, CGS_EPI_NONE, nullptr, nullptr, ws, ws_bytes, ws_prepacked, (hipStream_t)stream, "deconv2d_nhwc_bwd_data");
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// linear with a single output column (the D logit head, nsgan/GAN.py:68): wave-reduced dot product
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void linear_out1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                              const float* __restrict__ bias, float* __restrict__ y,
+                                                              int B, int K, int epilogue) {
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (b >= B) return;
+    const float* row = x + (size_t)b * K;
+    float s = 0.f;
+    if ((K & 3) == 0) {
+        for (int k = lane * 4; k < K; k += 256) {
+            const float4 a = *(const float4*)(row + k), ww = *(const float4*)(w + k);
+            s = fmaf(a.x, ww.x, s); s = fmaf(a.y, ww.y, s); s = fmaf(a.z, ww.z, s); s = fmaf(a.w, ww.w, s);
+        }
+    } else {
+        for (int k = lane; k < K; k += 64) s = fmaf(row[k], w[k], s);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if (lane == 0) {
+        float v = s + (bias ? bias[0] : 0.f);
+        if (epilogue == CGS_EPI_LRELU) v = fmaxf(v, 0.2f * v);
+        y[b] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void linear_out1_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                                              float* __restrict__ dx, int B, int K) {
+    const size_t n = (size_t)B * K;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int b = (int)(i / K), k = (int)(i - (size_t)b * K);
+        dx[i] = dy[b] * w[k];
+    }
+}
+
+extern "C" {
+
+int cgs_linear_fwd(const float* x, const float* w, const float* bias, float* y, int B, int in, int out, int epilogue,
+                   void* ws, size_t ws_bytes, int ws_prepacked, void* stream) {
+    if (B <= 0 || in <= 0 || out <= 0) return cgs_set_error(CGS_EINVAL, "linear_fwd: B=%d in=%d out=%d", B, in, out);
+    if (epilogue != CGS_EPI_NONE && epilogue != CGS_EPI_LRELU) return cgs_set_error(CGS_EINVAL, "linear_fwd: epilogue %d", epilogue);
+    if (out == 1) {
+        hipLaunchKernelGGL(linear_out1_fwd_kernel, dim3(cgs_ceil_div(B, 4)), dim3(256), 0, (hipStream_t)stream, x, w, bias, y, B, in, epilogue);
+        CGS_CHECK_LAUNCH("linear_out1_fwd");
+        return CGS_OK;
+    }
+    CgsLayer L;
+    int rc = make_layer(L, 1, 1, 1, 1, 1, 1, in, 1, 1, out, "linear_fwd");
+    if (rc) return rc;
+    return run_dir(L, false, B, x, w, bias, y, epilogue, nullptr, nullptr, ws, ws_bytes, ws_prepacked, (hipStream_t)stream, "linear_fwd");
+}
+
+int cgs_linear_bwd_data(const float* dy, const float* w, float* dx, int B, int in, int out, void* ws, size_t ws_bytes,
+                        int ws_prepacked, void* stream) {
+    if (B <= 0 || in <= 0 || out <= 0) return cgs_set_error(CGS_EINVAL, "linear_bwd_data: B=%d in=%d out=%d", B, in, out);
+    if (out == 1) {
+        size_t n = (size_t)B * in;
+        unsigned blocks = (unsigned)((n + 255) / 256 > 8192 ? 8192 : (n + 255) / 256);
+        hipLaunchKernelGGL(linear_out1_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, w, dx, B, in);
+        CGS_CHECK_LAUNCH("linear_out1_bwd");
+        return CGS_OK;
+    }
+    CgsLayer L;
+    int rc = make_layer(L, 1, 1, 1, 1, 1, 1, in, 1, 1, out, "linear_bwd_data");
+    if (rc) return rc;
+    return run_dir(L, true, B, dy, w, nullptr, dx, CGS_EPI_NONE, nullptr, nullptr, ws, ws_bytes, ws_prepacked, (hipStream_t)stream, "linear_bwd_data");
+}
+
+}  // extern "C"

@@ -1,0 +1,189 @@
+// Batch-statistics batch norm fused with LeakyReLU, forward and backward-data
+// (tf.contrib.layers.batch_norm(is_training=True) + lrelu, nsgan/ops.py:19-26,69-70 as used by D at
+// nsgan/GAN.py:65,67 inside the differentiated path, sampling/collaborator.py:31).
+//
+// HBM-bound: every pass streams [M,C] fp32 once with 16-byte accesses, channels across lanes.
+// Per-channel reductions are two-stage and deterministic (no float atomics): stage 1 writes one
+// (sum_a, sum_b) partial per block and channel, stage 2 adds the partials in a fixed order in
+// double and finishes the statistics.  Run-to-run results are bit-identical.
+#include "cgs_internal.h"
+
+#define BN_MAX_BLOCKS 1024
+
+struct BnGeom {
+    int G;               // stage-1 blocks
+    int rows_per_block;
+};
+
+static BnGeom bn_geom(int M, int C) {
+    // a block covers whole rows; aim at >= 8 rows per block pass and <= BN_MAX_BLOCKS blocks
+    BnGeom g;
+    int rpb = cgs_ceil_div(M, BN_MAX_BLOCKS);
+    if (rpb < 32) rpb = 32;
+    g.rows_per_block = rpb;
+    g.G = cgs_ceil_div(M, rpb);
+    (void)C;
+    return g;
+}
+
+size_t cgs_bn_ws_bytes(int M, int C) {
+    (void)M;
+    return ((size_t)BN_MAX_BLOCKS * 2 * C + 6 * (size_t)C) * sizeof(float);   // partials | stat[4][C] | stat2[2][C]
+}
+
+// MODE 0: a = x, b = x*x.   MODE 1: a = dy', b = dy'*xhat  (dy' = dy * lrelu'(scale*x+shift))
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                         const float* __restrict__ stat /* [4][C]: mean, invstd, scale, shift */,
+                                                         float leak, float* __restrict__ part, int M, int C,
+                                                         int rows_per_block) {
+    __shared__ float red[2][256];
+    const int tid = threadIdx.x;
+    const int r0 = blockIdx.x * rows_per_block;
+    const int r1 = min(M, r0 + rows_per_block);
+    // threads-per-row: largest power of two <= min(C, 256)
+    int tpr = 1;
+    while (tpr * 2 <= C && tpr * 2 <= 256) tpr *= 2;
+    const int rg = tid / tpr, RG = 256 / tpr, tc = tid - rg * tpr;
+    for (int c0 = 0; c0 < C; c0 += tpr) {
+        const int c = c0 + tc;
+        float sa = 0.f, sb = 0.f;
+        if (c < C) {
+            float mean = 0.f, invstd = 0.f, scale = 0.f, shift = 0.f;
+            if (MODE == 1) { mean = stat[c]; invstd = stat[C + c]; scale = stat[2 * C + c]; shift = stat[3 * C + c]; }
+            for (int r = r0 + rg; r < r1; r += RG) {
+                const float xv = x[(size_t)r * C + c];
+                if (MODE == 0) {
+                    sa += xv; sb = fmaf(xv, xv, sb);
+                } else {
+                    const float u = fmaf(xv, scale, shift);
+                    const float d = dy[(size_t)r * C + c] * (u > 0.f ? 1.f : leak);
+                    sa += d; sb = fmaf(d, (xv - mean) * invstd, sb);
+                }
+            }
+        }
+        red[0][tid] = sa; red[1][tid] = sb;
+        __syncthreads();
+        if (rg == 0 && c < C) {
+            float ta = 0.f, tb = 0.f;
+            for (int g = 0; g < RG; ++g) { ta += red[0][g * tpr + tc]; tb += red[1][g * tpr + tc]; }
+            part[((size_t)blockIdx.x * 2 + 0) * C + c] = ta;
+            part[((size_t)blockIdx.x * 2 + 1) * C + c] = tb;
+        }
+        __syncthreads();
+    }
+}
+
+// MODE 0: -> stat = {mean, invstd, scale = gamma*invstd, shift = beta - mean*scale}; also mean/invstd outputs
+// MODE 1: -> stat2 = {mean(dy'), mean(dy'*xhat)}
+template <int MODE>
+__global__ void bn_finalize_kernel(const float* __restrict__ part, int G, int M, int C, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float eps, float* __restrict__ stat,
+                                   float* __restrict__ mean_out, float* __restrict__ invstd_out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double a = 0.0, b = 0.0;
+    for (int g = 0; g < G; ++g) { a += (double)part[((size_t)g * 2 + 0) * C + c]; b += (double)part[((size_t)g * 2 + 1) * C + c]; }
+    if (MODE == 0) {
+        const double mean = a / M;
+        double var = b / M - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float scale = gamma[c] * invstd;
+        stat[c] = (float)mean; stat[C + c] = invstd; stat[2 * C + c] = scale; stat[3 * C + c] = beta[c] - (float)mean * scale;
+        mean_out[c] = (float)mean; invstd_out[c] = invstd;
+    } else {
+        stat[c] = (float)(a / M); stat[C + c] = (float)(b / M);
+    }
+}
+
+// y = lrelu(scale*x + shift)
+__global__ __launch_bounds__(256) void bn_apply_fwd_kernel(const float* __restrict__ x, const float* __restrict__ stat,
+                                                           float leak, float* __restrict__ y, size_t n4, int C) {
+    const float* scale = stat + 2 * C;
+    const float* shift = stat + 3 * C;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)((i * 4) % C);
+        const float4 v = ((const float4*)x)[i];
+        const float4 sc = *(const float4*)(scale + c), sh = *(const float4*)(shift + c);
+        float4 o;
+        o.x = fmaf(v.x, sc.x, sh.x); o.y = fmaf(v.y, sc.y, sh.y); o.z = fmaf(v.z, sc.z, sh.z); o.w = fmaf(v.w, sc.w, sh.w);
+        o.x = o.x > 0.f ? o.x : leak * o.x; o.y = o.y > 0.f ? o.y : leak * o.y;
+        o.z = o.z > 0.f ? o.z : leak * o.z; o.w = o.w > 0.f ? o.w : leak * o.w;
+        ((float4*)y)[i] = o;
+    }
+}
+
+// dx = gamma*invstd*(dy' - m1 - xhat*m2)
+__global__ __launch_bounds__(256) void bn_apply_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                           const float* __restrict__ stat, const float* __restrict__ stat2,
+                                                           float leak, float* __restrict__ dx, size_t n4, int C) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)((i * 4) % C);
+        const float4 xv = ((const float4*)x)[i], dv = ((const float4*)dy)[i];
+        const float4 mean = *(const float4*)(stat + c), inv = *(const float4*)(stat + C + c);
+        const float4 sc = *(const float4*)(stat + 2 * C + c), sh = *(const float4*)(stat + 3 * C + c);
+        const float4 m1 = *(const float4*)(stat2 + c), m2 = *(const float4*)(stat2 + C + c);
+        float4 o;
+#define BWD1(f)                                                       \
+        {                                                             \
+            const float u = fmaf(xv.f, sc.f, sh.f);                   \
+            const float d = dv.f * (u > 0.f ? 1.f : leak);            \
+            const float xh = (xv.f - mean.f) * inv.f;                 \
+            o.f = sc.f * (d - m1.f - xh * m2.f);                      \
+        }
+        BWD1(x) BWD1(y) BWD1(z) BWD1(w)
+#undef BWD1
+        ((float4*)dx)[i] = o;
+    }
+}
+
+static unsigned ew_blocks(size_t n) {
+    size_t b = (n + 255) / 256;
+    if (b > 8192) b = 8192;
+    if (b == 0) b = 1;
+    return (unsigned)b;
+}
+
+int cgs_bn_train_lrelu_fwd(const float* x, const float* gamma, const float* beta, float eps, float leak, float* y,
+                           float* mean, float* invstd, int M, int C, void* ws, size_t ws_bytes, void* stream) {
+    if (M <= 0 || C <= 0 || (C & 3)) return cgs_set_error(CGS_EINVAL, "bn fwd: M=%d C=%d (C must be a multiple of 4)", M, C);
+    if (ws_bytes < cgs_bn_ws_bytes(M, C)) return cgs_set_error(CGS_EWORKSPACE, "bn fwd: workspace %zu < %zu", ws_bytes, cgs_bn_ws_bytes(M, C));
+    hipStream_t s = (hipStream_t)stream;
+    const BnGeom g = bn_geom(M, C);
+    float* part = (float*)ws;
+    float* stat = part + (size_t)BN_MAX_BLOCKS * 2 * C;
+    hipLaunchKernelGGL(bn_partial_kernel<0>, dim3(g.G), dim3(256), 0, s, x, nullptr, nullptr, leak, part, M, C, g.rows_per_block);
+    hipLaunchKernelGGL(bn_finalize_kernel<0>, dim3(cgs_ceil_div(C, 128)), dim3(128), 0, s, part, g.G, M, C, gamma, beta, eps, stat, mean, invstd);
+    const size_t n4 = (size_t)M * C / 4;
+    hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3(ew_blocks(n4)), dim3(256), 0, s, x, stat, leak, y, n4, C);
+    CGS_CHECK_LAUNCH("bn_train_lrelu_fwd");
+    return CGS_OK;
+}
+
+__global__ void bn_restat_kernel(const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                 const float* __restrict__ beta, float* __restrict__ stat, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float scale = gamma[c] * invstd[c];
+    stat[c] = mean[c]; stat[C + c] = invstd[c]; stat[2 * C + c] = scale; stat[3 * C + c] = beta[c] - mean[c] * scale;
+}
+
+int cgs_bn_train_lrelu_bwd_data(const float* dy, const float* x, const float* gamma, const float* beta, const float* mean,
+                                const float* invstd, float leak, float* dx, int M, int C, void* ws, size_t ws_bytes,
+                                void* stream) {
+    if (M <= 0 || C <= 0 || (C & 3)) return cgs_set_error(CGS_EINVAL, "bn bwd: M=%d C=%d (C must be a multiple of 4)", M, C);
+    if (ws_bytes < cgs_bn_ws_bytes(M, C)) return cgs_set_error(CGS_EWORKSPACE, "bn bwd: workspace %zu < %zu", ws_bytes, cgs_bn_ws_bytes(M, C));
+    hipStream_t s = (hipStream_t)stream;
+    const BnGeom g = bn_geom(M, C);
+    float* part = (float*)ws;
+    float* stat = part + (size_t)BN_MAX_BLOCKS * 2 * C;           // [4][C]
+    float* stat2 = stat + 4 * (size_t)C;                          // [2][C]
+    hipLaunchKernelGGL(bn_restat_kernel, dim3(cgs_ceil_div(C, 128)), dim3(128), 0, s, mean, invstd, gamma, beta, stat, C);
+    hipLaunchKernelGGL(bn_partial_kernel<1>, dim3(g.G), dim3(256), 0, s, x, dy, stat, leak, part, M, C, g.rows_per_block);
+    hipLaunchKernelGGL(bn_finalize_kernel<1>, dim3(cgs_ceil_div(C, 128)), dim3(128), 0, s, part, g.G, M, C, nullptr, nullptr, 0.f, stat2, nullptr, nullptr);
+    const size_t n4 = (size_t)M * C / 4;
+    hipLaunchKernelGGL(bn_apply_bwd_kernel, dim3(ew_blocks(n4)), dim3(256), 0, s, dy, x, stat, stat2, leak, dx, n4, C);
+    CGS_CHECK_LAUNCH("bn_train_lrelu_bwd_data");
+    return CGS_OK;
+}

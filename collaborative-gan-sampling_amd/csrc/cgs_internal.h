@@ -1,0 +1,78 @@
+// Internal declarations shared by the kernels of libcgs_hip.so (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "cgs_hip.h"
+
+int cgs_set_error(int code, const char* fmt, ...);
+
+#define CGS_CHECK_LAUNCH(name)                                                        \
+    do {                                                                              \
+        hipError_t e_ = hipGetLastError();                                            \
+        if (e_ != hipSuccess) return cgs_set_error(CGS_ELAUNCH, "%s: %s", name, hipGetErrorString(e_)); \
+    } while (0)
+
+static inline int cgs_ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline int cgs_round_up(int a, int b) { return cgs_ceil_div(a, b) * b; }
+
+// TF 'SAME' padding before the first pixel.
+static inline int cgs_same_pad_before(int size, int k, int s) {
+    int out = cgs_ceil_div(size, s);
+    int tot = (out - 1) * s + k - size;
+    if (tot < 0) tot = 0;
+    return tot / 2;
+}
+
+// ---------------------------------------------------------------------------------------------
+// One "conv layer relation": a BIG tensor [B,Hb,Wb,Cb] and a SMALL tensor [B,Hs,Ws,Cs] with
+// Hs = ceil(Hb/s), tied by weights w[kh][kw][Cb][Cs] (conv HWIO: Cb=Cin,Cs=Cout; deconv
+// [kh,kw,Cout,Cin]: Cb=Cout,Cs=Cin -- the same layout, because conv2d_transpose is defined as the
+// adjoint of the conv with that filter).  Two contractions exist:
+//   F (big -> small): conv fwd, deconv bwd-data.   reduce over (tap, Cb), N = Cs
+//   T (small -> big): deconv fwd, conv bwd-data.   reduce over (tap, Cs), N = Cb; s*s parity classes
+// ---------------------------------------------------------------------------------------------
+struct CgsLayer {
+    int kh, kw, sh, sw;
+    int Hb, Wb, Cb, Hs, Ws, Cs;
+};
+
+#define CGS_BK 32           // K-tile of the implicit GEMM
+#define CGS_MAX_CLASSES 4   // stride <= 2 for the T direction
+
+struct IgemmClass {
+    int R, C;        // base-pixel grid of this class per image (rows of the GEMM: M = B*R*C)
+    int py, px;      // output pixel = (r*So + py, c*So + px)
+    int nty, ntx;    // taps of this class: t = ta*ntx + tb
+    int dy0, dx0;    // input pixel = (r*S + dy0 + ta*dstep, c*S + dx0 + tb*dstep)
+    int ky0, kx0;    // weight tap of (ta,tb) = (ky0 + ta*kstep, kx0 + tb*kstep)
+    int K;           // nty*ntx*Cred
+    int w_off;       // float offset of this class' packed weights
+};
+
+struct IgemmParams {
+    const float* in;
+    const float* wp;     // packed weights [class][Kpad/4][Np][4]
+    const float* bias;
+    const float* ep_a;
+    const float* ep_b;
+    float* out;
+    int B, Hin, Win, Cred;      // input tensor (reduction channels per tap)
+    int Hout, Wout, N, Np;      // output tensor, N channels (Np = N rounded up to 64)
+    int S, So, dstep, kstep;
+    int epilogue;
+    int nclasses;
+    IgemmClass cls[CGS_MAX_CLASSES];
+};
+
+// geometry builders (igemm.hip)
+void cgs_geom_F(const CgsLayer& L, IgemmParams& p);
+void cgs_geom_T(const CgsLayer& L, IgemmParams& p);
+size_t cgs_packed_floats(const IgemmParams& p);
+
+// launchers
+int cgs_pack_weights(const IgemmParams& p, const CgsLayer& L, bool dirT, const float* w, float* packed, hipStream_t s);
+int cgs_igemm_launch(const IgemmParams& p, hipStream_t s);
+int cgs_convt_smalln_launch(const CgsLayer& L, int B, const float* in, const float* w, const float* bias,
+                            float* out, int epilogue, hipStream_t s);

@@ -1,0 +1,161 @@
+// Element-wise and per-sample kernels of the refinement loop: activations and their input
+// gradients (nsgan/ops.py:69-70, nsgan/GAN.py:96-100), the loss seed and per-sample mean logit
+// (nsgan/GAN.py:176-177, sampling/collaborator.py:31-37), the momentum update
+// (sampling/policy.py:27-37, sampling/collaborator.py:66-70) and the best-sample selection
+// (sampling/collaborator.py:76-83).  All HBM-bound: 16-byte accesses, grid-stride.
+#include "cgs_internal.h"
+
+static unsigned ew_blocks(size_t n) {
+    size_t b = (n + 255) / 256;
+    if (b > 8192) b = 8192;
+    if (b == 0) b = 1;
+    return (unsigned)b;
+}
+
+#define GRID_STRIDE(i, n) for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (size_t)gridDim.x * blockDim.x)
+
+__global__ void bn_fold_kernel(const float* g, const float* b, const float* mm, const float* mv, float eps, float* a,
+                               float* bo, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float s = g[c] / sqrtf(mv[c] + eps);
+    a[c] = s; bo[c] = b[c] - s * mm[c];
+}
+
+int cgs_bn_fold(const float* gamma, const float* beta, const float* mm, const float* mv, float eps, float* a, float* b,
+                int C, void* stream) {
+    if (C <= 0) return cgs_set_error(CGS_EINVAL, "bn_fold: C=%d", C);
+    hipLaunchKernelGGL(bn_fold_kernel, dim3(cgs_ceil_div(C, 128)), dim3(128), 0, (hipStream_t)stream, gamma, beta, mm, mv, eps, a, b, C);
+    CGS_CHECK_LAUNCH("bn_fold");
+    return CGS_OK;
+}
+
+// MODE 0: y = relu(a*x+b).  MODE 1: dx = dy*(y>0)*a
+template <int MODE>
+__global__ __launch_bounds__(256) void affine_relu_kernel(const float* __restrict__ p0, const float* __restrict__ p1,
+                                                          const float* __restrict__ a, const float* __restrict__ b,
+                                                          float* __restrict__ o, size_t n, int C) {
+    GRID_STRIDE(i, n) {
+        const int c = (int)(i % C);
+        if (MODE == 0) o[i] = fmaxf(fmaf(a[c], p0[i], b[c]), 0.f);
+        else o[i] = p1[i] > 0.f ? p0[i] * a[c] : 0.f;
+    }
+}
+
+int cgs_affine_relu_fwd(const float* x, const float* a, const float* b, float* y, int M, int C, void* stream) {
+    if (M < 0 || C <= 0) return cgs_set_error(CGS_EINVAL, "affine_relu_fwd: M=%d C=%d", M, C);
+    const size_t n = (size_t)M * C;
+    if (n == 0) return CGS_OK;
+    hipLaunchKernelGGL(affine_relu_kernel<0>, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, x, nullptr, a, b, y, n, C);
+    CGS_CHECK_LAUNCH("affine_relu_fwd");
+    return CGS_OK;
+}
+
+int cgs_affine_relu_bwd(const float* dy, const float* y, const float* a, float* dx, int M, int C, void* stream) {
+    if (M < 0 || C <= 0) return cgs_set_error(CGS_EINVAL, "affine_relu_bwd: M=%d C=%d", M, C);
+    const size_t n = (size_t)M * C;
+    if (n == 0) return CGS_OK;
+    hipLaunchKernelGGL(affine_relu_kernel<1>, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, dy, y, a, nullptr, dx, n, C);
+    CGS_CHECK_LAUNCH("affine_relu_bwd");
+    return CGS_OK;
+}
+
+// OP 0 lrelu fwd, 1 lrelu bwd, 2 tanh fwd, 3 tanh bwd
+template <int OP>
+__global__ __launch_bounds__(256) void unary_kernel(const float* __restrict__ p0, const float* __restrict__ p1, float leak,
+                                                    float* __restrict__ o, size_t n) {
+    GRID_STRIDE(i, n) {
+        float r;
+        if (OP == 0) { const float v = p0[i]; r = fmaxf(v, leak * v); }
+        else if (OP == 1) r = p0[i] * (p1[i] > 0.f ? 1.f : leak);
+        else if (OP == 2) r = tanhf(p0[i]);
+        else { const float y = p1[i]; r = p0[i] * (1.f - y * y); }
+        o[i] = r;
+    }
+}
+
+#define UNARY_ENTRY(fn, OP, a0, a1, lk)                                                                  \
+    if (n == 0) return CGS_OK;                                                                           \
+    hipLaunchKernelGGL(unary_kernel<OP>, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, a0, a1, lk, out, n); \
+    CGS_CHECK_LAUNCH(fn);                                                                                \
+    return CGS_OK;
+
+int cgs_lrelu_fwd(const float* x, float leak, float* out, size_t n, void* stream) { UNARY_ENTRY("lrelu_fwd", 0, x, nullptr, leak) }
+int cgs_lrelu_bwd(const float* dy, const float* y, float leak, float* out, size_t n, void* stream) { UNARY_ENTRY("lrelu_bwd", 1, dy, y, leak) }
+int cgs_tanh_fwd(const float* x, float* out, size_t n, void* stream) { UNARY_ENTRY("tanh_fwd", 2, x, nullptr, 0.f) }
+int cgs_tanh_bwd(const float* dy, const float* y, float* out, size_t n, void* stream) { UNARY_ENTRY("tanh_bwd", 3, dy, y, 0.f) }
+
+__global__ void bce_rowmean_kernel(const float* __restrict__ l, float* __restrict__ dl, float* __restrict__ lm, int B, int P) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float s = 0.f;
+    for (int i = 0; i < P; ++i) {
+        const float v = l[(size_t)b * P + i];
+        s += v;
+        // sigmoid(v) - 1 = -1/(1+exp(v)), written to stay accurate for large |v|
+        dl[(size_t)b * P + i] = v >= 0.f ? -expf(-v) / (1.f + expf(-v)) : -1.f / (1.f + expf(v));
+    }
+    lm[b] = s / (float)P;
+}
+
+int cgs_bce_ones_grad_rowmean(const float* logits, float* dlogits, float* logit_mean, int B, int P, void* stream) {
+    if (B <= 0 || P <= 0) return cgs_set_error(CGS_EINVAL, "bce_ones_grad_rowmean: B=%d P=%d", B, P);
+    hipLaunchKernelGGL(bce_rowmean_kernel, dim3(cgs_ceil_div(B, 128)), dim3(128), 0, (hipStream_t)stream, logits, dlogits, logit_mean, B, P);
+    CGS_CHECK_LAUNCH("bce_ones_grad_rowmean");
+    return CGS_OK;
+}
+
+__global__ __launch_bounds__(256) void refine_update_kernel(float* __restrict__ theta, float* __restrict__ m,
+                                                            const float* __restrict__ g, float rate, float alpha,
+                                                            int first, int use_clip, float vmin, float vmax, size_t n) {
+#pragma clang fp contract(off)   // separately rounded mul / add, the reference's op sequence (policy.py:33-36)
+    GRID_STRIDE(i, n) {
+        const float lg = rate * g[i];
+        const float am = alpha * m[i];
+        const float mv = first ? lg : am + lg;
+        m[i] = mv;
+        float t = theta[i] - mv;
+        if (use_clip) t = fminf(fmaxf(t, vmin), vmax);          // collaborator.py:69-70
+        theta[i] = t;
+    }
+}
+
+int cgs_refine_update(float* theta, float* m, const float* g, float rate, float alpha, int first, int use_clip,
+                      float vmin, float vmax, size_t n, void* stream) {
+    if (n == 0) return CGS_OK;
+    hipLaunchKernelGGL(refine_update_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, theta, m, g, rate, alpha, first, use_clip, vmin, vmax, n);
+    CGS_CHECK_LAUNCH("refine_update");
+    return CGS_OK;
+}
+
+// pass 1: copy theta rows whose sample improves (reads best_logit, never writes it)
+__global__ __launch_bounds__(256) void refine_select_copy_kernel(const float* __restrict__ theta, const float* __restrict__ logit,
+                                                                 const int32_t* __restrict__ forced, int step,
+                                                                 float* __restrict__ best_theta, const float* __restrict__ best_logit,
+                                                                 int B, int F) {
+    const int b = blockIdx.y;
+    const bool upd = forced ? forced[b] == step : logit[b] > best_logit[b];
+    if (!upd) return;
+    const float* src = theta + (size_t)b * F;
+    float* dst = best_theta + (size_t)b * F;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < F; i += gridDim.x * blockDim.x) dst[i] = src[i];
+}
+// pass 2: per-sample scalars
+__global__ void refine_select_scalar_kernel(const float* __restrict__ logit, const int32_t* __restrict__ forced, int step,
+                                            float* __restrict__ best_logit, float* __restrict__ best_step, int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const bool upd = forced ? forced[b] == step : logit[b] > best_logit[b];
+    if (upd) { best_logit[b] = logit[b]; best_step[b] = (float)(step + 1); }
+}
+
+int cgs_refine_select(const float* theta, const float* logit, const int32_t* forced, int step_index, float* best_theta,
+                      float* best_logit, float* best_step, int B, int F, void* stream) {
+    if (B <= 0 || F <= 0 || B > 65535) return cgs_set_error(CGS_EINVAL, "refine_select: B=%d F=%d", B, F);
+    int bx = cgs_ceil_div(F, 256 * 4);
+    if (bx < 1) bx = 1;
+    hipLaunchKernelGGL(refine_select_copy_kernel, dim3(bx, B), dim3(256), 0, (hipStream_t)stream, theta, logit, forced, step_index, best_theta, best_logit, B, F);
+    hipLaunchKernelGGL(refine_select_scalar_kernel, dim3(cgs_ceil_div(B, 128)), dim3(128), 0, (hipStream_t)stream, logit, forced, step_index, best_logit, best_step, B);
+    CGS_CHECK_LAUNCH("refine_select");
+    return CGS_OK;
+}

@@ -1,0 +1,317 @@
+// Implicit-GEMM NHWC convolution family on the gfx950 fp32 matrix cores.
+//
+// One kernel serves the four contractions of the refinement hot path (conv fwd, conv bwd-data,
+// deconv fwd, deconv bwd-data -- sampling/collaborator.py:26-39 through nsgan/ops.py:41,55) and
+// the fully connected layers (nsgan/ops.py:81), all with TF 'SAME' geometry:
+//
+//   out[b, r*So+py, c*So+px, n] = epi( bias[n] + sum_{ta,tb,ci} in[b, r*S+dy0+ta*dstep, c*S+dx0+tb*dstep, ci]
+//                                                               * Wp[(ta*ntx+tb)*Cred + ci][n] )
+//
+// im2col is never materialised: A-tile rows are gathered straight from the NHWC activation (each
+// 32-deep K chunk lies inside one tap, so a row chunk is 128 contiguous bytes), staged through LDS
+// together with a pre-packed weight tile, and contracted with v_mfma_f32_32x32x2_f32 (exact fp32,
+// k-ordered fma chain).  The transposed direction runs as s*s parity classes (blockIdx.y), each a
+// dense GEMM over only the taps that hit that output parity (no zero-stuffing).
+//
+// Tiling: 256 threads = 4 waves (2x2), block tile BM x BN x 32, each wave (BM/2)x(BN/2) as 32x32
+// MFMA tiles; double-buffered LDS with the next tile's global loads issued before the MFMA block
+// and written after it (register staging), one barrier per K tile; 2 blocks per CU.
+//
+// K ordering trick: inside a 32-deep chunk lane-half h of MFMA step (jj,e) contracts
+// k = 4*(2*jj+h)+e for BOTH operands, so every lane fetches its 4 consecutive k of a row / column
+// with one ds_read_b128 (A rows padded to 36 floats and weights packed [k/4][n][4]: both
+// conflict-free).
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "cgs_internal.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+static constexpr int BK = CGS_BK;
+static constexpr int LDA = BK + 4;   // padded A row (floats): 144 B, keeps b128 reads conflict-free
+
+// ------------------------------------------------------------------------------------------------
+// geometry
+// ------------------------------------------------------------------------------------------------
+void cgs_geom_F(const CgsLayer& L, IgemmParams& p) {
+    p.Hin = L.Hb; p.Win = L.Wb; p.Cred = L.Cb;
+    p.Hout = L.Hs; p.Wout = L.Ws; p.N = L.Cs; p.Np = cgs_round_up(L.Cs, 64);
+    p.S = L.sh; p.So = 1; p.dstep = 1; p.kstep = 1; p.nclasses = 1;
+    IgemmClass& c = p.cls[0];
+    c.R = L.Hs; c.C = L.Ws; c.py = 0; c.px = 0; c.nty = L.kh; c.ntx = L.kw;
+    c.dy0 = -cgs_same_pad_before(L.Hb, L.kh, L.sh); c.dx0 = -cgs_same_pad_before(L.Wb, L.kw, L.sw);
+    c.ky0 = 0; c.kx0 = 0; c.K = L.kh * L.kw * L.Cb; c.w_off = 0;
+}
+
+void cgs_geom_T(const CgsLayer& L, IgemmParams& p) {
+    p.Hin = L.Hs; p.Win = L.Ws; p.Cred = L.Cs;
+    p.Hout = L.Hb; p.Wout = L.Wb; p.N = L.Cb; p.Np = cgs_round_up(L.Cb, 64);
+    p.S = 1; p.So = L.sh; p.dstep = -1; p.kstep = L.sh; p.nclasses = L.sh * L.sw;
+    const int pt = cgs_same_pad_before(L.Hb, L.kh, L.sh), pl = cgs_same_pad_before(L.Wb, L.kw, L.sw);
+    int off = 0;
+    for (int py = 0; py < L.sh; ++py)
+        for (int px = 0; px < L.sw; ++px) {
+            IgemmClass& c = p.cls[py * L.sw + px];
+            c.py = py; c.px = px;
+            c.R = py < L.Hb ? (L.Hb - py + L.sh - 1) / L.sh : 0;
+            c.C = px < L.Wb ? (L.Wb - px + L.sw - 1) / L.sw : 0;
+            c.ky0 = (py + pt) % L.sh; c.kx0 = (px + pl) % L.sw;
+            c.nty = c.ky0 < L.kh ? (L.kh - c.ky0 + L.sh - 1) / L.sh : 0;
+            c.ntx = c.kx0 < L.kw ? (L.kw - c.kx0 + L.sw - 1) / L.sw : 0;
+            c.dy0 = (py + pt - c.ky0) / L.sh; c.dx0 = (px + pl - c.kx0) / L.sw;
+            c.K = c.nty * c.ntx * L.Cs; c.w_off = off;
+            off += cgs_round_up(c.K, BK) * p.Np;
+        }
+}
+
+size_t cgs_packed_floats(const IgemmParams& p) {
+    size_t n = 0;
+    for (int i = 0; i < p.nclasses; ++i) n += (size_t)cgs_round_up(p.cls[i].K, BK) * p.Np;
+    return n;
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight packing: w[kh][kw][Cb][Cs] -> per class [Kpad/4][Np][4], zero padded
+// ------------------------------------------------------------------------------------------------
+__global__ void pack_weights_kernel(IgemmParams p, const float* __restrict__ w, float* __restrict__ packed,
+                                    int kw, int Cb, int Cs, int dirT) {
+    const IgemmClass& c = p.cls[blockIdx.y];
+    const int Kpad = (c.K + BK - 1) / BK * BK;
+    const size_t total = (size_t)Kpad * p.Np;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int e = (int)(i & 3);
+        const int n = (int)((i >> 2) % p.Np);
+        const int k = (int)((i >> 2) / p.Np) * 4 + e;
+        float v = 0.f;
+        if (k < c.K && n < p.N) {
+            const int t = k / p.Cred, ci = k - t * p.Cred;
+            const int ta = t / c.ntx, tb = t - ta * c.ntx;
+            const int tap = (c.ky0 + ta * p.kstep) * kw + (c.kx0 + tb * p.kstep);
+            const size_t src = dirT ? ((size_t)tap * Cb + n) * Cs + ci      // reduce over Cs, n indexes Cb
+                                    : ((size_t)tap * Cb + ci) * Cs + n;     // reduce over Cb, n indexes Cs
+            v = w[src];
+        }
+        packed[c.w_off + i] = v;
+    }
+}
+
+int cgs_pack_weights(const IgemmParams& p, const CgsLayer& L, bool dirT, const float* w, float* packed, hipStream_t s) {
+    size_t mx = 0;
+    for (int i = 0; i < p.nclasses; ++i) {
+        size_t n = (size_t)cgs_round_up(p.cls[i].K, BK) * p.Np;
+        if (n > mx) mx = n;
+    }
+    if (mx == 0) return CGS_OK;
+    int blocks = (int)((mx + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks, p.nclasses), dim3(256), 0, s, p, w, packed, L.kw, L.Cb, L.Cs,
+                       dirT ? 1 : 0);
+    CGS_CHECK_LAUNCH("pack_weights");
+    return CGS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// main kernel
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float epilogue_apply(float v, int mode, float a, float b) {
+    switch (mode) {
+        case CGS_EPI_LRELU: return fmaxf(v, 0.2f * v);
+        case CGS_EPI_AFFINE_RELU: return fmaxf(fmaf(a, v, b), 0.f);
+        case CGS_EPI_TANH: return tanhf(v);
+        default: return v;
+    }
+}
+
+template <int BM, int BN, bool VEC>
+__global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
+    constexpr int TM = BM / 64, TN = BN / 64;     // 32x32 MFMA tiles per wave
+    constexpr int AI = BM / 32, BI = BN / 32;     // float4 staged per thread (A rows / B columns)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                              // [2][BM][LDA]
+    float* Bs = smem + 2 * BM * LDA;               // [2][BK/4][BN][4]
+    int* rowpix = (int*)(Bs + 2 * BK * BN);        // [BM] output pixel index of each tile row, -1 = out of range
+
+    const IgemmClass& c = p.cls[blockIdx.y];
+    const int RC = c.R * c.C;
+    const int M = p.B * RC;
+    const int nblk_n = p.Np / BN;
+    const int mb = blockIdx.x / nblk_n, nb = blockIdx.x - mb * nblk_n;
+    const int m0 = mb * BM, n0 = nb * BN;
+    if (m0 >= M) return;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int h = lane >> 5, j = lane & 31;
+
+    if (tid < BM) {
+        const int m = m0 + tid;
+        int pix = -1;
+        if (m < M) {
+            const int b = m / RC, rem = m - b * RC;
+            const int r = rem / c.C, cc = rem - r * c.C;
+            pix = (b * p.Hout + r * p.So + c.py) * p.Wout + cc * p.So + c.px;
+        }
+        rowpix[tid] = pix;
+    }
+
+    // A staging: thread -> k-quad aq of rows ar + 32*i
+    const int aq = tid & 7, ar = tid >> 3;
+    int a_base[AI], a_iy[AI], a_ix[AI];
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+        const int m = m0 + ar + 32 * i;
+        if (m < M) {
+            const int b = m / RC, rem = m - b * RC;
+            const int r = rem / c.C, cc = rem - r * c.C;
+            a_base[i] = b * p.Hin * p.Win; a_iy[i] = r * p.S + c.dy0; a_ix[i] = cc * p.S + c.dx0;
+        } else {
+            a_base[i] = 0; a_iy[i] = -(1 << 20); a_ix[i] = 0;    // always out of range -> zeros
+        }
+    }
+    const float* wsrc = p.wp + c.w_off;
+    const int nk = (c.K + BK - 1) / BK;
+
+    f32x4 ra[AI], rb[BI];
+    // global -> registers for K tile kt_ (issued early; consumed by STORE_TILE after the MFMA block)
+#define LOAD_TILE(kt_)                                                                                          \
+    do {                                                                                                        \
+        if constexpr (VEC) {                                                                                    \
+            const int k0 = (kt_) * BK;                                                                          \
+            const int t = k0 / p.Cred, ci = k0 - t * p.Cred + aq * 4;                                           \
+            const int ta = t / c.ntx, tb = t - ta * c.ntx;                                                      \
+            const int dy = ta * p.dstep, dx = tb * p.dstep;                                                     \
+            _Pragma("unroll") for (int i = 0; i < AI; ++i) {                                                    \
+                const int iy = a_iy[i] + dy, ix = a_ix[i] + dx;                                                 \
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};                                                                 \
+                if ((unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win)                           \
+                    v = *(const f32x4*)(p.in + ((size_t)(a_base[i] + iy * p.Win + ix) * p.Cred + ci));          \
+                ra[i] = v;                                                                                      \
+            }                                                                                                   \
+        } else {                                                                                                \
+            _Pragma("unroll") for (int i = 0; i < AI; ++i) {                                                    \
+                float v[4];                                                                                     \
+                _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                 \
+                    const int k = (kt_) * BK + aq * 4 + e;                                                      \
+                    float x = 0.f;                                                                              \
+                    if (k < c.K) {                                                                              \
+                        const int t = k / p.Cred, ci = k - t * p.Cred;                                          \
+                        const int ta = t / c.ntx, tb = t - ta * c.ntx;                                          \
+                        const int iy = a_iy[i] + ta * p.dstep, ix = a_ix[i] + tb * p.dstep;                     \
+                        if ((unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win)                   \
+                            x = p.in[(size_t)(a_base[i] + iy * p.Win + ix) * p.Cred + ci];                      \
+                    }                                                                                           \
+                    v[e] = x;                                                                                   \
+                }                                                                                               \
+                ra[i] = f32x4{v[0], v[1], v[2], v[3]};                                                          \
+            }                                                                                                   \
+        }                                                                                                       \
+        _Pragma("unroll") for (int i = 0; i < BI; ++i) {                                                        \
+            const int idx = tid + 256 * i;                                                                      \
+            const int kq = idx / BN, n = idx - kq * BN;                                                         \
+            rb[i] = *(const f32x4*)(wsrc + ((size_t)((kt_) * (BK / 4) + kq) * p.Np + n0 + n) * 4);            \
+        }                                                                                                       \
+    } while (0)
+#define STORE_TILE(buf_)                                                                                        \
+    do {                                                                                                        \
+        float* a_ = As + (buf_) * BM * LDA;                                                                     \
+        float* b_ = Bs + (buf_) * BK * BN;                                                                      \
+        _Pragma("unroll") for (int i = 0; i < AI; ++i) *(f32x4*)(a_ + (ar + 32 * i) * LDA + aq * 4) = ra[i];    \
+        _Pragma("unroll") for (int i = 0; i < BI; ++i) *(f32x4*)(b_ + (tid + 256 * i) * 4) = rb[i];             \
+    } while (0)
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+
+    if (nk > 0) {
+        LOAD_TILE(0);
+        STORE_TILE(0);
+    }
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) LOAD_TILE(kt + 1);          // global loads in flight under the MFMA block
+        const float* a = As + buf * BM * LDA + (wm * (BM / 2) + j) * LDA;
+        const float* b = Bs + buf * BK * BN + (wn * (BN / 2) + j) * 4;
+#pragma unroll
+        for (int jj = 0; jj < BK / 8; ++jj) {
+            const int kq = 2 * jj + h;
+            f32x4 fa[TM], fb[TN];
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) fa[tm] = *(const f32x4*)(a + tm * 32 * LDA + kq * 4);
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) fb[tn] = *(const f32x4*)(b + (kq * BN + tn * 32) * 4);
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) {
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[tm].x, fb[tn].x, acc[tm][tn], 0, 0, 0);
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[tm].y, fb[tn].y, acc[tm][tn], 0, 0, 0);
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[tm].z, fb[tn].z, acc[tm][tn], 0, 0, 0);
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[tm].w, fb[tn].w, acc[tm][tn], 0, 0, 0);
+                }
+        }
+        if (kt + 1 < nk) STORE_TILE(buf ^ 1);
+        __syncthreads();
+    }
+
+#undef LOAD_TILE
+#undef STORE_TILE
+    // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int n = n0 + wn * (BN / 2) + tn * 32 + j;
+        if (n >= p.N) continue;
+        const float bias = p.bias ? p.bias[n] : 0.f;
+        float ea = 1.f, eb = 0.f;
+        if (p.epilogue == CGS_EPI_AFFINE_RELU) { ea = p.ep_a[n]; eb = p.ep_b[n]; }
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * (BM / 2) + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int pix = rowpix[row];
+                if (pix >= 0) p.out[(size_t)pix * p.N + n] = epilogue_apply(acc[tm][tn][r] + bias, p.epilogue, ea, eb);
+            }
+    }
+}
+
+template <int BM, int BN, bool VEC>
+static int launch_cfg(const IgemmParams& p, hipStream_t s) {
+    constexpr size_t smem = (size_t)(2 * BM * LDA + 2 * BK * BN) * sizeof(float) + BM * sizeof(int);
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)igemm_kernel<BM, BN, VEC>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return cgs_set_error(CGS_ELAUNCH, "igemm smem attr: %s", hipGetErrorString(e));
+        attr_done = true;
+    }
+    long maxM = 0;
+    for (int i = 0; i < p.nclasses; ++i) {
+        long m = (long)p.B * p.cls[i].R * p.cls[i].C;
+        if (m > maxM) maxM = m;
+    }
+    if (maxM == 0) return CGS_OK;
+    const long gx = (maxM + BM - 1) / BM * (p.Np / BN);
+    if (gx > 0x7fffffffL) return cgs_set_error(CGS_EINVAL, "igemm: grid too large");
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, VEC>), dim3((unsigned)gx, p.nclasses), dim3(256), smem, s, p);
+    CGS_CHECK_LAUNCH("igemm");
+    return CGS_OK;
+}
+
+int cgs_igemm_launch(const IgemmParams& p, hipStream_t s) {
+    if ((long)p.B * p.Hout * p.Wout > 0x7fffffffL || (long)p.B * p.Hin * p.Win > 0x7fffffffL)
+        return cgs_set_error(CGS_EINVAL, "igemm: tensor has more than 2^31 pixels");
+    const bool vec = (p.Cred % BK) == 0;
+    const bool wide = (p.Np % 128) == 0;
+    if (vec) return wide ? launch_cfg<128, 128, true>(p, s) : launch_cfg<128, 64, true>(p, s);
+    return wide ? launch_cfg<128, 128, false>(p, s) : launch_cfg<128, 64, false>(p, s);
+}

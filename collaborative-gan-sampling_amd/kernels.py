@@ -1,0 +1,261 @@
+"""Tensor-level wrappers over the C ABI (include/cgs_hip.h): torch CUDA(ROCm) tensors in, tensors out.
+
+PyTorch is plumbing only here -- device memory (``torch.empty``), the current HIP stream, and
+nothing else: every FLOP below runs in libcgs_hip.so.  Activations are NHWC fp32 contiguous; weight
+layouts are the reference's (nsgan/ops.py:39,51,76).  Packed-weight workspaces are cached per
+(weight storage, version, op): frozen weights are packed once.
+"""
+import math
+import weakref
+
+import torch
+
+from . import lib as L
+
+LEAK = 0.2      # nsgan/ops.py:69
+BN_EPS = 1e-5   # nsgan/ops.py:23
+
+
+def _chk(t, name):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise L.CgsError(f"{name}: expected a contiguous fp32 tensor on the GPU, got "
+                         f"{type(t).__name__} {getattr(t, 'dtype', None)} {getattr(t, 'device', None)}")
+    return t
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def same_out(size, stride):
+    """nsgan/ops.py:28-29."""
+    return int(math.ceil(float(size) / float(stride)))
+
+
+class _WsCache:
+    """Packed-weight workspaces, keyed by the weight tensor (identity + version)."""
+
+    def __init__(self):
+        self._d = {}
+
+    def get(self, w, op, kh, kw, sh, sw, cin, cout):
+        key = (w.data_ptr(), op, kh, kw, sh, sw, cin, cout, w.device.index)
+        hit = self._d.get(key)
+        if hit is not None and hit[0]() is w and hit[1] == w._version:
+            return hit[2], 1
+        nbytes = L.conv_ws_bytes(op, kh, kw, sh, sw, cin, cout)
+        ws = torch.empty(max(nbytes, 16) // 4, dtype=torch.float32, device=w.device)
+        if len(self._d) > 512:
+            self._d.clear()
+        self._d[key] = (weakref.ref(w), w._version, ws)
+        return ws, 0
+
+    def clear(self):
+        self._d.clear()
+
+
+WS = _WsCache()
+_bn_ws = {}
+
+
+def _bn_workspace(M, C, device):
+    key = (C, device.index)
+    ws = _bn_ws.get(key)
+    if ws is None:
+        ws = torch.empty(L.bn_ws_bytes(M, C) // 4, dtype=torch.float32, device=device)
+        _bn_ws[key] = ws
+    return ws
+
+
+# ----------------------------------------------------------------------------- conv family
+def conv2d_fwd(x, w, bias, sh=2, sw=2, epilogue=L.EPI_NONE, ep_a=None, ep_b=None, out=None):
+    """tf.nn.conv2d 'SAME' + bias (+ fused epilogue).  nsgan/ops.py:41-44."""
+    _chk(x, "x"); _chk(w, "w")
+    B, H, W, Cin = x.shape
+    kh, kw, Cin2, Cout = w.shape
+    if Cin2 != Cin:
+        raise L.CgsError(f"conv2d: weight Cin {Cin2} != input channels {Cin}")
+    y = out if out is not None else torch.empty((B, same_out(H, sh), same_out(W, sw), Cout), dtype=torch.float32, device=x.device)
+    ws, pre = WS.get(w, L.CONV_FWD, kh, kw, sh, sw, Cin, Cout)
+    L.call("cgs_conv2d_nhwc_fwd", _ptr(x), _ptr(w), _ptr(bias), _ptr(y), B, H, W, Cin, Cout, kh, kw, sh, sw,
+           epilogue, _ptr(ep_a), _ptr(ep_b), _ptr(ws), ws.numel() * 4, pre, _stream())
+    return y
+
+
+def conv2d_bwd_data(dy, w, in_hw, sh=2, sw=2, out=None):
+    """Input gradient of conv2d_fwd (Conv2DBackpropInput; sampling/collaborator.py:31)."""
+    _chk(dy, "dy"); _chk(w, "w")
+    kh, kw, Cin, Cout = w.shape
+    B = dy.shape[0]
+    H, W = in_hw
+    dx = out if out is not None else torch.empty((B, H, W, Cin), dtype=torch.float32, device=dy.device)
+    ws, pre = WS.get(w, L.CONV_BWD_DATA, kh, kw, sh, sw, Cin, Cout)
+    L.call("cgs_conv2d_nhwc_bwd_data", _ptr(dy), _ptr(w), _ptr(dx), B, H, W, Cin, Cout, kh, kw, sh, sw,
+           _ptr(ws), ws.numel() * 4, pre, _stream())
+    return dx
+
+
+def deconv2d_fwd(x, w, bias, out_hw, sh=2, sw=2, epilogue=L.EPI_NONE, ep_a=None, ep_b=None, out=None):
+    """tf.nn.conv2d_transpose (default 'SAME') + bias (+ fused epilogue).  nsgan/ops.py:55,61-62."""
+    _chk(x, "x"); _chk(w, "w")
+    B, H, W, Cin = x.shape
+    kh, kw, Cout, Cin2 = w.shape
+    if Cin2 != Cin:
+        raise L.CgsError(f"deconv2d: weight Cin {Cin2} != input channels {Cin}")
+    Ho, Wo = out_hw
+    y = out if out is not None else torch.empty((B, Ho, Wo, Cout), dtype=torch.float32, device=x.device)
+    ws, pre = WS.get(w, L.DECONV_FWD, kh, kw, sh, sw, Cin, Cout)
+    L.call("cgs_deconv2d_nhwc_fwd", _ptr(x), _ptr(w), _ptr(bias), _ptr(y), B, H, W, Cin, Ho, Wo, Cout, kh, kw, sh, sw,
+           epilogue, _ptr(ep_a), _ptr(ep_b), _ptr(ws), ws.numel() * 4, pre, _stream())
+    return y
+
+
+def deconv2d_bwd_data(dy, w, in_hw, sh=2, sw=2, out=None):
+    """Input gradient of deconv2d_fwd: a strided 'SAME' conv of dy with the deconv weights."""
+    _chk(dy, "dy"); _chk(w, "w")
+    kh, kw, Cout, Cin = w.shape
+    B, Ho, Wo, _ = dy.shape
+    H, W = in_hw
+    dx = out if out is not None else torch.empty((B, H, W, Cin), dtype=torch.float32, device=dy.device)
+    ws, pre = WS.get(w, L.DECONV_BWD_DATA, kh, kw, sh, sw, Cin, Cout)
+    L.call("cgs_deconv2d_nhwc_bwd_data", _ptr(dy), _ptr(w), _ptr(dx), B, H, W, Cin, Ho, Wo, Cout, kh, kw, sh, sw,
+           _ptr(ws), ws.numel() * 4, pre, _stream())
+    return dx
+
+
+def linear_fwd(x, w, bias, epilogue=L.EPI_NONE, out=None):
+    """tf.matmul(x, Matrix) + bias.  nsgan/ops.py:81-83."""
+    _chk(x, "x"); _chk(w, "w")
+    B, K = x.shape
+    K2, N = w.shape
+    if K2 != K:
+        raise L.CgsError(f"linear: Matrix rows {K2} != input features {K}")
+    y = out if out is not None else torch.empty((B, N), dtype=torch.float32, device=x.device)
+    if N == 1:
+        L.call("cgs_linear_fwd", _ptr(x), _ptr(w), _ptr(bias), _ptr(y), B, K, N, epilogue, None, 0, 0, _stream())
+        return y
+    ws, pre = WS.get(w, L.CONV_FWD, 1, 1, 1, 1, K, N)
+    L.call("cgs_linear_fwd", _ptr(x), _ptr(w), _ptr(bias), _ptr(y), B, K, N, epilogue, _ptr(ws), ws.numel() * 4, pre, _stream())
+    return y
+
+
+def linear_bwd_data(dy, w, out=None):
+    _chk(dy, "dy"); _chk(w, "w")
+    B, N = dy.shape
+    K = w.shape[0]
+    dx = out if out is not None else torch.empty((B, K), dtype=torch.float32, device=dy.device)
+    if N == 1:
+        L.call("cgs_linear_bwd_data", _ptr(dy), _ptr(w), _ptr(dx), B, K, N, None, 0, 0, _stream())
+        return dx
+    ws, pre = WS.get(w, L.CONV_BWD_DATA, 1, 1, 1, 1, K, N)
+    L.call("cgs_linear_bwd_data", _ptr(dy), _ptr(w), _ptr(dx), B, K, N, _ptr(ws), ws.numel() * 4, pre, _stream())
+    return dx
+
+
+# ----------------------------------------------------------------------------- batch norm / activations
+def bn_train_lrelu_fwd(x, gamma, beta, leak=LEAK, eps=BN_EPS, out=None):
+    """Batch-statistics bn (+ lrelu; leak=1 -> plain bn).  Returns (y, mean, invstd).  nsgan/ops.py:19-26."""
+    _chk(x, "x")
+    C = x.shape[-1]
+    M = x.numel() // C
+    y = out if out is not None else torch.empty_like(x)
+    mean = torch.empty(C, dtype=torch.float32, device=x.device)
+    invstd = torch.empty(C, dtype=torch.float32, device=x.device)
+    ws = _bn_workspace(M, C, x.device)
+    L.call("cgs_bn_train_lrelu_fwd", _ptr(x), _ptr(gamma), _ptr(beta), eps, leak, _ptr(y), _ptr(mean), _ptr(invstd),
+           M, C, _ptr(ws), ws.numel() * 4, _stream())
+    return y, mean, invstd
+
+
+def bn_train_lrelu_bwd_data(dy, x, gamma, beta, mean, invstd, leak=LEAK, out=None):
+    _chk(dy, "dy"); _chk(x, "x")
+    C = x.shape[-1]
+    M = x.numel() // C
+    dx = out if out is not None else torch.empty_like(x)
+    ws = _bn_workspace(M, C, x.device)
+    L.call("cgs_bn_train_lrelu_bwd_data", _ptr(dy), _ptr(x), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(invstd), leak,
+           _ptr(dx), M, C, _ptr(ws), ws.numel() * 4, _stream())
+    return dx
+
+
+def bn_fold(gamma, beta, moving_mean, moving_var, eps=BN_EPS):
+    """Inference-mode bn as a per-channel affine (a, b).  nsgan/GAN.py:87,94."""
+    C = gamma.numel()
+    a = torch.empty(C, dtype=torch.float32, device=gamma.device)
+    b = torch.empty(C, dtype=torch.float32, device=gamma.device)
+    L.call("cgs_bn_fold", _ptr(gamma), _ptr(beta), _ptr(moving_mean), _ptr(moving_var), eps, _ptr(a), _ptr(b), C, _stream())
+    return a, b
+
+
+def affine_relu_fwd(x, a, b, out=None):
+    _chk(x, "x")
+    C = x.shape[-1]
+    y = out if out is not None else torch.empty_like(x)
+    L.call("cgs_affine_relu_fwd", _ptr(x), _ptr(a), _ptr(b), _ptr(y), x.numel() // C, C, _stream())
+    return y
+
+
+def affine_relu_bwd(dy, y, a, out=None):
+    _chk(dy, "dy"); _chk(y, "y")
+    C = y.shape[-1]
+    dx = out if out is not None else torch.empty_like(y)
+    L.call("cgs_affine_relu_bwd", _ptr(dy), _ptr(y), _ptr(a), _ptr(dx), y.numel() // C, C, _stream())
+    return dx
+
+
+def lrelu_fwd(x, leak=LEAK, out=None):
+    _chk(x, "x")
+    y = out if out is not None else torch.empty_like(x)
+    L.call("cgs_lrelu_fwd", _ptr(x), leak, _ptr(y), x.numel(), _stream())
+    return y
+
+
+def lrelu_bwd(dy, y, leak=LEAK, out=None):
+    _chk(dy, "dy"); _chk(y, "y")
+    dx = out if out is not None else torch.empty_like(y)
+    L.call("cgs_lrelu_bwd", _ptr(dy), _ptr(y), leak, _ptr(dx), y.numel(), _stream())
+    return dx
+
+
+def tanh_fwd(x, out=None):
+    _chk(x, "x")
+    y = out if out is not None else torch.empty_like(x)
+    L.call("cgs_tanh_fwd", _ptr(x), _ptr(y), x.numel(), _stream())
+    return y
+
+
+def tanh_bwd(dy, y, out=None):
+    _chk(dy, "dy"); _chk(y, "y")
+    dx = out if out is not None else torch.empty_like(y)
+    L.call("cgs_tanh_bwd", _ptr(dy), _ptr(y), _ptr(dx), y.numel(), _stream())
+    return dx
+
+
+# ----------------------------------------------------------------------------- refinement-loop scalars
+def bce_ones_grad_rowmean(logits, dlogits=None, logit_mean=None):
+    """d softplus(-l)/dl = sigmoid(l) - 1 and the per-sample mean logit (collaborator.py:31-37)."""
+    _chk(logits, "logits")
+    B = logits.shape[0]
+    P = logits.numel() // B
+    dl = dlogits if dlogits is not None else torch.empty_like(logits)
+    lm = logit_mean if logit_mean is not None else torch.empty(B, dtype=torch.float32, device=logits.device)
+    L.call("cgs_bce_ones_grad_rowmean", _ptr(logits), _ptr(dl), _ptr(lm), B, P, _stream())
+    return dl, lm
+
+
+def refine_update(theta, m, g, rate, alpha, first, vmin=None, vmax=None):
+    """In-place momentum / sgd step on theta (+ optional clip).  policy.py:27-37, collaborator.py:66-70."""
+    use_clip = 1 if (vmin and vmax) else 0          # the reference's truthiness test (quirk Q5)
+    L.call("cgs_refine_update", _ptr(theta), _ptr(m), _ptr(g), rate, alpha, 1 if first else 0, use_clip,
+           float(vmin or 0.0), float(vmax or 0.0), theta.numel(), _stream())
+
+
+def refine_select(theta, logit, forced, step_index, best_theta, best_logit, best_step):
+    """Row-wise best-sample select.  collaborator.py:76-83."""
+    B = theta.shape[0]
+    L.call("cgs_refine_select", _ptr(theta), _ptr(logit), _ptr(forced), step_index, _ptr(best_theta), _ptr(best_logit),
+           _ptr(best_step), B, theta.numel() // B, _stream())

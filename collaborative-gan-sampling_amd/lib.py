@@ -1,0 +1,79 @@
+"""ctypes binding of libcgs_hip.so -- the C ABI declared in include/cgs_hip.h.
+
+The library is built in-tree by ``__graft_entry__.build()`` (or ``make -C csrc``).  Loading is
+lazy; if the shared object is missing every device op fails loudly (no fallback path exists).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcgs_hip.so")
+
+OK, EINVAL, EWORKSPACE, ELAUNCH = 0, -1, -2, -3
+EPI_NONE, EPI_LRELU, EPI_AFFINE_RELU, EPI_TANH = 0, 1, 2, 3
+CONV_FWD, CONV_BWD_DATA, DECONV_FWD, DECONV_BWD_DATA = 0, 1, 2, 3
+
+_p, _i, _f, _z = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+
+# name -> (restype, argtypes); mirrors include/cgs_hip.h one to one
+SIGNATURES = {
+    "cgs_version": (_i, []),
+    "cgs_last_error": (C.c_char_p, []),
+    "cgs_conv_ws_bytes": (_z, [_i] * 7),
+    "cgs_conv2d_nhwc_fwd": (_i, [_p] * 4 + [_i] * 9 + [_i, _p, _p, _p, _z, _i, _p]),
+    "cgs_conv2d_nhwc_bwd_data": (_i, [_p] * 3 + [_i] * 9 + [_p, _z, _i, _p]),
+    "cgs_deconv2d_nhwc_fwd": (_i, [_p] * 4 + [_i] * 11 + [_i, _p, _p, _p, _z, _i, _p]),
+    "cgs_deconv2d_nhwc_bwd_data": (_i, [_p] * 3 + [_i] * 11 + [_p, _z, _i, _p]),
+    "cgs_linear_fwd": (_i, [_p] * 4 + [_i] * 4 + [_p, _z, _i, _p]),
+    "cgs_linear_bwd_data": (_i, [_p] * 3 + [_i] * 3 + [_p, _z, _i, _p]),
+    "cgs_bn_ws_bytes": (_z, [_i, _i]),
+    "cgs_bn_train_lrelu_fwd": (_i, [_p, _p, _p, _f, _f, _p, _p, _p, _i, _i, _p, _z, _p]),
+    "cgs_bn_train_lrelu_bwd_data": (_i, [_p] * 6 + [_f, _p, _i, _i, _p, _z, _p]),
+    "cgs_bn_fold": (_i, [_p] * 4 + [_f, _p, _p, _i, _p]),
+    "cgs_affine_relu_fwd": (_i, [_p] * 4 + [_i, _i, _p]),
+    "cgs_affine_relu_bwd": (_i, [_p] * 4 + [_i, _i, _p]),
+    "cgs_lrelu_fwd": (_i, [_p, _f, _p, _z, _p]),
+    "cgs_lrelu_bwd": (_i, [_p, _p, _f, _p, _z, _p]),
+    "cgs_tanh_fwd": (_i, [_p, _p, _z, _p]),
+    "cgs_tanh_bwd": (_i, [_p, _p, _p, _z, _p]),
+    "cgs_bce_ones_grad_rowmean": (_i, [_p, _p, _p, _i, _i, _p]),
+    "cgs_refine_update": (_i, [_p, _p, _p, _f, _f, _i, _i, _f, _f, _z, _p]),
+    "cgs_refine_select": (_i, [_p, _p, _p, _i, _p, _p, _p, _i, _i, _p]),
+}
+
+_lib = None
+
+
+class CgsError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libcgs_hip.so (once) and type its entry points.  Raises if it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise CgsError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(there is no CPU fallback for the device path)")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)          # AttributeError if the ABI and this table diverge
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def call(name, *args):
+    """Call an int-returning entry point; raise CgsError with the library's message on failure."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != OK:
+        raise CgsError(f"{name} failed ({rc}): {lib.cgs_last_error().decode()}")
+
+
+def conv_ws_bytes(op, kh, kw, sh, sw, cin, cout):
+    return int(load().cgs_conv_ws_bytes(op, kh, kw, sh, sw, cin, cout))
+
+
+def bn_ws_bytes(m, c):
+    return int(load().cgs_bn_ws_bytes(m, c))

@@ -1,0 +1,146 @@
+/*
+ * cgs_hip.h -- C ABI of libcgs_hip.so: the MI355X (gfx950) kernels under the
+ * collaborative-sampling refinement hot path.
+ *
+ * The reference (vita-epfl/collaborative-gan-sampling) has no FFI layer: its hot
+ * path (sampling/collaborator.py:26-88) is made of stock TensorFlow ops reached
+ * through nsgan/ops.py.  Each entry point below replaces one of those TF call
+ * sites (cited per function; paths are under the reference root).  The host
+ * side that mirrors the reference's Python operator / sampler classes sits on
+ * top of this ABI (collaborative-gan-sampling_amd/ops.py, sampling/ *.py) and
+ * binds it with ctypes; INTEGRATION.md shows the binding.
+ *
+ * Conventions:
+ *   - plain C: raw DEVICE pointers + ints; no torch / hip types in signatures
+ *     (`stream` is a hipStream_t passed as void*; NULL = the null stream);
+ *   - activations NHWC fp32; conv weights HWIO [kh,kw,Cin,Cout]
+ *     (nsgan/ops.py:39); deconv weights [kh,kw,Cout,Cin] (nsgan/ops.py:51);
+ *     linear weights [in,out] (nsgan/ops.py:76);
+ *   - TF 'SAME' padding everywhere (extra pixel bottom/right);
+ *   - caller allocates every output and workspace; nothing is allocated or
+ *     freed inside; calls are asynchronous on `stream` and graph-capturable;
+ *   - return 0 on success, a negative CGS_E* code otherwise; never throws;
+ *     cgs_last_error() gives a thread-local message.
+ */
+#ifndef CGS_HIP_H
+#define CGS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CGS_OK 0
+#define CGS_EINVAL (-1)   /* bad argument / unsupported shape */
+#define CGS_EWORKSPACE (-2) /* workspace too small */
+#define CGS_ELAUNCH (-3)  /* HIP launch error */
+
+/* epilogues fused into the conv / deconv / linear kernels (applied after +bias) */
+#define CGS_EPI_NONE 0
+#define CGS_EPI_LRELU 1        /* max(v, leak*v), leak = 0.2        nsgan/ops.py:69-70            */
+#define CGS_EPI_AFFINE_RELU 2  /* relu(a[c]*v + b[c]) = inference-mode bn + relu, nsgan/GAN.py:96-98 */
+#define CGS_EPI_TANH 3         /* tanh(v)                            nsgan/GAN.py:100              */
+
+/* which transposition of the weights a conv-family call contracts over */
+#define CGS_CONV_FWD 0          /* tf.nn.conv2d                        nsgan/ops.py:41 */
+#define CGS_CONV_BWD_DATA 1     /* its input gradient (tf.gradients)   sampling/collaborator.py:31 */
+#define CGS_DECONV_FWD 2        /* tf.nn.conv2d_transpose              nsgan/ops.py:55 */
+#define CGS_DECONV_BWD_DATA 3   /* its input gradient                  sampling/collaborator.py:31 */
+
+int cgs_version(void);
+const char* cgs_last_error(void);
+
+/* Bytes of workspace a conv-family call needs for its packed copy of the weights
+ * (op = one of CGS_CONV_* above; Cin/Cout are those of the LAYER, i.e. of the
+ * forward op, for the backward variants too). */
+size_t cgs_conv_ws_bytes(int op, int kh, int kw, int sh, int sw, int Cin, int Cout);
+
+/* conv2d: y[B,Ho,Wo,Cout] = conv(x[B,H,W,Cin], w[kh,kw,Cin,Cout], stride, 'SAME') + bias, then epilogue.
+ * Replaces tf.nn.conv2d + tf.nn.bias_add at nsgan/ops.py:41-44 (Ho = ceil(H/sh)).
+ * ws/ws_bytes: see cgs_conv_ws_bytes; ws_prepacked != 0 means ws already holds the packed
+ * weights from an earlier call with the same w (frozen weights: pack once). bias may be NULL. */
+int cgs_conv2d_nhwc_fwd(const float* x, const float* w, const float* bias, float* y,
+                        int B, int H, int W, int Cin, int Cout, int kh, int kw, int sh, int sw,
+                        int epilogue, const float* ep_a, const float* ep_b,
+                        void* ws, size_t ws_bytes, int ws_prepacked, void* stream);
+
+/* conv2d backward-data: dx[B,H,W,Cin] = d/dx of the conv above applied to dy[B,Ho,Wo,Cout].
+ * Replaces the Conv2DBackpropInput node tf.gradients emits (sampling/collaborator.py:31). */
+int cgs_conv2d_nhwc_bwd_data(const float* dy, const float* w, float* dx,
+                             int B, int H, int W, int Cin, int Cout, int kh, int kw, int sh, int sw,
+                             void* ws, size_t ws_bytes, int ws_prepacked, void* stream);
+
+/* deconv2d: y[B,Ho,Wo,Cout] = conv2d_transpose(x[B,H,W,Cin], w[kh,kw,Cout,Cin], output_shape, stride) + bias,
+ * then epilogue.  Replaces tf.nn.conv2d_transpose + bias_add at nsgan/ops.py:55,61-62
+ * (requires H == ceil(Ho/sh), W == ceil(Wo/sw)). */
+int cgs_deconv2d_nhwc_fwd(const float* x, const float* w, const float* bias, float* y,
+                          int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int sh, int sw,
+                          int epilogue, const float* ep_a, const float* ep_b,
+                          void* ws, size_t ws_bytes, int ws_prepacked, void* stream);
+
+/* deconv2d backward-data: dx[B,H,W,Cin] from dy[B,Ho,Wo,Cout] (a strided 'SAME' conv with the deconv weights). */
+int cgs_deconv2d_nhwc_bwd_data(const float* dy, const float* w, float* dx,
+                               int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int sh, int sw,
+                               void* ws, size_t ws_bytes, int ws_prepacked, void* stream);
+
+/* linear: y[B,out] = x[B,in] @ w[in,out] + bias, then epilogue (NONE or LRELU).
+ * Replaces tf.matmul + bias at nsgan/ops.py:81-83.  ws as for conv (op CGS_CONV_FWD, kh=kw=1). */
+int cgs_linear_fwd(const float* x, const float* w, const float* bias, float* y, int B, int in, int out,
+                   int epilogue, void* ws, size_t ws_bytes, int ws_prepacked, void* stream);
+/* linear backward-data: dx[B,in] = dy[B,out] @ w^T   (ws: op CGS_CONV_BWD_DATA, kh=kw=1). */
+int cgs_linear_bwd_data(const float* dy, const float* w, float* dx, int B, int in, int out,
+                        void* ws, size_t ws_bytes, int ws_prepacked, void* stream);
+
+/* Batch-statistics batch norm (tf.contrib.layers.batch_norm(is_training=True), nsgan/ops.py:19-26)
+ * fused with the lrelu that follows it in D (nsgan/GAN.py:65,67).  x is [M,C] (M = B*H*W or B).
+ *   fwd : mean[c], invstd[c] = 1/sqrt(biased_var+eps) are written (saved for backward);
+ *         y = lrelu(gamma*(x-mean)*invstd + beta, leak)   (leak = 1 gives plain bn).
+ *   ws  : cgs_bn_ws_bytes(M, C) bytes of scratch for the two-stage deterministic reduction. */
+size_t cgs_bn_ws_bytes(int M, int C);
+int cgs_bn_train_lrelu_fwd(const float* x, const float* gamma, const float* beta, float eps, float leak,
+                           float* y, float* mean, float* invstd, int M, int C,
+                           void* ws, size_t ws_bytes, void* stream);
+/*   bwd : dx = gamma*invstd*(dy' - mean(dy') - xhat*mean(dy'*xhat)), dy' = dy*lrelu'(bn(x)),
+ *         the input gradient tf.gradients builds for the two ops (sampling/collaborator.py:31). */
+int cgs_bn_train_lrelu_bwd_data(const float* dy, const float* x, const float* gamma, const float* beta,
+                                const float* mean, const float* invstd, float leak, float* dx, int M, int C,
+                                void* ws, size_t ws_bytes, void* stream);
+
+/* Inference-mode bn folded to a per-channel affine (nsgan/GAN.py:87,94): a = gamma/sqrt(mv+eps), b = beta - a*mm. */
+int cgs_bn_fold(const float* gamma, const float* beta, const float* moving_mean, const float* moving_var,
+                float eps, float* a, float* b, int C, void* stream);
+/* y = relu(a[c]*x + b[c]) and its input gradient dx = dy*(y>0)*a[c]  (G-tail bn+relu, nsgan/GAN.py:96-98). */
+int cgs_affine_relu_fwd(const float* x, const float* a, const float* b, float* y, int M, int C, void* stream);
+int cgs_affine_relu_bwd(const float* dy, const float* y, const float* a, float* dx, int M, int C, void* stream);
+/* y = max(x, leak*x) and dx = dy*(y>0 ? 1 : leak)   (nsgan/ops.py:69-70). */
+int cgs_lrelu_fwd(const float* x, float leak, float* y, size_t n, void* stream);
+int cgs_lrelu_bwd(const float* dy, const float* y, float leak, float* dx, size_t n, void* stream);
+/* y = tanh(x), dx = dy*(1-y*y)   (nsgan/GAN.py:100). */
+int cgs_tanh_fwd(const float* x, float* y, size_t n, void* stream);
+int cgs_tanh_bwd(const float* dy, const float* y, float* dx, size_t n, void* stream);
+
+/* Loss seed: dlogit = sigmoid(logit) - 1 = d softplus(-logit)/d logit, the gradient of
+ * tf.nn.sigmoid_cross_entropy_with_logits(labels=1) summed over the batch (nsgan/GAN.py:176-177,
+ * sampling/collaborator.py:31), and the per-sample mean logit over P patch entries
+ * (sampling/collaborator.py:34-37).  logits is [B,P]. */
+int cgs_bce_ones_grad_rowmean(const float* logits, float* dlogits, float* logit_mean, int B, int P, void* stream);
+
+/* One refinement step's state update, fused (sampling/policy.py:31-37 momentum / :27-29 sgd,
+ * sampling/collaborator.py:66-70 clip):
+ *   m = first ? rate*g : alpha*m + rate*g ; theta -= m ; theta = clip(theta, vmin, vmax) if use_clip.
+ * alpha = 0 and first = 1 give sgd.  n = B*F elements. */
+int cgs_refine_update(float* theta, float* m, const float* g, float rate, float alpha, int first,
+                      int use_clip, float vmin, float vmax, size_t n, void* stream);
+/* Best-sample selection (sampling/collaborator.py:76-83): for each sample b
+ *   upd = forced ? forced[b] == step_index : logit[b] > best_logit[b]      (strict >)
+ *   best_logit[b], best_theta[b,:], best_step[b] = upd ? (logit[b], theta[b,:], step_index+1) : unchanged
+ * forced = the probabilistic-mode index vector (int32, device) or NULL for deterministic mode. */
+int cgs_refine_select(const float* theta, const float* logit, const int32_t* forced, int step_index,
+                      float* best_theta, float* best_logit, float* best_step, int B, int F, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CGS_HIP_H */

@@ -1,0 +1,215 @@
+"""Parity of every C-ABI kernel (through cgs_amd.kernels -> libcgs_hip.so) against the CPU oracle.
+fp32 tolerance: the MFMA contraction is an exact-fp32 k-ordered fma chain, the oracle a torch-CPU
+(MKL) contraction in another order -> |delta| <= 2e-5 * sqrt(K) * max|term| is ample; stated per test."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ops_ref as R
+
+
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def rnd(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).float()
+
+
+def close(got, want, tol):
+    got, want = got.detach().cpu().double(), want.detach().cpu().double()
+    err = (got - want).abs().max().item()
+    ref = want.abs().max().item() + 1e-30
+    assert err <= tol * ref, f"max|delta|={err:.3e} vs max|ref|={ref:.3e} (tol {tol})"
+
+
+CONV_CASES = [  # B,H,W,Cin,Cout,k,s
+    (3, 16, 16, 64, 128, 5, 2),      # vec path, BN=128
+    (2, 8, 8, 128, 64, 5, 2),        # vec path, BN=64
+    (5, 28, 28, 1, 64, 4, 2),        # mnist d_conv1: scalar path K=16
+    (2, 14, 14, 64, 128, 4, 2),      # mnist d_conv2
+    (3, 32, 32, 3, 64, 5, 2),        # dcgan d_h0: scalar path K=75
+    (2, 7, 9, 32, 40, 5, 2),         # odd sizes, N not a multiple of 64
+    (1, 6, 5, 32, 64, 3, 1),         # stride 1
+    (70, 4, 4, 256, 512, 5, 2),      # many images, M not a multiple of 128
+]
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,s", CONV_CASES)
+@pytest.mark.parametrize("epi", ["none", "lrelu"])
+def test_conv2d_fwd(B, H, W, Cin, Cout, k, s, epi):
+    from cgs_amd import kernels as K, lib
+    x, w, b = rnd((B, H, W, Cin), 1), rnd((k, k, Cin, Cout), 2, 0.05), rnd((Cout,), 3, 0.1)
+    want = R.conv2d(x, w, b, s, s)
+    if epi == "lrelu":
+        want = R.lrelu(want)
+    got = K.conv2d_fwd(x.to(dev()), w.to(dev()), b.to(dev()), s, s, lib.EPI_LRELU if epi == "lrelu" else lib.EPI_NONE)
+    assert got.shape == want.shape
+    close(got, want, 2e-5)
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,s", CONV_CASES)
+def test_conv2d_bwd_data(B, H, W, Cin, Cout, k, s):
+    from cgs_amd import kernels as K
+    x = rnd((B, H, W, Cin), 1).requires_grad_(True)
+    w = rnd((k, k, Cin, Cout), 2, 0.05)
+    y = R.conv2d(x, w, torch.zeros(Cout), s, s)
+    dy = rnd(tuple(y.shape), 4)
+    (y * dy).sum().backward()
+    got = K.conv2d_bwd_data(dy.to(dev()), w.to(dev()), (H, W), s, s)
+    close(got, x.grad, 2e-5)
+
+
+DECONV_CASES = [  # B,H,W,Cin,Ho,Wo,Cout,k,s
+    (3, 8, 8, 256, 16, 16, 128, 5, 2),
+    (2, 16, 16, 128, 32, 32, 64, 5, 2),
+    (2, 16, 16, 64, 32, 32, 3, 5, 2),     # small-N VALU kernel
+    (4, 14, 14, 64, 28, 28, 1, 4, 2),     # mnist g_dc4
+    (4, 7, 7, 128, 14, 14, 64, 4, 2),     # mnist g_dc3
+    (2, 4, 5, 32, 7, 9, 48, 5, 2),        # odd output
+    (2, 4, 5, 32, 7, 9, 3, 5, 2),         # odd output, N=3 -> MFMA fallback
+    (2, 6, 5, 32, 6, 5, 64, 3, 1),        # stride 1
+    (37, 4, 4, 512, 8, 8, 256, 5, 2),
+]
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Ho,Wo,Cout,k,s", DECONV_CASES)
+@pytest.mark.parametrize("epi", ["none", "affine_relu", "tanh"])
+def test_deconv2d_fwd(B, H, W, Cin, Ho, Wo, Cout, k, s, epi):
+    from cgs_amd import kernels as K, lib
+    x, w, b = rnd((B, H, W, Cin), 1), rnd((k, k, Cout, Cin), 2, 0.05), rnd((Cout,), 3, 0.1)
+    a, c = rnd((Cout,), 5).abs() + 0.5, rnd((Cout,), 6, 0.3)
+    want = R.deconv2d(x, w, b, (B, Ho, Wo, Cout), s, s)
+    d = dev()
+    if epi == "affine_relu":
+        want = torch.relu(a * want + c)
+        got = K.deconv2d_fwd(x.to(d), w.to(d), b.to(d), (Ho, Wo), s, s, lib.EPI_AFFINE_RELU, a.to(d), c.to(d))
+    elif epi == "tanh":
+        want = torch.tanh(want)
+        got = K.deconv2d_fwd(x.to(d), w.to(d), b.to(d), (Ho, Wo), s, s, lib.EPI_TANH)
+    else:
+        got = K.deconv2d_fwd(x.to(d), w.to(d), b.to(d), (Ho, Wo), s, s)
+    close(got, want, 2e-5)
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Ho,Wo,Cout,k,s", DECONV_CASES)
+def test_deconv2d_bwd_data(B, H, W, Cin, Ho, Wo, Cout, k, s):
+    from cgs_amd import kernels as K
+    x = rnd((B, H, W, Cin), 1).requires_grad_(True)
+    w = rnd((k, k, Cout, Cin), 2, 0.05)
+    y = R.deconv2d(x, w, torch.zeros(Cout), (B, Ho, Wo, Cout), s, s)
+    dy = rnd(tuple(y.shape), 4)
+    (y * dy).sum().backward()
+    got = K.deconv2d_bwd_data(dy.to(dev()), w.to(dev()), (H, W), s, s)
+    close(got, x.grad, 2e-5)
+
+
+@pytest.mark.parametrize("B,K_,N", [(64, 6272, 1024), (64, 62, 1024), (33, 1024, 6272), (1024, 8192, 1), (7, 100, 8192), (5, 1023, 1)])
+def test_linear_fwd_bwd(B, K_, N):
+    from cgs_amd import kernels as K
+    x = rnd((B, K_), 1).requires_grad_(True)
+    w, b = rnd((K_, N), 2, 0.02), rnd((N,), 3, 0.1)
+    y = R.linear(x, w, b)
+    dy = rnd((B, N), 4)
+    (y * dy).sum().backward()
+    d = dev()
+    close(K.linear_fwd(x.detach().to(d), w.to(d), b.to(d)), y, 2e-5)
+    close(K.linear_bwd_data(dy.to(d), w.to(d)), x.grad, 2e-5)
+
+
+@pytest.mark.parametrize("shape", [(64, 7, 7, 128), (64, 1024), (10, 16, 16, 128), (3, 4, 4, 512), (257, 8, 8, 256)])
+@pytest.mark.parametrize("leak", [0.2, 1.0])
+def test_bn_train_lrelu_fwd_bwd(shape, leak):
+    from cgs_amd import kernels as K
+    C = shape[-1]
+    x = (rnd(shape, 1) * 1.5 + 0.3).requires_grad_(True)
+    g, b = rnd((C,), 2, 0.1) + 1.0, rnd((C,), 3, 0.1)
+    bn = R.bn_train(x, g, b)
+    y = torch.where(bn > 0, bn, leak * bn)
+    dy = rnd(shape, 4)
+    (y * dy).sum().backward()
+    d = dev()
+    gy, mean, invstd = K.bn_train_lrelu_fwd(x.detach().to(d), g.to(d), b.to(d), leak)
+    red = tuple(range(len(shape) - 1))
+    close(mean, x.detach().mean(red), 1e-5)
+    close(invstd, 1.0 / torch.sqrt(x.detach().var(red, unbiased=False) + R.BN_EPS), 1e-5)
+    close(gy, y, 1e-5)
+    gdx = K.bn_train_lrelu_bwd_data(dy.to(d), x.detach().to(d), g.to(d), b.to(d), mean, invstd, leak)
+    close(gdx, x.grad, 5e-5)
+    # determinism: same inputs twice -> bit-identical statistics
+    gy2, mean2, invstd2 = K.bn_train_lrelu_fwd(x.detach().to(d), g.to(d), b.to(d), leak)
+    assert torch.equal(mean, mean2) and torch.equal(invstd, invstd2) and torch.equal(gy, gy2)
+
+
+def test_elementwise_and_fold():
+    from cgs_amd import kernels as K
+    d = dev()
+    x = rnd((5, 6, 6, 12), 1)
+    dy = rnd((5, 6, 6, 12), 2)
+    C = 12
+    g, b, mm, mv = rnd((C,), 3).abs() + 0.5, rnd((C,), 4), rnd((C,), 5), rnd((C,), 6).abs() + 0.1
+    a, c = K.bn_fold(g.to(d), b.to(d), mm.to(d), mv.to(d))
+    aw = g / torch.sqrt(mv + R.BN_EPS)
+    close(a, aw, 1e-6); close(c, b - aw * mm, 1e-6)
+    y = K.affine_relu_fwd(x.to(d), a, c)
+    close(y, torch.relu(R.bn_infer(x, g, b, mm, mv)), 1e-5)
+    close(K.affine_relu_bwd(dy.to(d), y, a), dy * (y.cpu() > 0) * aw, 1e-5)
+    yl = K.lrelu_fwd(x.to(d))
+    close(yl, R.lrelu(x), 1e-6)
+    close(K.lrelu_bwd(dy.to(d), yl), dy * torch.where(x > 0, 1.0, 0.2), 1e-6)
+    yt = K.tanh_fwd(x.to(d))
+    close(yt, torch.tanh(x), 1e-5)
+    close(K.tanh_bwd(dy.to(d), yt), dy * (1 - torch.tanh(x) ** 2), 1e-5)
+    logits = rnd((9, 4), 7, 5.0)
+    dl, lm = K.bce_ones_grad_rowmean(logits.to(d))
+    close(dl, torch.sigmoid(logits) - 1, 1e-5); close(lm, logits.mean(1), 1e-6)
+
+
+def test_refine_update_and_select_match_policy():
+    from cgs_amd import kernels as K
+    from oracle import sampling_ref as S
+    d = dev()
+    B, F = 6, 3 * 3 * 8
+    th0 = rnd((B, 3, 3, 8), 1)
+    pol = S.Policy(0.1, "momentum")
+    th_ref = th0.clone()
+    th, m = th0.to(d).clone(), torch.zeros_like(th0).to(d)
+    best_t, best_l, best_s = th.clone(), torch.full((B,), -1.0, device=d), torch.ones(B, device=d)
+    bl_ref, bs_ref, bt_ref = torch.full((B,), -1.0), torch.ones(B), th0.clone()
+    for i in range(4):
+        g = rnd((B, 3, 3, 8), 10 + i)
+        th_ref = pol.step(th_ref, g)
+        K.refine_update(th, m, g.to(d), 0.1, 0.9, first=(i == 0))
+        assert torch.equal(th.cpu(), th_ref), "momentum update must be bit-exact (same op order, policy.py:33-36)"
+        logit = rnd((B,), 20 + i)
+        upd = logit > bl_ref
+        bl_ref = torch.where(upd, logit, bl_ref); bs_ref = torch.where(upd, torch.full_like(bs_ref, i + 1), bs_ref)
+        bt_ref = torch.where(upd.view(-1, 1, 1, 1), th_ref, bt_ref)
+        K.refine_select(th, logit.to(d), None, i, best_t, best_l, best_s)
+        assert torch.equal(best_l.cpu(), bl_ref) and torch.equal(best_s.cpu(), bs_ref) and torch.equal(best_t.cpu(), bt_ref)
+    # probabilistic mode: forced indices
+    forced = torch.tensor([0, 1, 2, 3, 4, 1], dtype=torch.int32, device=d)
+    bt2, bl2, bs2 = th.clone().zero_(), torch.zeros(B, device=d), torch.ones(B, device=d)
+    K.refine_select(th, best_l, forced, 1, bt2, bl2, bs2)
+    sel = (forced == 1).cpu()
+    assert torch.equal(bs2.cpu(), torch.where(sel, 2.0, 1.0)) and torch.equal(bt2.cpu()[sel], th.cpu()[sel]) and bt2.cpu()[~sel].abs().sum() == 0
+    # clip (collaborator.py:69-70)
+    th3, m3 = th0.to(d).clone(), torch.zeros_like(th0).to(d)
+    g = rnd((B, 3, 3, 8), 99)
+    K.refine_update(th3, m3, g.to(d), 0.1, 0.9, True, 0.05, 1.5)
+    assert torch.equal(th3.cpu(), torch.clamp(th0 - 0.1 * g, 0.05, 1.5))
+
+
+def test_errors_are_loud():
+    from cgs_amd import kernels as K, lib
+    d = dev()
+    with pytest.raises(lib.CgsError):
+        K.conv2d_fwd(torch.zeros(1, 4, 4, 8), torch.zeros(5, 5, 8, 8, device=d), None)      # CPU tensor
+    with pytest.raises(lib.CgsError):
+        K.conv2d_fwd(torch.zeros(1, 4, 4, 8, device=d), torch.zeros(5, 5, 4, 8, device=d), None)   # Cin mismatch
+    with pytest.raises(lib.CgsError):
+        K.deconv2d_fwd(torch.zeros(1, 4, 4, 8, device=d), torch.zeros(5, 5, 8, 8, device=d), None, (9, 9))  # bad SAME geometry
