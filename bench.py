@@ -1,0 +1,159 @@
+#!/usr/bin/env python3
+"""bench.py -- refined samples/sec @ K refinement steps (BASELINE.json metric) on N MI355X GPUs.
+
+A "step" = one pass of the hot path over one z-batch: propose (G head) + K-step collaborative
+refinement (K+1 G-tail/D forwards, K backward-datas, momentum update, best-sample select) + final
+render, images left in HBM.  Default workload = BASELINE configs[2]: DCGAN CelebA 64x64, batch 1024
+per GPU, K = 20 (the configuration the 10k samples/s target is quoted on; it fits one GPU).
+Inputs (z batches) and weights are resident in HBM before the timed region.
+
+N > 1: one process per GPU (torch.distributed, backend nccl = RCCL), independent z-batches per rank
+(seed 2019+rank, weak scaling), and ONE RCCL all-gather per step of the refined images into the
+node-wide sample pool -- inside the timed region.
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nproc-per-node 8 ... bench.py --gpus 8 --steps 3 --warmup 1
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+PEAK_FP32_MATRIX_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+
+
+def cpu_baseline(arch, refine_steps, rate, budget_batch=64):
+    """The CPU oracle (torch-CPU fp32 restatement of collaborator.build_refiner) timed on the host cores
+    on a bounded sample of the same workload (same net, same K, a smaller batch: work is linear in B)."""
+    from oracle import nets_ref as N
+    from oracle import sampling_ref as S
+    P = N.init_params(arch, 2019, True)
+    zdim = N.ARCHS[arch]["z_dim"]
+    gt, dd = (lambda f: N.feature_to_data(arch, P, f)), (lambda x: N.discriminator(arch, P, x))
+
+    def run(B, K):
+        z = torch.from_numpy(np.random.RandomState(0).uniform(-1, 1, (B, zdim)).astype(np.float32))
+        with torch.no_grad():
+            f0 = N.input_to_feature(arch, P, z)
+        t = time.time()
+        S.collaborative_refine(f0, gt, dd, K, rate)
+        return time.time() - t
+    run(4, 1)                                  # warm the thread pool / allocator
+    dt = run(budget_batch, refine_steps)
+    return {"value": round(budget_batch / dt, 3), "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle.collaborative_refine (torch-CPU fp32), {arch}, batch {budget_batch}, K={refine_steps}, "
+                      f"{dt:.1f} s wall, all host threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--arch", default="dcgan64", choices=["mnist", "dcgan32", "dcgan64"])
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: 1024 dcgan64, 256 dcgan32, 64 mnist)")
+    ap.add_argument("--refine-steps", type=int, default=0, help="K (default: 20; 50 for mnist)")
+    ap.add_argument("--rate", type=float, default=0.1)
+    ap.add_argument("--graph", action="store_true", help="replay the K-step program as a hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (there is no CPU path to benchmark)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from cgs_amd import kernels as K
+    from cgs_amd import nets
+    from cgs_amd.engine import RefineEngine
+
+    B = args.batch or {"dcgan64": 1024, "dcgan32": 256, "mnist": 64}[args.arch]
+    Ksteps = args.refine_steps or (50 if args.arch == "mnist" else 20)
+    A = nets.ARCHS[args.arch]
+    P = nets.init_params(args.arch, dev, seed=2019)                     # same frozen weights on every rank
+    eng = RefineEngine(args.arch, P, B, dev, use_graph=args.graph)
+    n_batches = args.steps + args.warmup
+    rs = np.random.RandomState(2019 + rank)                            # rank-offset seed: disjoint z shards
+    z = torch.from_numpy(rs.uniform(-1, 1, (n_batches, B, A["z_dim"])).astype(np.float32)).to(dev)
+    pool = torch.empty((world * B,) + tuple(A["img"]), dtype=torch.float32, device=dev) if world > 1 else None
+
+    def step(i):
+        img = eng.refine_from_z(z[i], Ksteps, args.rate)[0]
+        if world > 1:
+            dist.all_gather_into_tensor(pool, img)                     # RCCL over xGMI: the refined sample pool
+        return img
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    if rank == 0 and not args.graph:
+        K.PROFILE = {}
+    t0 = time.perf_counter()
+    for i in range(args.warmup, n_batches):
+        step(i)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    prof, K.PROFILE = K.PROFILE, None
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        value = world * B * args.steps / dt
+        flops_per_sample = nets.refine_flops_per_sample(args.arch, Ksteps)
+        out = {
+            "metric": f"refined samples/sec @ {Ksteps} refinement steps", "value": round(value, 2), "unit": "samples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.arch} collaborative refinement (propose + K-step refine + render), "
+                                   f"batch {B}/GPU, K={Ksteps}, momentum rate {args.rate}, refine@G.h1 "
+                                   f"{list(A['feature'])}, random-init weights, z~U(-1,1) seed 2019+rank",
+                       "global_batch": world * B, "refine_steps": Ksteps, "parallelism": f"z-shards x{world} + RCCL all-gather of the pool" if world > 1 else "single GPU",
+                       "hipgraph": bool(args.graph)},
+            "algorithmic_tflops": round(value * flops_per_sample / 1e12, 2),
+        }
+        if prof:
+            dom = max(prof.items(), key=lambda kv: sum(a.elapsed_time(b) for a, b in kv[1][1]))
+            per = {}
+            for name, (fl, evs) in prof.items():
+                ms = sum(a.elapsed_time(b) for a, b in evs)
+                per[name] = {"launches": len(evs), "avg_us": round(1e3 * ms / len(evs), 2), "tflops": round(fl / ms / 1e9, 2),
+                             "share_of_step": round(ms / (1e3 * dt), 3)}
+            name, (fl, evs) = dom
+            ms = sum(a.elapsed_time(b) for a, b in evs)
+            ach = fl / ms / 1e9
+            out["roofline"] = {"kernel": name, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MATRIX_TFLOPS,
+                               "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MATRIX_TFLOPS, 4), "traffic": None,
+                               "launches": len(evs), "avg_launch_us": round(1e3 * ms / len(evs), 2),
+                               "flop_per_launch_avg": round(fl / len(evs), 0)}
+            out["kernels"] = per
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.arch, Ksteps, args.rate)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -60,6 +60,34 @@ int cgs_affine_relu_bwd(const float* dy, const float* y, const float* a, float* 
     return CGS_OK;
 }
 
+// plain per-channel affine (inference-mode bn without an activation) and its input gradient
+template <int MODE>
+__global__ __launch_bounds__(256) void affine_kernel(const float* __restrict__ p0, const float* __restrict__ a,
+                                                     const float* __restrict__ b, float* __restrict__ o, size_t n, int C) {
+    GRID_STRIDE(i, n) {
+        const int c = (int)(i % C);
+        o[i] = MODE == 0 ? fmaf(a[c], p0[i], b[c]) : p0[i] * a[c];
+    }
+}
+
+int cgs_affine_fwd(const float* x, const float* a, const float* b, float* y, int M, int C, void* stream) {
+    if (M < 0 || C <= 0) return cgs_set_error(CGS_EINVAL, "affine_fwd: M=%d C=%d", M, C);
+    const size_t n = (size_t)M * C;
+    if (n == 0) return CGS_OK;
+    hipLaunchKernelGGL(affine_kernel<0>, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, x, a, b, y, n, C);
+    CGS_CHECK_LAUNCH("affine_fwd");
+    return CGS_OK;
+}
+
+int cgs_affine_bwd(const float* dy, const float* a, float* dx, int M, int C, void* stream) {
+    if (M < 0 || C <= 0) return cgs_set_error(CGS_EINVAL, "affine_bwd: M=%d C=%d", M, C);
+    const size_t n = (size_t)M * C;
+    if (n == 0) return CGS_OK;
+    hipLaunchKernelGGL(affine_kernel<1>, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, dy, a, nullptr, dx, n, C);
+    CGS_CHECK_LAUNCH("affine_bwd");
+    return CGS_OK;
+}
+
 // OP 0 lrelu fwd, 1 lrelu bwd, 2 tanh fwd, 3 tanh bwd
 template <int OP>
 __global__ __launch_bounds__(256) void unary_kernel(const float* __restrict__ p0, const float* __restrict__ p1, float leak,

@@ -1,0 +1,340 @@
+"""The fused refinement loop on one GPU (sampling/collaborator.py:26-88 as an eager device program).
+
+The reference unrolls K copies of (G tail -> D -> d loss/d theta) into a static TF graph.  Here the
+layer lists of ``nets`` are compiled ONCE into a tape of stages over libcgs_hip.so kernels:
+
+  * peephole fusion: deconv+bn(infer)+relu and deconv+tanh, conv+lrelu, linear+lrelu become one
+    implicit-GEMM launch with a fused epilogue; D's bn(train)+lrelu one fused stage;
+  * every activation / gradient buffer is allocated once (single step live, reused across the K
+    steps and across batches); refinement state (theta, momentum, best theta/logit/step) stays in
+    HBM for the whole call; weights are packed once;
+  * no host synchronisation inside the loop, so the whole K-step program can be captured into a
+    hipGraph (``use_graph=True``) and replayed per batch -- the launch-bound regime of small batches.
+
+Only forward + backward-DATA exist: the weights are frozen, no weight gradient is ever formed.
+"""
+import numpy as np
+import torch
+
+from . import kernels as K
+from . import lib as L
+from .nets import ARCHS, _same_out
+
+
+# ----------------------------------------------------------------------------- stages
+class _Stage:
+    out = None
+
+    def fwd(self, x):
+        raise NotImplementedError
+
+    def bwd(self, dy):
+        raise NotImplementedError
+
+
+class _View(_Stage):
+    def __init__(self, in_shape, out_shape):
+        self.in_shape, self.out_shape = in_shape, out_shape
+
+    def fwd(self, x):
+        return x.view(self.out_shape)
+
+    def bwd(self, dy):
+        return dy.view(self.in_shape)
+
+
+class _Conv(_Stage):
+    """conv2d 'SAME' + bias [+ lrelu]   (nsgan/ops.py:37-46, 69-70)."""
+
+    def __init__(self, B, in_shape, w, b, stride, epi, dev):
+        self.w, self.b, self.s, self.epi = w, b, stride, epi
+        H, W, _ = in_shape
+        self.in_hw = (H, W)
+        self.out = torch.empty((B, _same_out(H, stride), _same_out(W, stride), w.shape[3]), dtype=torch.float32, device=dev)
+        self.dx = torch.empty((B,) + tuple(in_shape), dtype=torch.float32, device=dev)
+
+    def fwd(self, x):
+        return K.conv2d_fwd(x, self.w, self.b, self.s, self.s, self.epi, out=self.out)
+
+    def bwd(self, dy):
+        if self.epi == L.EPI_LRELU:
+            dy = K.lrelu_bwd(dy, self.out, out=dy)
+        return K.conv2d_bwd_data(dy, self.w, self.in_hw, self.s, self.s, out=self.dx)
+
+
+class _Deconv(_Stage):
+    """conv2d_transpose + bias [+ folded inference bn + relu | + tanh]   (nsgan/ops.py:48-67, nsgan/GAN.py:96-100)."""
+
+    def __init__(self, B, in_shape, out_shape, w, b, stride, epi, a, c, dev):
+        self.w, self.b, self.s, self.epi, self.a, self.c = w, b, stride, epi, a, c
+        self.in_hw, self.out_hw = (in_shape[0], in_shape[1]), (out_shape[0], out_shape[1])
+        self.out = torch.empty((B,) + tuple(out_shape), dtype=torch.float32, device=dev)
+        self.dx = torch.empty((B,) + tuple(in_shape), dtype=torch.float32, device=dev)
+
+    def fwd(self, x):
+        return K.deconv2d_fwd(x, self.w, self.b, self.out_hw, self.s, self.s, self.epi, self.a, self.c, out=self.out)
+
+    def bwd(self, dy):
+        if self.epi == L.EPI_AFFINE_RELU:
+            dy = K.affine_relu_bwd(dy, self.out, self.a, out=dy)
+        elif self.epi == L.EPI_TANH:
+            dy = K.tanh_bwd(dy, self.out, out=dy)
+        return K.deconv2d_bwd_data(dy, self.w, self.in_hw, self.s, self.s, out=self.dx)
+
+
+class _Linear(_Stage):
+    def __init__(self, B, w, b, epi, dev):
+        self.w, self.b, self.epi = w, b, epi
+        self.out = torch.empty((B, w.shape[1]), dtype=torch.float32, device=dev)
+        self.dx = torch.empty((B, w.shape[0]), dtype=torch.float32, device=dev)
+
+    def fwd(self, x):
+        return K.linear_fwd(x, self.w, self.b, self.epi, out=self.out)
+
+    def bwd(self, dy):
+        if self.epi == L.EPI_LRELU:
+            dy = K.lrelu_bwd(dy, self.out, out=dy)
+        return K.linear_bwd_data(dy, self.w, out=self.dx)
+
+
+class _BnTrainLrelu(_Stage):
+    """Batch-statistics bn [+ lrelu]: D inside the differentiated path (nsgan/GAN.py:65,67,175)."""
+
+    def __init__(self, B, shape, gamma, beta, leak, dev):
+        self.gamma, self.beta, self.leak = gamma, beta, leak
+        self.out = torch.empty((B,) + tuple(shape), dtype=torch.float32, device=dev)
+        self.mean = torch.empty(shape[-1], dtype=torch.float32, device=dev)
+        self.invstd = torch.empty(shape[-1], dtype=torch.float32, device=dev)
+        self.x = None
+
+    def fwd(self, x):
+        self.x = x
+        K.bn_train_lrelu_fwd(x, self.gamma, self.beta, self.leak, out=self.out, stats=(self.mean, self.invstd))
+        return self.out
+
+    def bwd(self, dy):
+        return K.bn_train_lrelu_bwd_data(dy, self.x, self.gamma, self.beta, self.mean, self.invstd, self.leak, out=dy)
+
+
+class _AffineRelu(_Stage):
+    """Inference-mode bn + relu that could not be folded into a producer epilogue (G head)."""
+
+    def __init__(self, B, shape, a, c, dev):
+        self.a, self.c = a, c
+        self.out = torch.empty((B,) + tuple(shape), dtype=torch.float32, device=dev)
+
+    def fwd(self, x):
+        return K.affine_relu_fwd(x, self.a, self.c, out=self.out)
+
+    def bwd(self, dy):
+        return K.affine_relu_bwd(dy, self.out, self.a, out=dy)
+
+
+class _Unary(_Stage):
+    def __init__(self, B, shape, kind, dev):
+        self.kind = kind
+        self.out = torch.empty((B,) + tuple(shape), dtype=torch.float32, device=dev)
+
+    def fwd(self, x):
+        if self.kind == "lrelu":
+            return K.lrelu_fwd(x, out=self.out)
+        if self.kind == "tanh":
+            return K.tanh_fwd(x, out=self.out)
+        return K.lrelu_fwd(x, 0.0, out=self.out)     # relu = lrelu with leak 0
+
+    def bwd(self, dy):
+        if self.kind == "lrelu":
+            return K.lrelu_bwd(dy, self.out, out=dy)
+        if self.kind == "tanh":
+            return K.tanh_bwd(dy, self.out, out=dy)
+        return K.lrelu_bwd(dy, self.out, 0.0, out=dy)
+
+
+def compile_layers(layers, in_shape, P, scope, B, k, stride, bn_training, dev):
+    """Layer list -> stage tape with peephole fusion.  Returns (stages, out_shape)."""
+    stages, shape, i = [], tuple(in_shape), 0
+    n = len(layers)
+
+    def kind(j):
+        return layers[j][0] if j < n else None
+
+    def fold(name):
+        s = f"{scope}/{name}"
+        return K.bn_fold(P[s + "/gamma"], P[s + "/beta"], P[s + "/moving_mean"], P[s + "/moving_variance"])
+
+    while i < n:
+        Lr = layers[i]
+        t = Lr[0]
+        if t == "deconv":
+            w, b = P[f"{scope}/{Lr[1]}/w"], P[f"{scope}/{Lr[1]}/biases"]
+            epi, a, c, used = L.EPI_NONE, None, None, 1
+            if kind(i + 1) == "bn" and kind(i + 2) == "relu" and not bn_training:
+                a, c = fold(layers[i + 1][1]); epi, used = L.EPI_AFFINE_RELU, 3
+            elif kind(i + 1) == "tanh":
+                epi, used = L.EPI_TANH, 2
+            stages.append(_Deconv(B, shape, Lr[2], w, b, stride, epi, a, c, dev))
+            shape = tuple(Lr[2]); i += used
+        elif t == "conv":
+            w, b = P[f"{scope}/{Lr[1]}/w"], P[f"{scope}/{Lr[1]}/biases"]
+            epi, used = (L.EPI_LRELU, 2) if kind(i + 1) == "lrelu" else (L.EPI_NONE, 1)
+            st = _Conv(B, shape, w, b, stride, epi, dev)
+            stages.append(st)
+            shape = tuple(st.out.shape[1:]); i += used
+        elif t == "linear":
+            w, b = P[f"{scope}/{Lr[1]}/Matrix"], P[f"{scope}/{Lr[1]}/bias"]
+            epi, used = (L.EPI_LRELU, 2) if kind(i + 1) == "lrelu" else (L.EPI_NONE, 1)
+            stages.append(_Linear(B, w, b, epi, dev))
+            shape = (Lr[2],); i += used
+        elif t == "bn":
+            s = f"{scope}/{Lr[1]}"
+            if bn_training:
+                leak, used = (K.LEAK, 2) if kind(i + 1) == "lrelu" else (1.0, 1)
+                stages.append(_BnTrainLrelu(B, shape, P[s + "/gamma"], P[s + "/beta"], leak, dev))
+                i += used
+            else:
+                if kind(i + 1) != "relu":
+                    raise NotImplementedError("inference-mode bn is only supported when followed by relu")
+                a, c = fold(Lr[1])
+                stages.append(_AffineRelu(B, shape, a, c, dev)); i += 2
+        elif t in ("relu", "lrelu", "tanh"):
+            stages.append(_Unary(B, shape, t, dev)); i += 1
+        elif t == "reshape":
+            stages.append(_View((B,) + shape, (B,) + tuple(Lr[1]))); shape = tuple(Lr[1]); i += 1
+        elif t == "flatten":
+            flat = (int(np.prod(shape)),)
+            stages.append(_View((B,) + shape, (B,) + flat)); shape = flat; i += 1
+        else:
+            raise KeyError(t)
+    return stages, shape
+
+
+class Tape:
+    """A compiled layer list: forward keeps what backward-data needs; no weight gradients."""
+
+    def __init__(self, layers, in_shape, P, scope, B, k, stride, bn_training, dev):
+        self.stages, self.out_shape = compile_layers(layers, in_shape, P, scope, B, k, stride, bn_training, dev)
+
+    def forward(self, x):
+        for st in self.stages:
+            x = st.fwd(x)
+        return x
+
+    def backward(self, dy):
+        for st in reversed(self.stages):
+            dy = st.bwd(dy)
+        return dy
+
+
+# ----------------------------------------------------------------------------- the loop
+class RefineEngine:
+    """K-step collaborative refinement of a batch of G activation maps on one GPU."""
+
+    def __init__(self, arch, params, batch_size, device=None, use_graph=False):
+        self.A = ARCHS[arch] if isinstance(arch, str) else arch
+        self.dev = torch.device(device if device is not None else "cuda:0")
+        if self.dev.type != "cuda":
+            raise L.CgsError("RefineEngine needs a GPU device (there is no CPU path)")
+        L.load()
+        A, B = self.A, int(batch_size)
+        self.B, self.P = B, params
+        with torch.cuda.device(self.dev):
+            self.g_head = Tape(A["g_head"], (A["z_dim"],), params, "generator", B, A["k"], A["stride"], False, self.dev)
+            self.g_tail = Tape(A["g_tail"], A["feature"], params, "generator", B, A["k"], A["stride"], False, self.dev)
+            self.d = Tape(A["d"], A["img"], params, "discriminator", B, A["k"], A["stride"], True, self.dev)
+            fs = (B,) + tuple(A["feature"])
+            f32 = dict(dtype=torch.float32, device=self.dev)
+            self.theta, self.mom, self.best_theta = torch.empty(fs, **f32), torch.empty(fs, **f32), torch.empty(fs, **f32)
+            self.logit, self.best_logit = torch.empty(B, **f32), torch.empty(B, **f32)
+            self.default_logit, self.best_step = torch.empty(B, **f32), torch.empty(B, **f32)
+            self.dlogits = torch.empty((B,) + tuple(self.d.out_shape), **f32)
+            self.forced = torch.zeros(B, dtype=torch.int32, device=self.dev)
+            self.images = torch.empty((B,) + tuple(A["img"]), **f32)
+        self.use_graph = use_graph
+        self._graphs = {}
+
+    # -- pieces (sampling/collaborator.py:26-39) ------------------------------------------------
+    def input_to_feature(self, z):
+        """G head (nsgan/GAN.py:87-92)."""
+        return self.g_head.forward(z)
+
+    def feature_to_data(self, feat):
+        """G tail (nsgan/GAN.py:94-101)."""
+        return self.g_tail.forward(feat)
+
+    def discriminator(self, x):
+        """D with batch-statistics bn (nsgan/GAN.py:59-70 bound at :175)."""
+        return self.d.forward(x)
+
+    def forward_logits(self, theta, logit_out):
+        logits = self.d.forward(self.g_tail.forward(theta))
+        K.bce_ones_grad_rowmean(logits, self.dlogits, logit_out)
+        return logits
+
+    def backward_to_feature(self):
+        """d sum_b softplus(-logit_b) / d theta, through D then the G tail (collaborator.py:31)."""
+        return self.g_tail.backward(self.d.backward(self.dlogits))
+
+    def compute_forward_logits_and_grad(self, feature):
+        self.forward_logits(feature, self.logit)
+        return self.logit, self.backward_to_feature()
+
+    # -- the K-step program -------------------------------------------------------------------
+    def _program(self, steps, rate, alpha, probabilistic, vmin, vmax):
+        th = self.theta
+        self.forward_logits(th, self.logit)
+        self.default_logit.copy_(self.logit)
+        self.best_logit.copy_(self.logit)
+        self.best_theta.copy_(th)
+        self.best_step.fill_(1.0)                                   # collaborator.py:60 (starts at 1)
+        for i in range(steps):
+            g = self.backward_to_feature()
+            K.refine_update(th, self.mom, g, rate, alpha, first=(i == 0), vmin=vmin, vmax=vmax)
+            self.forward_logits(th, self.logit)                     # the K-th gradient is never formed (Q4)
+            K.refine_select(th, self.logit, self.forced if probabilistic else None, i,
+                            self.best_theta, self.best_logit, self.best_step)
+        img = self.g_tail.forward(self.best_theta)                  # collaborator.py:88
+        self.images.copy_(img)
+
+    def refine(self, feature0, steps, rate, method="momentum", mode="deterministic", indices=None,
+               vmin=None, vmax=None):
+        """collaborator.py:41-88 on device.  Returns (images, default_logit, optimal_logit, optimal_step,
+        optimal_feature) -- engine-owned buffers, valid until the next call."""
+        if method == "momentum":
+            alpha = 0.9                                             # policy.py:10
+        elif method == "sgd":
+            alpha = 0.0
+        elif method == "ladam":
+            raise L.CgsError("ladam needs a loss argument the map-space refiner never passes "
+                             "(sampling/collaborator.py:66 vs policy.py:48-51); use momentum or sgd")
+        else:
+            raise NotImplementedError(method)
+        if mode not in ("deterministic", "probabilistic"):
+            raise NotImplementedError(mode)
+        prob = mode == "probabilistic"
+        if prob:
+            if indices is None:
+                raise L.CgsError("probabilistic mode needs the step indices (np.random.randint(K+1, size=B))")
+            self.forced.copy_(torch.as_tensor(np.asarray(indices), dtype=torch.int32))
+        if tuple(feature0.shape) != tuple(self.theta.shape):
+            raise L.CgsError(f"feature batch {tuple(feature0.shape)} != engine shape {tuple(self.theta.shape)}")
+        with torch.cuda.device(self.dev):
+            self.theta.copy_(feature0)
+            key = (steps, float(rate), alpha, prob, vmin, vmax)
+            if not self.use_graph:
+                self._program(steps, rate, alpha, prob, vmin, vmax)
+            else:
+                g = self._graphs.get(key)
+                if g is None:
+                    self._program(steps, rate, alpha, prob, vmin, vmax)      # warm-up: packs weights, sizes workspaces
+                    self.theta.copy_(feature0)
+                    torch.cuda.synchronize(self.dev)
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        self._program(steps, rate, alpha, prob, vmin, vmax)
+                    self._graphs[key] = g
+                g.replay()
+        return self.images, self.default_logit, self.best_logit, self.best_step, self.best_theta
+
+    def refine_from_z(self, z, steps, rate, **kw):
+        """Propose (G head) + refine + render: one whole unit of the BASELINE metric."""
+        return self.refine(self.input_to_feature(z), steps, rate, **kw)

@@ -31,6 +31,38 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+# ---- optional per-kernel timing (bench.py): {kernel_name: [flops, [(ev_start, ev_end), ...]]} or None.
+# Events are recorded on the stream the kernel is launched on (torch's current stream).
+PROFILE = None
+
+
+def igemm_kernel_name(dirT, kh, kw, sh, sw, Cb, Cs, Hb, Wb, Hs, Ws, epilogue=0):
+    """Which kernel the C-ABI dispatcher (csrc/api.hip run_dir) picks for a conv-family call."""
+    if dirT and Cb <= 4 and sh == 2 and sw == 2 and Hb == 2 * Hs and Wb == 2 * Ws and Cs % 4 == 0 and epilogue != L.EPI_AFFINE_RELU:
+        return "convt_smalln_kernel"
+    cred, n = (Cs, Cb) if dirT else (Cb, Cs)
+    npad = (n + 63) // 64 * 64
+    return "igemm_kernel<128,%d,%s>" % (128 if npad % 128 == 0 else 64, "true" if cred % 32 == 0 else "false")
+
+
+class _Prof:
+    __slots__ = ("name", "flops", "e0")
+
+    def __init__(self, name, flops):
+        self.name, self.flops, self.e0 = name, flops, None
+        if PROFILE is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+
+    def done(self):
+        if self.e0 is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            rec = PROFILE.setdefault(self.name, [0.0, []])
+            rec[0] += self.flops
+            rec[1].append((self.e0, e1))
+
+
 def same_out(size, stride):
     """nsgan/ops.py:28-29."""
     return int(math.ceil(float(size) / float(stride)))
@@ -81,8 +113,12 @@ def conv2d_fwd(x, w, bias, sh=2, sw=2, epilogue=L.EPI_NONE, ep_a=None, ep_b=None
         raise L.CgsError(f"conv2d: weight Cin {Cin2} != input channels {Cin}")
     y = out if out is not None else torch.empty((B, same_out(H, sh), same_out(W, sw), Cout), dtype=torch.float32, device=x.device)
     ws, pre = WS.get(w, L.CONV_FWD, kh, kw, sh, sw, Cin, Cout)
+    Ho, Wo = y.shape[1], y.shape[2]
+    pr = _Prof(igemm_kernel_name(False, kh, kw, sh, sw, Cin, Cout, H, W, Ho, Wo), 2.0 * B * Ho * Wo * Cout * kh * kw * Cin) if PROFILE is not None else None
     L.call("cgs_conv2d_nhwc_fwd", _ptr(x), _ptr(w), _ptr(bias), _ptr(y), B, H, W, Cin, Cout, kh, kw, sh, sw,
            epilogue, _ptr(ep_a), _ptr(ep_b), _ptr(ws), ws.numel() * 4, pre, _stream())
+    if pr is not None:
+        pr.done()
     return y
 
 
@@ -94,8 +130,12 @@ def conv2d_bwd_data(dy, w, in_hw, sh=2, sw=2, out=None):
     H, W = in_hw
     dx = out if out is not None else torch.empty((B, H, W, Cin), dtype=torch.float32, device=dy.device)
     ws, pre = WS.get(w, L.CONV_BWD_DATA, kh, kw, sh, sw, Cin, Cout)
+    Ho, Wo = dy.shape[1], dy.shape[2]
+    pr = _Prof(igemm_kernel_name(True, kh, kw, sh, sw, Cin, Cout, H, W, Ho, Wo), 2.0 * B * Ho * Wo * Cout * kh * kw * Cin) if PROFILE is not None else None
     L.call("cgs_conv2d_nhwc_bwd_data", _ptr(dy), _ptr(w), _ptr(dx), B, H, W, Cin, Cout, kh, kw, sh, sw,
            _ptr(ws), ws.numel() * 4, pre, _stream())
+    if pr is not None:
+        pr.done()
     return dx
 
 
@@ -109,8 +149,11 @@ def deconv2d_fwd(x, w, bias, out_hw, sh=2, sw=2, epilogue=L.EPI_NONE, ep_a=None,
     Ho, Wo = out_hw
     y = out if out is not None else torch.empty((B, Ho, Wo, Cout), dtype=torch.float32, device=x.device)
     ws, pre = WS.get(w, L.DECONV_FWD, kh, kw, sh, sw, Cin, Cout)
+    pr = _Prof(igemm_kernel_name(True, kh, kw, sh, sw, Cout, Cin, Ho, Wo, H, W, epilogue), 2.0 * B * H * W * Cin * kh * kw * Cout) if PROFILE is not None else None
     L.call("cgs_deconv2d_nhwc_fwd", _ptr(x), _ptr(w), _ptr(bias), _ptr(y), B, H, W, Cin, Ho, Wo, Cout, kh, kw, sh, sw,
            epilogue, _ptr(ep_a), _ptr(ep_b), _ptr(ws), ws.numel() * 4, pre, _stream())
+    if pr is not None:
+        pr.done()
     return y
 
 
@@ -122,8 +165,11 @@ def deconv2d_bwd_data(dy, w, in_hw, sh=2, sw=2, out=None):
     H, W = in_hw
     dx = out if out is not None else torch.empty((B, H, W, Cin), dtype=torch.float32, device=dy.device)
     ws, pre = WS.get(w, L.DECONV_BWD_DATA, kh, kw, sh, sw, Cin, Cout)
+    pr = _Prof(igemm_kernel_name(False, kh, kw, sh, sw, Cout, Cin, Ho, Wo, H, W), 2.0 * B * H * W * Cin * kh * kw * Cout) if PROFILE is not None else None
     L.call("cgs_deconv2d_nhwc_bwd_data", _ptr(dy), _ptr(w), _ptr(dx), B, H, W, Cin, Ho, Wo, Cout, kh, kw, sh, sw,
            _ptr(ws), ws.numel() * 4, pre, _stream())
+    if pr is not None:
+        pr.done()
     return dx
 
 
@@ -157,14 +203,18 @@ def linear_bwd_data(dy, w, out=None):
 
 
 # ----------------------------------------------------------------------------- batch norm / activations
-def bn_train_lrelu_fwd(x, gamma, beta, leak=LEAK, eps=BN_EPS, out=None):
-    """Batch-statistics bn (+ lrelu; leak=1 -> plain bn).  Returns (y, mean, invstd).  nsgan/ops.py:19-26."""
+def bn_train_lrelu_fwd(x, gamma, beta, leak=LEAK, eps=BN_EPS, out=None, stats=None):
+    """Batch-statistics bn (+ lrelu; leak=1 -> plain bn).  Returns (y, mean, invstd).  nsgan/ops.py:19-26.
+    ``stats`` = optional preallocated (mean, invstd)."""
     _chk(x, "x")
     C = x.shape[-1]
     M = x.numel() // C
     y = out if out is not None else torch.empty_like(x)
-    mean = torch.empty(C, dtype=torch.float32, device=x.device)
-    invstd = torch.empty(C, dtype=torch.float32, device=x.device)
+    if stats is not None:
+        mean, invstd = stats
+    else:
+        mean = torch.empty(C, dtype=torch.float32, device=x.device)
+        invstd = torch.empty(C, dtype=torch.float32, device=x.device)
     ws = _bn_workspace(M, C, x.device)
     L.call("cgs_bn_train_lrelu_fwd", _ptr(x), _ptr(gamma), _ptr(beta), eps, leak, _ptr(y), _ptr(mean), _ptr(invstd),
            M, C, _ptr(ws), ws.numel() * 4, _stream())
@@ -204,6 +254,22 @@ def affine_relu_bwd(dy, y, a, out=None):
     C = y.shape[-1]
     dx = out if out is not None else torch.empty_like(y)
     L.call("cgs_affine_relu_bwd", _ptr(dy), _ptr(y), _ptr(a), _ptr(dx), y.numel() // C, C, _stream())
+    return dx
+
+
+def affine_fwd(x, a, b, out=None):
+    _chk(x, "x")
+    C = x.shape[-1]
+    y = out if out is not None else torch.empty_like(x)
+    L.call("cgs_affine_fwd", _ptr(x), _ptr(a), _ptr(b), _ptr(y), x.numel() // C, C, _stream())
+    return y
+
+
+def affine_bwd(dy, a, out=None):
+    _chk(dy, "dy")
+    C = dy.shape[-1]
+    dx = out if out is not None else torch.empty_like(dy)
+    L.call("cgs_affine_bwd", _ptr(dy), _ptr(a), _ptr(dx), dy.numel() // C, C, _stream())
     return dx
 
 

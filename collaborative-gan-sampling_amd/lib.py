@@ -32,6 +32,8 @@ SIGNATURES = {
     "cgs_bn_fold": (_i, [_p] * 4 + [_f, _p, _p, _i, _p]),
     "cgs_affine_relu_fwd": (_i, [_p] * 4 + [_i, _i, _p]),
     "cgs_affine_relu_bwd": (_i, [_p] * 4 + [_i, _i, _p]),
+    "cgs_affine_fwd": (_i, [_p] * 4 + [_i, _i, _p]),
+    "cgs_affine_bwd": (_i, [_p] * 3 + [_i, _i, _p]),
     "cgs_lrelu_fwd": (_i, [_p, _f, _p, _z, _p]),
     "cgs_lrelu_bwd": (_i, [_p, _p, _f, _p, _z, _p]),
     "cgs_tanh_fwd": (_i, [_p, _p, _z, _p]),

@@ -1,0 +1,115 @@
+"""GAN: the sampler-facing half of the reference's model class (nsgan/GAN.py:59-101,164-183),
+written against ``ops`` exactly as nsgan/GAN.py is written against nsgan/ops.py.
+
+Training, evaluation, checkpoint and plotting code of nsgan/GAN.py is out of scope;
+what is kept is what the refiner calls: ``discriminator`` (batch-statistics bn), ``generator``,
+``input_to_feature`` (G head), ``feature_to_data`` (G tail), ``loss_refine``, and the wiring
+``build_refiner()`` of nsgan/GAN.py:171-183.  The layer lists come from ``nets.ARCHS`` so the in-tree
+MNIST net and the DCGAN-32/64 nets share one code path.
+
+Two ways to run the refinement:
+  * generic  -- the bound methods below are plain callables over ``ops`` (autograd over HIP kernels);
+  * engine   -- ``GAN.engine(batch)`` compiles the same layer lists into the fused ``RefineEngine``;
+                ``collaborator.Refiner`` picks it automatically when handed this object's methods.
+"""
+import numpy as np
+import torch
+
+from . import ops
+from .nets import ARCHS
+
+
+class GAN(object):
+    model_name = "GAN"
+
+    def __init__(self, arch="mnist", batch_size=64, device="cuda:0", params=None):
+        self.arch = arch
+        self.A = ARCHS[arch] if isinstance(arch, str) else arch
+        self.batch_size = batch_size
+        self.z_dim = self.A["z_dim"]
+        self.image_dims = list(self.A["img"])
+        self.device = torch.device(device)
+        ops.set_device(self.device)
+        if params is not None:
+            ops.set_variables(params, self.device)
+        self._engines = {}
+
+    # -- layer-list interpreter over the operator API ------------------------------------------
+    def _run(self, layers, net, is_training):
+        k, s = self.A["k"], self.A["stride"]
+        for L in layers:
+            kind = L[0]
+            if kind == "linear":
+                net = ops.linear(net, L[2], scope=L[1])
+            elif kind == "reshape":
+                net = net.reshape([net.shape[0]] + list(L[1]))
+            elif kind == "flatten":
+                net = net.reshape([net.shape[0], -1])
+            elif kind == "conv":
+                net = ops.conv2d(net, L[2], k, k, s, s, name=L[1])
+            elif kind == "deconv":
+                net = ops.deconv2d(net, [net.shape[0]] + list(L[2]), k, k, s, s, name=L[1])
+            elif kind == "bn":
+                net = ops.bn(net, is_training=is_training, scope=L[1])
+            elif kind == "relu":
+                net = ops.relu(net)
+            elif kind == "lrelu":
+                net = ops.lrelu(net)
+            elif kind == "tanh":
+                net = ops.tanh(net)
+            else:
+                raise KeyError(kind)
+        return net
+
+    def discriminator(self, x, is_training=True, reuse=False):
+        """nsgan/GAN.py:59-70."""
+        with ops.variable_scope("discriminator", reuse=reuse):
+            return self._run(self.A["d"], x, is_training)
+
+    def generator(self, z, is_training=True, reuse=False):
+        """nsgan/GAN.py:72-85."""
+        with ops.variable_scope("generator", reuse=reuse):
+            return self._run(self.A["g_head"] + self.A["g_tail"], z, is_training)
+
+    def input_to_feature(self, z, is_training=False):
+        """nsgan/GAN.py:87-92."""
+        with ops.variable_scope("generator", reuse=True):
+            return self._run(self.A["g_head"], z, is_training)
+
+    def feature_to_data(self, net, is_training=False):
+        """nsgan/GAN.py:94-101."""
+        with ops.variable_scope("generator", reuse=True):
+            return self._run(self.A["g_tail"], net, is_training)
+
+    # -- what nsgan/GAN.py:171-183 wires into the refiner ---------------------------------------
+    def discriminator_refine(self, x):
+        """partial(self.discriminator, is_training=True, reuse=True)  (nsgan/GAN.py:175)."""
+        return self.discriminator(x, is_training=True, reuse=True)
+
+    @staticmethod
+    def loss_refine(logits):
+        """nsgan/GAN.py:176-177."""
+        return ops.sigmoid_cross_entropy_with_logits_ones(logits)
+
+    def build_variables(self):
+        """Create every variable (the reference does this by building the training graph, :117-121)."""
+        with torch.no_grad():
+            z = torch.zeros([2, self.z_dim], device=self.device)
+            self.discriminator(self.generator(z, is_training=False, reuse=False), is_training=False, reuse=False)
+        return ops.variables()
+
+    def engine(self, batch_size=None, use_graph=False):
+        """The fused device program for this net at a batch size (compiled once, cached)."""
+        from .engine import RefineEngine
+        B = int(batch_size or self.batch_size)
+        key = (B, use_graph)
+        if key not in self._engines:
+            self._engines[key] = RefineEngine(self.A, self.build_variables(), B, self.device, use_graph=use_graph)
+        return self._engines[key]
+
+    def build_refiner(self, rollout_steps, rollout_rate, rollout_method="momentum"):
+        """nsgan/GAN.py:179-181."""
+        from .sampling.collaborator import Refiner
+        refiner = Refiner(rollout_steps=rollout_steps, rollout_rate=rollout_rate, rollout_method=rollout_method)
+        refiner.set_env(self.discriminator_refine, self.feature_to_data, self.loss_refine)
+        return refiner

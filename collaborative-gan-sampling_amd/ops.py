@@ -1,0 +1,286 @@
+"""The reference's operator API (nsgan/ops.py:12-83) on torch GPU tensors over libcgs_hip.so.
+
+Same function names, argument names, defaults and layouts -- ``bn``, ``conv2d``, ``deconv2d``,
+``lrelu``, ``linear``, ``conv_out_size_same``, ``conv_cond_concat``, ``concat`` -- so that network
+code written against nsgan/ops.py (nsgan/GAN.py:59-101) reads the same here.  TF's
+``variable_scope`` / ``get_variable`` are restated as a small name -> tensor store with the same
+variable names (``discriminator/d_conv1/w`` ...), which is also the checkpoint key space.
+
+Each op is a ``torch.autograd.Function`` whose forward and backward-DATA run hand-written HIP
+kernels (no weight gradients: the sampler only differentiates w.r.t. activations with frozen
+weights, sampling/collaborator.py:31).  ``tf.gradients(loss, feature)`` becomes
+``torch.autograd.grad(loss.sum(), feature)``.
+"""
+import contextlib
+import math
+
+import torch
+
+from . import kernels as K
+from . import lib as L
+
+# ----------------------------------------------------------------------------- variable store
+_VARS = {}
+_SCOPE = []
+_REUSE = [False]
+_DEVICE = [None]
+
+
+def set_device(device):
+    """Device new variables are created on (default: cuda:0)."""
+    _DEVICE[0] = torch.device(device)
+
+
+def _device():
+    return _DEVICE[0] if _DEVICE[0] is not None else torch.device("cuda:0")
+
+
+@contextlib.contextmanager
+def variable_scope(name, reuse=None):
+    """tf.variable_scope(name, reuse=...)."""
+    _SCOPE.append(name)
+    _REUSE.append(_REUSE[-1] if reuse is None else bool(reuse))
+    try:
+        yield "/".join(_SCOPE)
+    finally:
+        _SCOPE.pop()
+        _REUSE.pop()
+
+
+def get_variable(name, shape, initializer):
+    """tf.get_variable: look up ``scope/name``; create it with ``initializer(shape)`` unless reusing."""
+    full = "/".join(_SCOPE + [name])
+    v = _VARS.get(full)
+    if v is None:
+        if _REUSE[-1]:
+            raise ValueError(f"Variable {full} does not exist, or was not created with get_variable() (reuse=True)")
+        v = initializer(tuple(int(s) for s in shape)).float().contiguous().to(_device())
+        _VARS[full] = v
+    elif tuple(v.shape) != tuple(int(s) for s in shape):
+        raise ValueError(f"Variable {full} has shape {tuple(v.shape)}, requested {tuple(shape)}")
+    return v
+
+
+def variables():
+    return _VARS
+
+
+def set_variables(params, device=None):
+    """Load a name -> array checkpoint (TF variable names) into the store."""
+    dev = torch.device(device) if device is not None else _device()
+    for k, v in params.items():
+        _VARS[k] = torch.as_tensor(v).float().contiguous().to(dev)
+
+
+def reset_variables():
+    _VARS.clear()
+    K.WS.clear()
+
+
+def truncated_normal_initializer(stddev):
+    def init(shape):
+        t = torch.empty(shape)
+        torch.nn.init.trunc_normal_(t, 0.0, stddev, -2 * stddev, 2 * stddev)
+        return t
+    return init
+
+
+def random_normal_initializer(stddev):
+    return lambda shape: torch.randn(shape) * stddev
+
+
+def constant_initializer(value):
+    return lambda shape: torch.full(shape, float(value))
+
+
+# ----------------------------------------------------------------------------- autograd glue
+def _no_wgrad(ctx_needs, what):
+    if any(ctx_needs):
+        raise L.CgsError(f"{what}: weight gradients are not part of the refinement path "
+                         "(frozen weights, sampling/collaborator.py:31); detach the parameters")
+
+
+class _Conv2d(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, sh, sw):
+        ctx.save_for_backward(w)
+        ctx.hw, ctx.s = (x.shape[1], x.shape[2]), (sh, sw)
+        return K.conv2d_fwd(x.contiguous(), w, b, sh, sw)
+
+    @staticmethod
+    def backward(ctx, dy):
+        _no_wgrad(ctx.needs_input_grad[1:3], "conv2d")
+        (w,) = ctx.saved_tensors
+        return K.conv2d_bwd_data(dy.contiguous(), w, ctx.hw, *ctx.s), None, None, None, None
+
+
+class _Deconv2d(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, ho, wo, sh, sw):
+        ctx.save_for_backward(w)
+        ctx.hw, ctx.s = (x.shape[1], x.shape[2]), (sh, sw)
+        return K.deconv2d_fwd(x.contiguous(), w, b, (ho, wo), sh, sw)
+
+    @staticmethod
+    def backward(ctx, dy):
+        _no_wgrad(ctx.needs_input_grad[1:3], "deconv2d")
+        (w,) = ctx.saved_tensors
+        return K.deconv2d_bwd_data(dy.contiguous(), w, ctx.hw, *ctx.s), None, None, None, None, None, None
+
+
+class _Linear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(w)
+        return K.linear_fwd(x.contiguous(), w, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        _no_wgrad(ctx.needs_input_grad[1:3], "linear")
+        (w,) = ctx.saved_tensors
+        return K.linear_bwd_data(dy.contiguous(), w), None, None
+
+
+class _BnTrain(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, leak):
+        x = x.contiguous()
+        y, mean, invstd = K.bn_train_lrelu_fwd(x, gamma, beta, leak)
+        ctx.save_for_backward(x, gamma, beta, mean, invstd)
+        ctx.leak = leak
+        ctx.mark_non_differentiable(mean, invstd)
+        return y, mean, invstd
+
+    @staticmethod
+    def backward(ctx, dy, _dm, _di):
+        _no_wgrad(ctx.needs_input_grad[1:3], "bn")
+        x, gamma, beta, mean, invstd = ctx.saved_tensors
+        return K.bn_train_lrelu_bwd_data(dy.contiguous(), x, gamma, beta, mean, invstd, ctx.leak), None, None, None
+
+
+class _Affine(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, a, b):
+        ctx.save_for_backward(a)
+        return K.affine_fwd(x.contiguous(), a, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (a,) = ctx.saved_tensors
+        return K.affine_bwd(dy.contiguous(), a), None, None
+
+
+class _Lrelu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, leak):
+        y = K.lrelu_fwd(x.contiguous(), leak)
+        ctx.save_for_backward(y)
+        ctx.leak = leak
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        return K.lrelu_bwd(dy.contiguous(), y, ctx.leak), None
+
+
+class _Tanh(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        y = K.tanh_fwd(x.contiguous())
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        return K.tanh_bwd(dy.contiguous(), y)
+
+
+# ----------------------------------------------------------------------------- the operator API
+def concat(tensors, axis, *args, **kwargs):
+    """nsgan/ops.py:12-17."""
+    return torch.cat(tensors, dim=axis)
+
+
+def bn(x, is_training, scope, leak=1.0):
+    """nsgan/ops.py:19-26: contrib batch_norm(decay=0.9, epsilon=1e-5, scale=True, updates_collections=None).
+    is_training=True: batch statistics (and the moving averages are updated in place);
+    is_training=False: moving averages.  ``leak`` (extension) fuses a following lrelu into the kernel."""
+    C = x.shape[-1]
+    with variable_scope(scope):
+        beta = get_variable("beta", [C], constant_initializer(0.0))
+        gamma = get_variable("gamma", [C], constant_initializer(1.0))
+        mm = get_variable("moving_mean", [C], constant_initializer(0.0))
+        mv = get_variable("moving_variance", [C], constant_initializer(1.0))
+    if is_training:
+        y, mean, invstd = _BnTrain.apply(x, gamma, beta, float(leak))
+        with torch.no_grad():                      # decay 0.9 moving averages (nothing on the sampling path reads D's)
+            mm.mul_(0.9).add_(0.1 * mean)
+            mv.mul_(0.9).add_(0.1 * (1.0 / (invstd * invstd) - K.BN_EPS))
+        return y
+    a, b = K.bn_fold(gamma, beta, mm, mv)
+    y = _Affine.apply(x, a, b)
+    return y if leak == 1.0 else _Lrelu.apply(y, float(leak))
+
+
+def conv_out_size_same(size, stride):
+    """nsgan/ops.py:28-29."""
+    return int(math.ceil(float(size) / float(stride)))
+
+
+def conv_cond_concat(x, y):
+    """nsgan/ops.py:31-35: concatenate a conditioning vector on the feature-map axis."""
+    return concat([x, y * torch.ones([x.shape[0], x.shape[1], x.shape[2], y.shape[3]], device=x.device)], 3)
+
+
+def conv2d(input_, output_dim, k_h=5, k_w=5, d_h=2, d_w=2, stddev=0.02, name="conv2d"):
+    """nsgan/ops.py:37-46."""
+    with variable_scope(name):
+        w = get_variable("w", [k_h, k_w, input_.shape[-1], output_dim], truncated_normal_initializer(stddev))
+        biases = get_variable("biases", [output_dim], constant_initializer(0.0))
+    return _Conv2d.apply(input_, w, biases, d_h, d_w)
+
+
+def deconv2d(input_, output_shape, k_h=5, k_w=5, d_h=2, d_w=2, name="deconv2d", stddev=0.02, with_w=False):
+    """nsgan/ops.py:48-67.  ``output_shape`` = [batch, height, width, channels] as in the reference."""
+    if int(output_shape[0]) != int(input_.shape[0]):
+        raise ValueError(f"deconv2d: output_shape batch {output_shape[0]} != input batch {input_.shape[0]}")
+    with variable_scope(name):
+        w = get_variable("w", [k_h, k_w, output_shape[-1], input_.shape[-1]], random_normal_initializer(stddev))
+        biases = get_variable("biases", [output_shape[-1]], constant_initializer(0.0))
+    deconv = _Deconv2d.apply(input_, w, biases, int(output_shape[1]), int(output_shape[2]), d_h, d_w)
+    if with_w:
+        return deconv, w, biases
+    return deconv
+
+
+def lrelu(x, leak=0.2, name="lrelu"):
+    """nsgan/ops.py:69-70."""
+    return _Lrelu.apply(x, float(leak))
+
+
+def relu(x):
+    """tf.nn.relu (nsgan/GAN.py:89-96)."""
+    return _Lrelu.apply(x, 0.0)
+
+
+def tanh(x):
+    """tf.nn.tanh (nsgan/GAN.py:100)."""
+    return _Tanh.apply(x)
+
+
+def linear(input_, output_size, scope=None, stddev=0.02, bias_start=0.0, with_w=False):
+    """nsgan/ops.py:72-83."""
+    with variable_scope(scope or "Linear"):
+        matrix = get_variable("Matrix", [input_.shape[1], output_size], random_normal_initializer(stddev))
+        bias = get_variable("bias", [output_size], constant_initializer(bias_start))
+    y = _Linear.apply(input_, matrix, bias)
+    if with_w:
+        return y, matrix, bias
+    return y
+
+
+def sigmoid_cross_entropy_with_logits_ones(logits):
+    """tf.nn.sigmoid_cross_entropy_with_logits(logits, labels=ones), unreduced (nsgan/GAN.py:176-177)."""
+    return torch.nn.functional.softplus(-logits)

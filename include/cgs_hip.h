@@ -114,6 +114,9 @@ int cgs_bn_fold(const float* gamma, const float* beta, const float* moving_mean,
 /* y = relu(a[c]*x + b[c]) and its input gradient dx = dy*(y>0)*a[c]  (G-tail bn+relu, nsgan/GAN.py:96-98). */
 int cgs_affine_relu_fwd(const float* x, const float* a, const float* b, float* y, int M, int C, void* stream);
 int cgs_affine_relu_bwd(const float* dy, const float* y, const float* a, float* dx, int M, int C, void* stream);
+/* y = a[c]*x + b[c] (inference-mode bn with no activation after it) and dx = dy*a[c]. */
+int cgs_affine_fwd(const float* x, const float* a, const float* b, float* y, int M, int C, void* stream);
+int cgs_affine_bwd(const float* dy, const float* a, float* dx, int M, int C, void* stream);
 /* y = max(x, leak*x) and dx = dy*(y>0 ? 1 : leak)   (nsgan/ops.py:69-70). */
 int cgs_lrelu_fwd(const float* x, float leak, float* y, size_t n, void* stream);
 int cgs_lrelu_bwd(const float* dy, const float* y, float leak, float* dx, size_t n, void* stream);

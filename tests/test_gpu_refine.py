@@ -1,0 +1,165 @@
+"""End-to-end parity of the refinement loop on the GPU: the fused engine and the generic
+(ops + autograd) path against (a) the golden vectors captured from the reference's
+collaborator.Refiner and (b) the CPU oracle, plus size-independent properties at larger sizes.
+
+Tolerances (fp32, SURVEY.md section 7 'hard parts'): one forward pass 1e-4 relative on logits;
+K-step trajectories 2e-3 on logits / features / images; optimal_step must agree wherever the two
+candidate logits differ by more than the trajectory tolerance."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from conftest import GOLDEN
+from oracle import nets_ref as N
+from oracle import sampling_ref as S
+
+G3 = sorted(glob.glob(os.path.join(GOLDEN, "g3_collab_*.npz")))
+
+
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def relerr(got, want):
+    got, want = np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64)
+    return np.abs(got - want).max() / (np.abs(want).max() + 1e-30)
+
+
+def check_against_golden(g, img, dl, ol, os_, of, traj_tol=2e-3):
+    assert relerr(dl.cpu().numpy(), g["default_logit"]) < 1e-4
+    assert relerr(ol.cpu().numpy(), g["optimal_logit"]) < traj_tol
+    steps_ok = os_.cpu().numpy() == g["optimal_step"]
+    if not steps_ok.all():     # a flipped select is only tolerable on a numerical tie
+        bad = ~steps_ok
+        assert np.all(np.abs(ol.cpu().numpy()[bad] - g["optimal_logit"][bad]) < traj_tol * np.abs(g["optimal_logit"]).max())
+    ok = steps_ok
+    assert ok.mean() >= 0.75
+    assert relerr(of.cpu().numpy()[ok], g["optimal_feature"][ok]) < traj_tol
+    assert relerr(img.cpu().numpy()[ok], g["images"][ok]) < traj_tol
+
+
+def load_case(path):
+    g = np.load(path, allow_pickle=True)
+    arch = str(g["arch"][0])
+    P = N.init_params(arch, seed=2019, perturb=True)
+    chk = float(sum(v.double().abs().sum() for v in P.values()))
+    assert abs(chk - float(g["params_checksum"][0])) <= 1e-9 * chk
+    c = g["constraints"]
+    vmin, vmax = (None, None) if np.isnan(c[0]) else (float(c[0]), float(c[1]))
+    return g, arch, P, vmin, vmax
+
+
+@pytest.mark.parametrize("path", G3, ids=lambda p: os.path.basename(p)[10:-4])
+@pytest.mark.parametrize("use_graph", [False, True], ids=["eager", "hipgraph"])
+def test_engine_matches_reference_golden(path, use_graph):
+    from cgs_amd.engine import RefineEngine
+    from cgs_amd.nets import to_device
+    g, arch, P, vmin, vmax = load_case(path)
+    d = dev()
+    eng = RefineEngine(arch, to_device(P, d), len(g["z"]), d, use_graph=use_graph)
+    f0 = eng.input_to_feature(torch.from_numpy(g["z"]).to(d))
+    assert relerr(f0.cpu().numpy(), g["feature0"]) < 1e-4             # the propose step (G head)
+    mode = str(g["mode"][0])
+    for _ in range(2 if use_graph else 1):                              # 2nd call = graph replay
+        out = eng.refine(torch.from_numpy(g["feature0"]).to(d), int(g["K"][0]), float(g["rate"][0]), "momentum", mode,
+                         g["indices"] if mode == "probabilistic" else None, vmin, vmax)
+        check_against_golden(g, *out)
+
+
+@pytest.mark.parametrize("path", [p for p in G3 if "K5" in p], ids=lambda p: os.path.basename(p)[10:-4])
+def test_refiner_class_generic_and_engine_paths(path):
+    """collaborator.Refiner with (a) opaque callables over cgs_amd.ops (autograd path) and
+    (b) the GAN object's own methods (engine path)."""
+    from cgs_amd import ops
+    from cgs_amd.model import GAN
+    from cgs_amd.sampling.collaborator import Refiner
+    g, arch, P, vmin, vmax = load_case(path)
+    d = dev()
+    ops.reset_variables()
+    gan = GAN(arch, batch_size=len(g["z"]), device=d, params=P)
+    mode = str(g["mode"][0])
+    idx = g["indices"] if mode == "probabilistic" else None
+    f0 = torch.from_numpy(g["feature0"]).to(d)
+    real = torch.from_numpy(g["real"]).to(d)
+    # (a) generic: wrap in lambdas so the engine detection cannot trigger
+    ref = Refiner(int(g["K"][0]), float(g["rate"][0]))
+    ref.set_env(lambda x: gan.discriminator(x, is_training=True, reuse=True), lambda f: gan.feature_to_data(f), gan.loss_refine)
+    if vmin is not None:
+        ref.set_constraints(vmin, vmax)
+    assert ref._engine_for(len(f0)) is None
+    img = ref.build_refiner(f0, real, mode, indices=idx)
+    check_against_golden(g, img, ref.default_logit, ref.optimal_logit, ref.optimal_step, ref.optimal_feature)
+    assert ref.optimizer.momentum is None                                   # reset (collaborator.py:86)
+    # (b) engine via the class surface (nsgan/GAN.py:179-183 wiring)
+    ref2 = gan.build_refiner(int(g["K"][0]), float(g["rate"][0]))
+    if vmin is not None:
+        ref2.set_constraints(vmin, vmax)
+    assert ref2._engine_for(len(f0)) is not None
+    img2 = ref2.build_refiner(f0, real, mode, indices=idx)
+    check_against_golden(g, img2, ref2.default_logit, ref2.optimal_logit, ref2.optimal_step, ref2.optimal_feature)
+    # one evaluation: logits + gradient vs the oracle (collaborator.py:26-39)
+    lm, grad = ref.compute_forward_logits_and_grad(f0)
+    lm_o, grad_o = S.forward_logits_and_grad(torch.from_numpy(g["feature0"]), lambda f: N.feature_to_data(arch, P, f),
+                                             lambda x: N.discriminator(arch, P, x))
+    assert relerr(lm.cpu().numpy(), lm_o.numpy()) < 1e-4 and relerr(grad.cpu().numpy(), grad_o.numpy()) < 1e-3
+    lm_e, grad_e = gan.engine(len(f0)).compute_forward_logits_and_grad(f0)
+    assert relerr(lm_e.cpu().numpy(), lm_o.numpy()) < 1e-4 and relerr(grad_e.cpu().numpy(), grad_o.numpy()) < 1e-3
+    ops.reset_variables()
+
+
+def test_probabilistic_draw_and_ladam_guard():
+    from cgs_amd import ops, lib
+    from cgs_amd.model import GAN
+    d = dev()
+    ops.reset_variables()
+    gan = GAN("mnist", batch_size=4, device=d, params=N.init_params("mnist", 2019, True))
+    ref = gan.build_refiner(3, 0.1)
+    z = torch.from_numpy(np.random.RandomState(0).uniform(-1, 1, (4, 62)).astype(np.float32)).to(d)
+    f0 = gan.input_to_feature(z)
+    np.random.seed(5)
+    want = np.random.randint(3 + 1, size=4)
+    np.random.seed(5)
+    ref.build_refiner(f0, None, "probabilistic")
+    np.testing.assert_array_equal(ref.indices_batch, want)               # drawn from the global RNG like collaborator.py:56
+    never = want == 3
+    assert np.all(ref.optimal_step.cpu().numpy()[never] == 1)
+    with pytest.raises(NotImplementedError):
+        ref.build_refiner(f0, None, "greedy")
+    with pytest.raises(lib.CgsError):
+        gan.engine(4).refine(f0, 2, 0.1, method="ladam")
+    ops.reset_variables()
+
+
+@pytest.mark.parametrize("arch,B,K", [("dcgan32", 256, 3), ("dcgan64", 128, 2)])
+def test_full_size_properties(arch, B, K):
+    """BASELINE-shaped nets at sizes the CPU oracle would not finish quickly: properties that hold at any size."""
+    from cgs_amd.engine import RefineEngine
+    from cgs_amd.nets import to_device, ARCHS
+    d = dev()
+    P = to_device(N.init_params(arch, 2019, True), d)
+    eng = RefineEngine(arch, P, B, d)
+    z = torch.from_numpy(np.random.RandomState(2019).uniform(-1, 1, (B, ARCHS[arch]["z_dim"])).astype(np.float32)).to(d)
+    f0 = eng.input_to_feature(z).clone()
+    img, dl, ol, os_, of = [t.clone() for t in eng.refine(f0, K, 0.1)]
+    assert torch.isfinite(img).all() and img.abs().max() <= 1.0           # tanh range
+    assert (ol >= dl).all()                                                # the best logit never decreases
+    assert ((os_ >= 1) & (os_ <= K)).all()
+    unchanged = ol == dl
+    assert torch.equal(of[unchanged], f0[unchanged])                       # never improved -> theta0 kept (step stays 1, Q1)
+    img2, dl2, ol2, os2, of2 = eng.refine(f0, K, 0.1)
+    assert torch.equal(img, img2) and torch.equal(ol, ol2) and torch.equal(os_, os2)   # deterministic, bit-identical
+    img0 = eng.refine(f0, 0, 0.1)[0].clone()                               # K = 0: plain rendering of the proposal
+    assert torch.equal(img0, eng.feature_to_data(f0))
+    idx = np.full(B, K)                                                    # probabilistic index K => never selected (Q2)
+    _, _, _, osp, ofp = eng.refine(f0, K, 0.1, mode="probabilistic", indices=idx)
+    assert torch.equal(ofp, f0) and (osp == 1).all()
+    idx0 = np.zeros(B, dtype=np.int64)                                     # index 0 => exactly one update applied
+    _, _, _, osp, ofp = eng.refine(f0, K, 0.1, mode="probabilistic", indices=idx0)
+    lm, grad = eng.compute_forward_logits_and_grad(f0)
+    assert (osp == 1).all() and torch.allclose(ofp, f0 - 0.1 * grad, rtol=0, atol=1e-6)
