@@ -46,7 +46,10 @@ static int run_dir(const CgsLayer& L, bool dirT, int B, const float* in, const f
     if (epilogue < CGS_EPI_NONE || epilogue > CGS_EPI_TANH) return cgs_set_error(CGS_EINVAL, "%s: epilogue %d", who, epilogue);
     if (epilogue == CGS_EPI_AFFINE_RELU && (!ep_a || !ep_b)) return cgs_set_error(CGS_EINVAL, "%s: affine epilogue needs a,b", who);
     if (dirT && (L.sh > 2 || L.sw > 2)) return cgs_set_error(CGS_EINVAL, "%s: transposed direction supports stride <= 2", who);
-    if (dirT && smalln_ok(L, epilogue)) return cgs_convt_smalln_launch(L, B, in, w, bias, out, epilogue, s);
+    if (dirT && smalln_ok(L, epilogue)) {
+        if ((L.Cs % 16) == 0 && ws) return cgs_convt_quad_launch(L, B, in, w, bias, out, epilogue, (float*)ws, ws_bytes, prepacked, s);
+        return cgs_convt_smalln_launch(L, B, in, w, bias, out, epilogue, s);     // VALU form (any Cs % 4 == 0)
+    }
     IgemmParams p;
     p.in = in; p.bias = bias; p.ep_a = ep_a; p.ep_b = ep_b; p.out = out; p.B = B; p.epilogue = epilogue;
     if (dirT) cgs_geom_T(L, p); else cgs_geom_F(L, p);
@@ -78,6 +81,10 @@ size_t cgs_conv_ws_bytes(int op, int kh, int kw, int sh, int sw, int Cin, int Co
             const int nty = a < kh ? (kh - a + sh - 1) / sh : 0, ntx = b < kw ? (kw - b + sw - 1) / sw : 0;
             n += (size_t)cgs_round_up(nty * ntx * Cs, CGS_BK) * cgs_round_up(Cb, 64);
         }
+    if (Cb <= 4 && sh == 2 && sw == 2) {      // quad-form small-N kernel keeps its own packed copy
+        const size_t q = cgs_convt_quad_ws_floats_bound(kh, kw, Cs);
+        if (q > n) n = q;
+    }
     return n * sizeof(float);
 }
 

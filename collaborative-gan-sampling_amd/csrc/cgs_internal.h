@@ -74,5 +74,8 @@ size_t cgs_packed_floats(const IgemmParams& p);
 // launchers
 int cgs_pack_weights(const IgemmParams& p, const CgsLayer& L, bool dirT, const float* w, float* packed, hipStream_t s);
 int cgs_igemm_launch(const IgemmParams& p, hipStream_t s);
+size_t cgs_convt_quad_ws_floats_bound(int kh, int kw, int Cs);
+int cgs_convt_quad_launch(const CgsLayer& L, int B, const float* in, const float* w, const float* bias, float* out,
+                          int epilogue, float* ws, size_t ws_bytes, int prepacked, hipStream_t s);
 int cgs_convt_smalln_launch(const CgsLayer& L, int B, const float* in, const float* w, const float* bias,
                             float* out, int epilogue, hipStream_t s);

@@ -1,0 +1,185 @@
+// Transposed stride-2 convolution with <= 4 output channels on the fp32 matrix cores, "quad" form:
+// the last generator deconv (64 -> 3, nsgan/GAN.py:99 / DCGAN g_h4) and the backward-data of the first
+// discriminator conv (3 <- 64, nsgan/GAN.py:64 via sampling/collaborator.py:31).
+//
+// With N = 3 output channels a per-parity-class GEMM fills 3 of 32 MFMA columns.  Instead one GEMM row
+// is an input-resolution pixel ("quad") and its columns are all 2x2 output pixels x N channels of that
+// quad (4N <= 16 columns = one v_mfma_f32_16x16x4_f32 tile); K runs over the quad's input neighbourhood
+// (<= 3x3 pixels) x Cs channels, with zero weights where a (neighbour, parity) pair has no tap:
+//
+//   out[b, 2r+py, 2c+px, n] = epi(bias[n] + sum_{dy,dx,ci} in[b, r+dy, c+dx, ci] * Wq[(dy,dx,ci)][(py,px,n)])
+//
+// 12 of 16 columns and 25 of 36 (neighbour,parity) pairs carry work: ~52 % useful MFMA work instead of ~9 %.
+// A fragments are read straight from global memory (each lane one float4 = 4 consecutive ci of its
+// row; the K order inside a 16-channel chunk is permuted identically for A and B so no shuffle is
+// needed); the packed weights (37 KB for 9 x 64 x 16) sit in LDS for the whole block.
+#include "cgs_internal.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct QuadParams {
+    const float* in;     // [B,Hs,Ws,Cs]
+    const float* wq;     // packed [K/4][16][4], K = ny*nx*Cs
+    const float* bias;   // [N] or null
+    float* out;          // [B,2Hs,2Ws,N]
+    int B, Hs, Ws, Cs, N;
+    int dmin_y, ny, dmin_x, nx;
+    int epilogue;
+};
+
+// w[kh][kw][N][Cs] -> Wq[(a,bq,ci)][(py,px,n)], a/bq index the neighbourhood rows/cols (dy = dmin_y + a)
+__global__ void pack_quad_weights_kernel(const float* __restrict__ w, float* __restrict__ wq, int kh, int kw, int N, int Cs,
+                                         int pt, int pl, int dmin_y, int ny, int dmin_x, int nx) {
+    const int K = ny * nx * Cs;
+    const int total = K * 16;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int e = i & 3, col = (i >> 2) & 15, k = (i >> 6) * 4 + e;
+        const int nb = k / Cs, ci = k - nb * Cs;
+        const int a = nb / nx, bq = nb - a * nx;
+        const int cls = col / N, n = col - cls * N;
+        float v = 0.f;
+        if (cls < 4) {
+            const int py = cls >> 1, px = cls & 1;
+            const int ky = py + pt - 2 * (dmin_y + a), kx = px + pl - 2 * (dmin_x + bq);
+            if (ky >= 0 && ky < kh && kx >= 0 && kx < kw) v = w[((size_t)(ky * kw + kx) * N + n) * Cs + ci];
+        }
+        wq[i] = v;
+    }
+}
+
+template <int MT>
+__global__ __launch_bounds__(256) void convt_quad_mfma_kernel(QuadParams p) {
+    extern __shared__ __attribute__((aligned(16))) float Bs[];
+    const int tid = threadIdx.x;
+    const int K = p.ny * p.nx * p.Cs;
+    for (int i = tid; i < K * 4; i += 256) ((f32x4*)Bs)[i] = ((const f32x4*)p.wq)[i];
+    __syncthreads();
+
+    const int lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, i = lane & 15;
+    const long HW = (long)p.Hs * p.Ws;
+    const long total = (long)p.B * HW;
+    const long q0 = ((long)blockIdx.x * 4 + wave) * (16 * MT);
+    if (q0 >= total) return;
+
+    int pbase[MT], pr[MT], pc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        const long q = q0 + t * 16 + i;
+        if (q < total) {
+            const int b = (int)(q / HW);
+            const int rem = (int)(q - (long)b * HW);
+            pr[t] = rem / p.Ws; pc[t] = rem - pr[t] * p.Ws; pbase[t] = b * p.Hs;
+        } else {
+            pr[t] = -(1 << 20); pc[t] = 0; pbase[t] = 0;
+        }
+    }
+    const int nchunk = p.Cs >> 4;
+    const int nit = p.ny * p.nx * nchunk;
+
+    f32x4 acc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    f32x4 a_cur[MT], a_nxt[MT];
+#define LOAD_A(dst, it_)                                                                              \
+    do {                                                                                              \
+        const int nb_ = (it_) / nchunk, ch_ = (it_) - nb_ * nchunk;                                   \
+        const int a_ = nb_ / p.nx, b_ = nb_ - a_ * p.nx;                                              \
+        const int dy_ = p.dmin_y + a_, dx_ = p.dmin_x + b_;                                           \
+        _Pragma("unroll") for (int t = 0; t < MT; ++t) {                                              \
+            const int iy = pr[t] + dy_, ix = pc[t] + dx_;                                             \
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};                                                           \
+            if ((unsigned)iy < (unsigned)p.Hs && (unsigned)ix < (unsigned)p.Ws)                       \
+                v = *(const f32x4*)(p.in + ((size_t)(pbase[t] + iy) * p.Ws + ix) * p.Cs + ch_ * 16 + g * 4); \
+            dst[t] = v;                                                                               \
+        }                                                                                             \
+    } while (0)
+
+    LOAD_A(a_cur, 0);
+    for (int it = 0; it < nit; ++it) {
+        if (it + 1 < nit) LOAD_A(a_nxt, it + 1);
+        // B fragment: k-quad (it*4 + g), column i
+        const f32x4 fb = *(const f32x4*)(Bs + ((size_t)(it * 4 + g) * 16 + i) * 4);
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[t].x, fb.x, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[t].y, fb.y, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[t].z, fb.z, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[t].w, fb.w, acc[t], 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < MT; ++t) a_cur[t] = a_nxt[t];
+    }
+#undef LOAD_A
+
+    // epilogue.  C/D of 16x16x4: col = lane & 15, row = (lane >> 4) * 4 + reg
+    const int col = i;
+    const int cls = col / p.N, n = col - cls * p.N;
+    if (cls >= 4) return;
+    const int py = cls >> 1, px = cls & 1;
+    const float bias = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const long q = q0 + t * 16 + g * 4 + r;
+            if (q >= total) continue;
+            const int b = (int)(q / HW);
+            const int rem = (int)(q - (long)b * HW);
+            const int rr = rem / p.Ws, cc = rem - rr * p.Ws;
+            float v = acc[t][r] + bias;
+            if (p.epilogue == CGS_EPI_TANH) v = tanhf(v);
+            else if (p.epilogue == CGS_EPI_LRELU) v = fmaxf(v, 0.2f * v);
+            p.out[((size_t)(b * 2 * p.Hs + 2 * rr + py) * (2 * p.Ws) + 2 * cc + px) * p.N + n] = v;
+        }
+}
+
+static void quad_range(int k, int pad, int& lo, int& hi) {
+    lo = 1 << 20; hi = -(1 << 20);
+    for (int par = 0; par < 2; ++par)
+        for (int kk = 0; kk < k; ++kk)
+            if (((par + pad - kk) & 1) == 0) {
+                const int d = (par + pad - kk) / 2;
+                if (d < lo) lo = d;
+                if (d > hi) hi = d;
+            }
+}
+
+size_t cgs_convt_quad_ws_floats_bound(int kh, int kw, int Cs) {
+    return (size_t)((kh + 1) / 2 + 1) * ((kw + 1) / 2 + 1) * Cs * 16;
+}
+
+int cgs_convt_quad_launch(const CgsLayer& L, int B, const float* in, const float* w, const float* bias, float* out,
+                          int epilogue, float* ws, size_t ws_bytes, int prepacked, hipStream_t s) {
+    QuadParams p;
+    p.in = in; p.wq = ws; p.bias = bias; p.out = out;
+    p.B = B; p.Hs = L.Hs; p.Ws = L.Ws; p.Cs = L.Cs; p.N = L.Cb; p.epilogue = epilogue;
+    const int pt = cgs_same_pad_before(L.Hb, L.kh, 2), pl = cgs_same_pad_before(L.Wb, L.kw, 2);
+    int hy, hx;
+    quad_range(L.kh, pt, p.dmin_y, hy);
+    quad_range(L.kw, pl, p.dmin_x, hx);
+    p.ny = hy - p.dmin_y + 1; p.nx = hx - p.dmin_x + 1;
+    const size_t K = (size_t)p.ny * p.nx * L.Cs;
+    const size_t need = K * 16 * sizeof(float);
+    if (!ws || ws_bytes < need) return cgs_set_error(CGS_EWORKSPACE, "convt_quad: workspace %zu < %zu bytes", ws_bytes, need);
+    if (need > 150 * 1024) return cgs_set_error(CGS_EINVAL, "convt_quad: packed weights (%zu B) exceed LDS", need);
+    if (!prepacked) {
+        hipLaunchKernelGGL(pack_quad_weights_kernel, dim3((unsigned)((K * 16 + 255) / 256)), dim3(256), 0, s, w, ws, L.kh, L.kw,
+                           L.Cb, L.Cs, pt, pl, p.dmin_y, p.ny, p.dmin_x, p.nx);
+        CGS_CHECK_LAUNCH("pack_quad_weights");
+    }
+    constexpr int MT = 4;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)convt_quad_mfma_kernel<MT>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        if (e != hipSuccess) return cgs_set_error(CGS_ELAUNCH, "convt_quad smem attr: %s", hipGetErrorString(e));
+        attr_done = true;
+    }
+    const long total = (long)B * L.Hs * L.Ws;
+    if (total == 0) return CGS_OK;
+    const long blocks = (total + 64 * MT - 1) / (64 * MT);
+    hipLaunchKernelGGL(convt_quad_mfma_kernel<MT>, dim3((unsigned)blocks), dim3(256), need, s, p);
+    CGS_CHECK_LAUNCH("convt_quad_mfma");
+    return CGS_OK;
+}

@@ -39,7 +39,7 @@ PROFILE = None
 def igemm_kernel_name(dirT, kh, kw, sh, sw, Cb, Cs, Hb, Wb, Hs, Ws, epilogue=0):
     """Which kernel the C-ABI dispatcher (csrc/api.hip run_dir) picks for a conv-family call."""
     if dirT and Cb <= 4 and sh == 2 and sw == 2 and Hb == 2 * Hs and Wb == 2 * Ws and Cs % 4 == 0 and epilogue != L.EPI_AFFINE_RELU:
-        return "convt_smalln_kernel"
+        return "convt_quad_mfma_kernel" if Cs % 16 == 0 else "convt_smalln_kernel"
     cred, n = (Cs, Cb) if dirT else (Cb, Cs)
     npad = (n + 63) // 64 * 64
     return "igemm_kernel<128,%d,%s>" % (128 if npad % 128 == 0 else 64, "true" if cred % 32 == 0 else "false")

