@@ -62,7 +62,19 @@ static int run_dir(const CgsLayer& L, bool dirT, int B, const float* in, const f
         int rc = cgs_pack_weights(p, L, dirT, w, (float*)ws, s);
         if (rc) return rc;
     }
-    return cgs_igemm_launch(p, s);
+    // one launch addresses its tensors with 32-bit byte offsets: split the batch so each stays < 2 GiB
+    const size_t in_img = (size_t)p.Hin * p.Win * p.Cred * 4, out_img = (size_t)p.Hout * p.Wout * p.N * 4;
+    const size_t per = in_img > out_img ? in_img : out_img;
+    long chunk = (long)(0x7fffffffUL / per);
+    if (chunk < 1) return cgs_set_error(CGS_EINVAL, "%s: one image exceeds 2 GiB", who);
+    for (long b0 = 0; b0 < B; b0 += chunk) {
+        p.B = (int)(B - b0 < chunk ? B - b0 : chunk);
+        p.in = in + (size_t)b0 * (in_img / 4);
+        p.out = out + (size_t)b0 * (out_img / 4);
+        int rc = cgs_igemm_launch(p, s);
+        if (rc) return rc;
+    }
+    return CGS_OK;
 }
 
 extern "C" {

@@ -175,6 +175,9 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
     const int nk = (c.K + BK - 1) / BK;
 
     f32x4 ra[AI], rb[BI];
+    // buffer descriptor over the input tensor (wave-uniform: built from kernel arguments only)
+    const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)p.in, 0, (int)((unsigned)p.B * (unsigned)p.Hin * (unsigned)p.Win * (unsigned)p.Cred * 4u), 0x00020000);
     // global -> registers for K tile kt_ (issued early; consumed by STORE_TILE after the MFMA block)
 #define LOAD_TILE(kt_)                                                                                          \
     do {                                                                                                        \
@@ -185,10 +188,11 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
             const int dy = ta * p.dstep, dx = tb * p.dstep;                                                     \
             _Pragma("unroll") for (int i = 0; i < AI; ++i) {                                                    \
                 const int iy = a_iy[i] + dy, ix = a_ix[i] + dx;                                                 \
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};                                                                 \
-                if ((unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win)                           \
-                    v = *(const f32x4*)(p.in + ((size_t)(a_base[i] + iy * p.Win + ix) * p.Cred + ci));          \
-                ra[i] = v;                                                                                      \
+                const bool ok = (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;               \
+                /* branch-free zero padding: out-of-range rows use an offset past the buffer's num_records, */  \
+                /* for which the hardware bounds check of buffer_load returns 0 */                              \
+                const unsigned off = ok ? (unsigned)((a_base[i] + iy * p.Win + ix) * p.Cred + ci) * 4u : 0xFFFFFFF0u; \
+                ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, off, 0, 0));   \
             }                                                                                                   \
         } else {                                                                                                \
             _Pragma("unroll") for (int i = 0; i < AI; ++i) {                                                    \
@@ -308,8 +312,8 @@ static int launch_cfg(const IgemmParams& p, hipStream_t s) {
 }
 
 int cgs_igemm_launch(const IgemmParams& p, hipStream_t s) {
-    if ((long)p.B * p.Hout * p.Wout > 0x7fffffffL || (long)p.B * p.Hin * p.Win > 0x7fffffffL)
-        return cgs_set_error(CGS_EINVAL, "igemm: tensor has more than 2^31 pixels");
+    if ((long)p.B * p.Hout * p.Wout * p.N * 4 > 0x7fffffffL || (long)p.B * p.Hin * p.Win * p.Cred * 4 > 0x7fffffffL)
+        return cgs_set_error(CGS_EINVAL, "igemm: a tensor of one launch exceeds 2 GiB (the caller splits the batch)");
     const bool vec = (p.Cred % BK) == 0;
     const bool wide = (p.Np % 128) == 0;
     if (vec) return wide ? launch_cfg<128, 128, true>(p, s) : launch_cfg<128, 64, true>(p, s);
