@@ -1,0 +1,187 @@
+"""CPU-only tests: host-side classes against the golden vectors captured from the reference, the C ABI
+surface (library loads, exports every declared symbol; no compute without a GPU), loud failure of the
+device path without a GPU, the layer-list / FLOP model, and the sharding + gather plumbing over gloo."""
+import os
+import re
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, load_golden
+from oracle import nets_ref as N
+from oracle import sampling_ref as S
+
+
+def test_policy_bit_exact_vs_reference():
+    from cgs_amd.sampling import PolicyAdaptive
+    g = load_golden("g2_policy.npz")
+    for m in ("sgd", "momentum", "ladam"):
+        p = PolicyAdaptive(0.1, m)
+        th = g["theta0"].copy()
+        for i in range(3):
+            r = p.apply_gradient(th, g["grads"][i], g["losses"][i])
+            assert r is th                                        # in place on ndarrays (policy.py `theta -= ...`)
+            np.testing.assert_array_equal(th, g[m][i])
+        p.reset_moving_average()
+        assert p.momentum is None and p.mean_square is None and p.loss is None
+    p = PolicyAdaptive(0.5, "momentum")
+    th = torch.from_numpy(g["theta0_map"])
+    for i in range(3):
+        th = p.apply_gradient(th, torch.from_numpy(g["grads_map"][i]))
+        np.testing.assert_allclose(th.numpy(), g["momentum_map"][i], rtol=1e-6, atol=1e-7)
+    with pytest.raises(NotImplementedError):
+        PolicyAdaptive(0.1, "adamw").apply_gradient(np.zeros((2, 2)), np.zeros((2, 2)))
+    with pytest.raises(ValueError):
+        PolicyAdaptive(0.1, "ladam").apply_gradient(np.zeros((2, 2)), np.zeros((2, 2)))     # quirk Q7 made explicit
+
+
+def test_refiner_cpu_config1_matches_reference():
+    """BASELINE config 1 (Imbal-8Gaussians, B=512, K=10, ladam): the product's refiner_cpu.Refiner driven
+    exactly like the reference's (duck-typed gan / sess / data), against the reference's own output."""
+    from cgs_amd.sampling import refiner_cpu
+    g = load_golden("g1_refiner_cpu.npz")
+    Ws = [torch.from_numpy(w) for w in g["W"]]
+    bs = [torch.from_numpy(b) for b in g["b"]]
+    calls = []
+
+    class Gan:
+        fake_samples, fake_sigmoid, fake_saliency = "x", "sig", "sal"
+
+    class Sess:
+        def run(self, fetches, feed_dict):
+            sig, sal = S.mlp_sigmoid_and_saliency(Ws, bs, feed_dict[Gan.fake_samples])
+            calls.append(1)
+            return [{"sig": sig, "sal": sal}[f] for f in fetches]
+
+    class Data:
+        def next_batch(self, n):
+            return S.toy_next_batch("Imbal-8Gaussians", 10.0, 0.9, n)
+
+    args = types.SimpleNamespace(rollout_steps=10, rollout_rate=0.1, rollout_method="ladam")
+    for mode in ("deterministic", "probabilistic"):
+        ref = refiner_cpu.Refiner(args)
+        ref.set_env(Gan, Sess(), Data())
+        np.random.seed(2019)
+        calls.clear()
+        fake = g["fake"].copy()
+        out = ref.manipulate_sample(fake, mode)
+        np.testing.assert_array_equal(fake, g["fake"])            # input untouched
+        assert len(calls) == int(g[mode + "_calls"][0]) == 12      # K+2 D evaluations
+        assert str(out.dtype) == str(g[mode + "_dtype"][0])
+        np.testing.assert_allclose(out, g[mode], rtol=0, atol=1e-6)
+        assert ref.policy.momentum is None
+    with pytest.raises(NotImplementedError):
+        ref.manipulate_sample(g["fake"].copy(), "greedy")
+
+
+def test_rejector_bit_exact_vs_reference():
+    from cgs_amd.sampling import Rejector
+    g = load_golden("g6_rejector.npz")
+    for tag, pct in (("p60", 60.0), ("p100", 100.0), ("none", None)):
+        r = Rejector()
+        np.random.seed(2019)
+        for c in range(3):
+            samples = np.arange(257, dtype=np.float32).reshape(-1, 1)
+            good = r.sampling(samples, g[f"{tag}_sig{c}"], shift_percent=pct)
+            np.testing.assert_array_equal(r.last_accept, g[f"{tag}_mask{c}"])     # accept mask: bit-exact
+            np.testing.assert_array_equal(good[:, 0], samples[g[f"{tag}_mask{c}"], 0])
+            assert r.D_tilde_M == g[f"{tag}_M{c}"][0]
+    r = Rejector()
+    r.set_score_max(np.array(0.93, dtype=np.float32))
+    assert r.D_tilde_M == g["set_score_max_M"][0]
+    with pytest.raises(NotImplementedError):
+        r.sampling(np.zeros((2, 1)), np.full((2, 1), 0.5), ranking=[0, 1])
+
+
+def test_independence_sampler_exact_vs_reference():
+    from cgs_amd.sampling import IndependenceSampler
+    g = load_golden("g7_mh.npz")
+    mh = IndependenceSampler(T=20)
+    mh.set_score_curr(0.4)
+    np.random.seed(2019)
+    for c in range(2):
+        good = mh.sampling(np.arange(400, dtype=np.float32).reshape(-1, 1), g[f"sig{c}"])
+        assert good.dtype == np.float32
+        np.testing.assert_array_equal(good[:, 0].astype(np.int64), g[f"accepted{c}"])
+    with pytest.raises(AssertionError):
+        mh.sampling(np.zeros((2, 1)), np.array([[0.5], [1.5]]))
+
+
+def test_c_abi_library_exports_every_declared_symbol():
+    from cgs_amd import lib
+    header = open(os.path.join(ROOT, "include", "cgs_hip.h")).read()
+    declared = set(re.findall(r"\b(cgs_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    assert declared == set(lib.SIGNATURES), (declared ^ set(lib.SIGNATURES))
+    l = lib.load()                                                  # dlopen + dlsym of each entry point
+    for name in declared:
+        assert getattr(l, name) is not None
+    assert l.cgs_version() >= 100
+    assert lib.conv_ws_bytes(lib.CONV_FWD, 5, 5, 2, 2, 64, 128) == 25 * 64 * 128 * 4
+    assert lib.bn_ws_bytes(1000, 128) > 0
+
+
+def test_device_path_fails_loudly_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from cgs_amd import kernels as K, lib
+    from cgs_amd.engine import RefineEngine
+    with pytest.raises(lib.CgsError):
+        K.conv2d_fwd(torch.zeros(1, 4, 4, 8), torch.zeros(5, 5, 8, 8), None)      # CPU tensors are rejected, no fallback
+    with pytest.raises(lib.CgsError):
+        RefineEngine("mnist", {}, 4, device="cpu")
+
+
+def test_layer_lists_agree_with_oracle_and_flop_model():
+    from cgs_amd import nets
+    for arch in ("mnist", "dcgan32", "dcgan64"):
+        assert nets.param_shapes(arch) == {k: tuple(v) for k, v in N.param_shapes(arch).items()}
+        assert nets.macs_per_sample(arch) == N.macs_per_sample(arch)
+    # GFLOP per refined sample
+    assert abs(nets.refine_flops_per_sample("mnist", 50) / 1e9 - 3.987) < 0.01
+    assert abs(nets.refine_flops_per_sample("dcgan32", 20) / 1e9 - 5.631) < 0.01
+    assert abs(nets.refine_flops_per_sample("dcgan64", 20) / 1e9 - 22.522) < 0.01
+
+
+def test_kernel_name_mirror_of_dispatcher():
+    from cgs_amd import kernels as K
+    assert K.igemm_kernel_name(False, 5, 5, 2, 2, 64, 128, 32, 32, 16, 16) == "igemm_kernel<128,128,true>"
+    assert K.igemm_kernel_name(False, 5, 5, 2, 2, 3, 64, 64, 64, 32, 32) == "igemm_kernel<128,64,false>"
+    assert K.igemm_kernel_name(True, 5, 5, 2, 2, 3, 64, 64, 64, 32, 32) == "convt_quad_mfma_kernel"
+    assert K.igemm_kernel_name(True, 5, 5, 2, 2, 64, 128, 32, 32, 16, 16) == "igemm_kernel<128,64,true>"
+
+
+def _gloo_worker(rank, world, port, out):
+    import torch.distributed as dist
+    from cgs_amd import dist as D
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    z = torch.from_numpy(D.z_batches(rank, 3, 4, 5))
+
+    def fake_refine(zb):                       # stand-in for the GPU engine: deterministic function of z
+        return zb.view(4, 5, 1).repeat(1, 1, 2), zb.sum(1), torch.full((4,), float(rank))
+    img, logit, step = D.refine_pool(fake_refine, z)
+    if rank == 0:
+        torch.save((img, logit, step), out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharding_and_gather_over_gloo(tmp_path):
+    import torch.multiprocessing as mp
+    from cgs_amd import dist as D
+    world, out = 2, str(tmp_path / "pool.pt")
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_gloo_worker, args=(world, port, out), nprocs=world, join=True)
+    img, logit, step = torch.load(out)
+    assert img.shape == (world * 3 * 4, 5, 2) and logit.shape == (24,) and step.shape == (24,)
+    for r in range(world):
+        z = torch.from_numpy(D.z_batches(r, 3, 4, 5)).reshape(12, 5)
+        np.testing.assert_array_equal(img[r * 12:(r + 1) * 12, :, 0].numpy(), z.numpy())       # rank-major pool
+        np.testing.assert_allclose(logit[r * 12:(r + 1) * 12].numpy(), z.sum(1).numpy(), rtol=1e-6)
+        assert (step[r * 12:(r + 1) * 12] == r).all()
+    assert not np.array_equal(D.z_batches(0, 1, 4, 5), D.z_batches(1, 1, 4, 5))                  # disjoint shards
+    assert D.batch_owner(5, 4) == (1, 1) and D.rank_seed(3) == 2022
+    assert D.gather_pool(torch.ones(2, 3)).shape == (2, 3)                                        # no group: identity
