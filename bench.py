@@ -63,6 +63,7 @@ def main():
     ap.add_argument("--rate", type=float, default=0.1)
     ap.add_argument("--graph", action="store_true", help="replay the K-step program as a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--by-layer", action="store_true", help="key the per-kernel timing records by layer shape too (diagnostic)")
     args = ap.parse_args()
 
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
@@ -72,7 +73,8 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (there is no CPU path to benchmark)"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    use_dist = "RANK" in os.environ and "MASTER_ADDR" in os.environ      # launched by torch.distributed.run (any world size)
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
@@ -89,32 +91,33 @@ def main():
     n_batches = args.steps + args.warmup
     rs = np.random.RandomState(2019 + rank)                            # rank-offset seed: disjoint z shards
     z = torch.from_numpy(rs.uniform(-1, 1, (n_batches, B, A["z_dim"])).astype(np.float32)).to(dev)
-    pool = torch.empty((world * B,) + tuple(A["img"]), dtype=torch.float32, device=dev) if world > 1 else None
+    pool = torch.empty((world * B,) + tuple(A["img"]), dtype=torch.float32, device=dev) if use_dist else None
 
     def step(i):
         img = eng.refine_from_z(z[i], Ksteps, args.rate)[0]
-        if world > 1:
+        if use_dist:
             dist.all_gather_into_tensor(pool, img)                     # RCCL over xGMI: the refined sample pool
         return img
 
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize(dev)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize(dev)
     if rank == 0 and not args.graph:
         K.PROFILE = {}
+        K.PROFILE_BY_LAYER = args.by_layer
     t0 = time.perf_counter()
     for i in range(args.warmup, n_batches):
         step(i)
     torch.cuda.synchronize(dev)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
     prof, K.PROFILE = K.PROFILE, None
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -151,7 +154,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.arch, Ksteps, args.rate)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -6,6 +6,9 @@
 #include "cgs_internal.h"
 
 static thread_local char g_err[512] = "";
+static thread_local const char* g_last_kernel = "";
+
+void cgs_note_kernel(const char* name) { g_last_kernel = name; }
 
 int cgs_set_error(int code, const char* fmt, ...) {
     va_list ap;
@@ -19,6 +22,7 @@ extern "C" {
 
 int cgs_version(void) { return 100; }
 const char* cgs_last_error(void) { return g_err; }
+const char* cgs_last_kernel(void) { return g_last_kernel; }
 
 }  // extern "C"
 
@@ -39,19 +43,23 @@ static int make_layer(CgsLayer& L, int kh, int kw, int sh, int sw, int Hb, int W
 }
 
 static int run_dir(const CgsLayer& L, bool dirT, int B, const float* in, const float* w, const float* bias, float* out,
-                   int epilogue, const float* ep_a, const float* ep_b, void* ws, size_t ws_bytes, int prepacked,
-                   hipStream_t s, const char* who) {
+                   int epilogue, const float* ep_a, const float* ep_b, const float* ep_aux, void* ws, size_t ws_bytes,
+                   int prepacked, hipStream_t s, const char* who) {
     if (B <= 0) return cgs_set_error(CGS_EINVAL, "%s: B=%d", who, B);
     if (!in || !w || !out) return cgs_set_error(CGS_EINVAL, "%s: null tensor", who);
-    if (epilogue < CGS_EPI_NONE || epilogue > CGS_EPI_TANH) return cgs_set_error(CGS_EINVAL, "%s: epilogue %d", who, epilogue);
+    if (epilogue < CGS_EPI_NONE || epilogue > CGS_EPI_TANH_BWD) return cgs_set_error(CGS_EINVAL, "%s: epilogue %d", who, epilogue);
     if (epilogue == CGS_EPI_AFFINE_RELU && (!ep_a || !ep_b)) return cgs_set_error(CGS_EINVAL, "%s: affine epilogue needs a,b", who);
+    if (epilogue >= CGS_EPI_RELU_BWD_AFFINE && (!ep_aux || (epilogue == CGS_EPI_RELU_BWD_AFFINE && !ep_a)))
+        return cgs_set_error(CGS_EINVAL, "%s: backward epilogue %d needs aux%s", who, epilogue, epilogue == CGS_EPI_RELU_BWD_AFFINE ? " and a" : "");
     if (dirT && (L.sh > 2 || L.sw > 2)) return cgs_set_error(CGS_EINVAL, "%s: transposed direction supports stride <= 2", who);
     if (dirT && smalln_ok(L, epilogue)) {
-        if ((L.Cs % 16) == 0 && ws) return cgs_convt_quad_launch(L, B, in, w, bias, out, epilogue, (float*)ws, ws_bytes, prepacked, s);
-        return cgs_convt_smalln_launch(L, B, in, w, bias, out, epilogue, s);     // VALU form (any Cs % 4 == 0)
+        if ((L.Cs % 16) == 0 && ws)
+            return cgs_convt_quad_launch(L, B, in, w, bias, out, epilogue, ep_a, ep_aux, (float*)ws, ws_bytes, prepacked, s);
+        if (epilogue < CGS_EPI_RELU_BWD_AFFINE)
+            return cgs_convt_smalln_launch(L, B, in, w, bias, out, epilogue, s);     // VALU form (any Cs % 4 == 0)
     }
     IgemmParams p;
-    p.in = in; p.bias = bias; p.ep_a = ep_a; p.ep_b = ep_b; p.out = out; p.B = B; p.epilogue = epilogue;
+    p.in = in; p.bias = bias; p.ep_a = ep_a; p.ep_b = ep_b; p.ep_aux = ep_aux; p.out = out; p.B = B; p.epilogue = epilogue;
     if (dirT) cgs_geom_T(L, p); else cgs_geom_F(L, p);
     const size_t need = cgs_packed_floats(p) * sizeof(float);
     if (!ws || ws_bytes < need) return cgs_set_error(CGS_EWORKSPACE, "%s: workspace %zu < %zu bytes", who, ws_bytes, need);
@@ -71,6 +79,7 @@ static int run_dir(const CgsLayer& L, bool dirT, int B, const float* in, const f
         p.B = (int)(B - b0 < chunk ? B - b0 : chunk);
         p.in = in + (size_t)b0 * (in_img / 4);
         p.out = out + (size_t)b0 * (out_img / 4);
+        p.ep_aux = ep_aux ? ep_aux + (size_t)b0 * (out_img / 4) : nullptr;
         int rc = cgs_igemm_launch(p, s);
         if (rc) return rc;
     }
@@ -106,15 +115,17 @@ int cgs_conv2d_nhwc_fwd(const float* x, const float* w, const float* bias, float
     CgsLayer L;
     int rc = make_layer(L, kh, kw, sh, sw, H, W, Cin, cgs_ceil_div(H, sh > 0 ? sh : 1), cgs_ceil_div(W, sw > 0 ? sw : 1), Cout, "conv2d_nhwc_fwd");
     if (rc) return rc;
-    return run_dir(L, false, B, x, w, bias, y, epilogue, ep_a, ep_b, ws, ws_bytes, ws_prepacked, (hipStream_t)stream, "conv2d_nhwc_fwd");
+    return run_dir(L, false, B, x, w, bias, y, epilogue, ep_a, ep_b, nullptr, ws, ws_bytes, ws_prepacked, (hipStream_t)stream, "conv2d_nhwc_fwd");
 }
 
 int cgs_conv2d_nhwc_bwd_data(const float* dy, const float* w, float* dx, int B, int H, int W, int Cin, int Cout, int kh,
-                             int kw, int sh, int sw, void* ws, size_t ws_bytes, int ws_prepacked, void* stream) {
+                             int kw, int sh, int sw, int epilogue, const float* ep_a, const float* ep_aux, void* ws,
+                             size_t ws_bytes, int ws_prepacked, void* stream) {
+    if (epilogue != CGS_EPI_NONE && epilogue < CGS_EPI_RELU_BWD_AFFINE) return cgs_set_error(CGS_EINVAL, "conv2d_nhwc_bwd_data: epilogue %d", epilogue);
     CgsLayer L;
     int rc = make_layer(L, kh, kw, sh, sw, H, W, Cin, cgs_ceil_div(H, sh > 0 ? sh : 1), cgs_ceil_div(W, sw > 0 ? sw : 1), Cout, "conv2d_nhwc_bwd_data");
     if (rc) return rc;
-    return run_dir(L, true, B, dy, w, nullptr, dx, CGS_EPI_NONE, nullptr, nullptr, ws, ws_bytes, ws_prepacked, (hipStream_t)stream, "conv2d_nhwc_bwd_data");
+    return run_dir(L, true, B, dy, w, nullptr, dx, epilogue, ep_a, nullptr, ep_aux, ws, ws_bytes, ws_prepacked, (hipStream_t)stream, "conv2d_nhwc_bwd_data");
 }
 
 int cgs_deconv2d_nhwc_fwd(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int Cin,
@@ -123,16 +134,17 @@ int cgs_deconv2d_nhwc_fwd(const float* x, const float* w, const float* bias, flo
     CgsLayer L;
     int rc = make_layer(L, kh, kw, sh, sw, Ho, Wo, Cout, H, W, Cin, "deconv2d_nhwc_fwd");
     if (rc) return rc;
-    return run_dir(L, true, B, x, w, bias, y, epilogue, ep_a, ep_b, ws, ws_bytes, ws_prepacked, (hipStream_t)stream, "deconv2d_nhwc_fwd");
+    return run_dir(L, true, B, x, w, bias, y, epilogue, ep_a, ep_b, nullptr, ws, ws_bytes, ws_prepacked, (hipStream_t)stream, "deconv2d_nhwc_fwd");
 }
 
 int cgs_deconv2d_nhwc_bwd_data(const float* dy, const float* w, float* dx, int B, int H, int W, int Cin, int Ho, int Wo,
-                               int Cout, int kh, int kw, int sh, int sw, void* ws, size_t ws_bytes, int ws_prepacked,
-                               void* stream) {
+                               int Cout, int kh, int kw, int sh, int sw, int epilogue, const float* ep_a,
+                               const float* ep_aux, void* ws, size_t ws_bytes, int ws_prepacked, void* stream) {
+    if (epilogue != CGS_EPI_NONE && epilogue < CGS_EPI_RELU_BWD_AFFINE) return cgs_set_error(CGS_EINVAL, "deconv2d_nhwc_bwd_data: epilogue %d", epilogue);
     CgsLayer L;
     int rc = make_layer(L, kh, kw, sh, sw, Ho, Wo, Cout, H, W, Cin, "deconv2d_nhwc_bwd_data");
     if (rc) return rc;
-    return run_dir(L, false, B, dy, w, nullptr, dx, CGS_EPI_NONE, nullptr, nullptr, ws, ws_bytes, ws_prepacked, (hipStream_t)stream, "deconv2d_nhwc_bwd_data");
+    return run_dir(L, false, B, dy, w, nullptr, dx, epilogue, ep_a, nullptr, ep_aux, ws, ws_bytes, ws_prepacked, (hipStream_t)stream, "deconv2d_nhwc_bwd_data");
 }
 
 }  // extern "C"
@@ -188,7 +200,7 @@ int cgs_linear_fwd(const float* x, const float* w, const float* bias, float* y, 
     CgsLayer L;
     int rc = make_layer(L, 1, 1, 1, 1, 1, 1, in, 1, 1, out, "linear_fwd");
     if (rc) return rc;
-    return run_dir(L, false, B, x, w, bias, y, epilogue, nullptr, nullptr, ws, ws_bytes, ws_prepacked, (hipStream_t)stream, "linear_fwd");
+    return run_dir(L, false, B, x, w, bias, y, epilogue, nullptr, nullptr, nullptr, ws, ws_bytes, ws_prepacked, (hipStream_t)stream, "linear_fwd");
 }
 
 int cgs_linear_bwd_data(const float* dy, const float* w, float* dx, int B, int in, int out, void* ws, size_t ws_bytes,
@@ -204,7 +216,7 @@ int cgs_linear_bwd_data(const float* dy, const float* w, float* dx, int B, int i
     CgsLayer L;
     int rc = make_layer(L, 1, 1, 1, 1, 1, 1, in, 1, 1, out, "linear_bwd_data");
     if (rc) return rc;
-    return run_dir(L, true, B, dy, w, nullptr, dx, CGS_EPI_NONE, nullptr, nullptr, ws, ws_bytes, ws_prepacked, (hipStream_t)stream, "linear_bwd_data");
+    return run_dir(L, true, B, dy, w, nullptr, dx, CGS_EPI_NONE, nullptr, nullptr, nullptr, ws, ws_bytes, ws_prepacked, (hipStream_t)stream, "linear_bwd_data");
 }
 
 }  // extern "C"

@@ -7,6 +7,7 @@
 #include "cgs_hip.h"
 
 int cgs_set_error(int code, const char* fmt, ...);
+void cgs_note_kernel(const char* name);   // remembered per thread, read back by cgs_last_kernel()
 
 #define CGS_CHECK_LAUNCH(name)                                                        \
     do {                                                                              \
@@ -57,13 +58,17 @@ struct IgemmParams {
     const float* bias;
     const float* ep_a;
     const float* ep_b;
+    const float* ep_aux; // [same shape as out] for the *_BWD epilogues
     float* out;
     int B, Hin, Win, Cred;      // input tensor (reduction channels per tap)
     int Hout, Wout, N, Np;      // output tensor, N channels (Np = N rounded up to 64)
     int S, So, dstep, kstep;
     int epilogue;
+    int pix_major;       // GEMM rows ordered (pixel, image) instead of (image, pixel): enables zero-tap skipping
+    int lpt;             // pixel-major only: m-tiles visit the pixels in perm[] order (most valid taps first)
     int nclasses;
     IgemmClass cls[CGS_MAX_CLASSES];
+    unsigned char perm[CGS_MAX_CLASSES][64];   // per class: base pixels sorted by descending valid-tap count
 };
 
 // geometry builders (igemm.hip)
@@ -76,6 +81,7 @@ int cgs_pack_weights(const IgemmParams& p, const CgsLayer& L, bool dirT, const f
 int cgs_igemm_launch(const IgemmParams& p, hipStream_t s);
 size_t cgs_convt_quad_ws_floats_bound(int kh, int kw, int Cs);
 int cgs_convt_quad_launch(const CgsLayer& L, int B, const float* in, const float* w, const float* bias, float* out,
-                          int epilogue, float* ws, size_t ws_bytes, int prepacked, hipStream_t s);
+                          int epilogue, const float* ep_a, const float* ep_aux, float* ws, size_t ws_bytes, int prepacked,
+                          hipStream_t s);
 int cgs_convt_smalln_launch(const CgsLayer& L, int B, const float* in, const float* w, const float* bias,
                             float* out, int epilogue, hipStream_t s);

@@ -21,6 +21,8 @@ struct QuadParams {
     const float* in;     // [B,Hs,Ws,Cs]
     const float* wq;     // packed [K/4][16][4], K = ny*nx*Cs
     const float* bias;   // [N] or null
+    const float* ep_a;   // [N] for RELU_BWD_AFFINE
+    const float* ep_aux; // [B,2Hs,2Ws,N] for the *_BWD epilogues
     float* out;          // [B,2Hs,2Ws,N]
     int B, Hs, Ws, Cs, N;
     int dmin_y, ny, dmin_x, nx;
@@ -119,6 +121,7 @@ __global__ __launch_bounds__(256) void convt_quad_mfma_kernel(QuadParams p) {
     if (cls >= 4) return;
     const int py = cls >> 1, px = cls & 1;
     const float bias = p.bias ? p.bias[n] : 0.f;
+    const float ea = p.epilogue == CGS_EPI_RELU_BWD_AFFINE ? p.ep_a[n] : 1.f;
 #pragma unroll
     for (int t = 0; t < MT; ++t)
 #pragma unroll
@@ -129,9 +132,13 @@ __global__ __launch_bounds__(256) void convt_quad_mfma_kernel(QuadParams p) {
             const int rem = (int)(q - (long)b * HW);
             const int rr = rem / p.Ws, cc = rem - rr * p.Ws;
             float v = acc[t][r] + bias;
+            const size_t o = ((size_t)(b * 2 * p.Hs + 2 * rr + py) * (2 * p.Ws) + 2 * cc + px) * p.N + n;
             if (p.epilogue == CGS_EPI_TANH) v = tanhf(v);
             else if (p.epilogue == CGS_EPI_LRELU) v = fmaxf(v, 0.2f * v);
-            p.out[((size_t)(b * 2 * p.Hs + 2 * rr + py) * (2 * p.Ws) + 2 * cc + px) * p.N + n] = v;
+            else if (p.epilogue == CGS_EPI_TANH_BWD) { const float y = p.ep_aux[o]; v *= (1.f - y * y); }
+            else if (p.epilogue == CGS_EPI_LRELU_BWD) v = p.ep_aux[o] > 0.f ? v : 0.2f * v;
+            else if (p.epilogue == CGS_EPI_RELU_BWD_AFFINE) v = p.ep_aux[o] > 0.f ? v * ea : 0.f;
+            p.out[o] = v;
         }
 }
 
@@ -151,9 +158,10 @@ size_t cgs_convt_quad_ws_floats_bound(int kh, int kw, int Cs) {
 }
 
 int cgs_convt_quad_launch(const CgsLayer& L, int B, const float* in, const float* w, const float* bias, float* out,
-                          int epilogue, float* ws, size_t ws_bytes, int prepacked, hipStream_t s) {
+                          int epilogue, const float* ep_a, const float* ep_aux, float* ws, size_t ws_bytes, int prepacked,
+                          hipStream_t s) {
     QuadParams p;
-    p.in = in; p.wq = ws; p.bias = bias; p.out = out;
+    p.in = in; p.wq = ws; p.bias = bias; p.out = out; p.ep_a = ep_a; p.ep_aux = ep_aux;
     p.B = B; p.Hs = L.Hs; p.Ws = L.Ws; p.Cs = L.Cs; p.N = L.Cb; p.epilogue = epilogue;
     const int pt = cgs_same_pad_before(L.Hb, L.kh, 2), pl = cgs_same_pad_before(L.Wb, L.kw, 2);
     int hy, hx;
@@ -181,5 +189,6 @@ int cgs_convt_quad_launch(const CgsLayer& L, int B, const float* in, const float
     const long blocks = (total + 64 * MT - 1) / (64 * MT);
     hipLaunchKernelGGL(convt_quad_mfma_kernel<MT>, dim3((unsigned)blocks), dim3(256), need, s, p);
     CGS_CHECK_LAUNCH("convt_quad_mfma");
+    cgs_note_kernel("convt_quad_mfma_kernel<4>");
     return CGS_OK;
 }

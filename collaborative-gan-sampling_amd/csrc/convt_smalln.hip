@@ -115,5 +115,6 @@ int cgs_convt_smalln_launch(const CgsLayer& L, int B, const float* in, const flo
         default: return cgs_set_error(CGS_EINVAL, "convt_smalln: N=%d unsupported", L.Cb);
     }
     CGS_CHECK_LAUNCH("convt_smalln");
+    cgs_note_kernel("convt_smalln_kernel");
     return CGS_OK;
 }

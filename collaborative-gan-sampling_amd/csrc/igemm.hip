@@ -64,6 +64,9 @@ void cgs_geom_T(const CgsLayer& L, IgemmParams& p) {
             c.K = c.nty * c.ntx * L.Cs; c.w_off = off;
             off += cgs_round_up(c.K, BK) * p.Np;
         }
+    // heaviest class first: blocks are dispatched in blockIdx.y-major order, so the 9-tap class must not be the tail
+    for (int i = 1; i < p.nclasses; ++i)
+        for (int j = i; j > 0 && p.cls[j].K > p.cls[j - 1].K; --j) { IgemmClass t = p.cls[j]; p.cls[j] = p.cls[j - 1]; p.cls[j - 1] = t; }
 }
 
 size_t cgs_packed_floats(const IgemmParams& p) {
@@ -115,11 +118,14 @@ int cgs_pack_weights(const IgemmParams& p, const CgsLayer& L, bool dirT, const f
 // ------------------------------------------------------------------------------------------------
 // main kernel
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float epilogue_apply(float v, int mode, float a, float b) {
+__device__ __forceinline__ float epilogue_apply(float v, int mode, float a, float b, float aux) {
     switch (mode) {
         case CGS_EPI_LRELU: return fmaxf(v, 0.2f * v);
         case CGS_EPI_AFFINE_RELU: return fmaxf(fmaf(a, v, b), 0.f);
         case CGS_EPI_TANH: return tanhf(v);
+        case CGS_EPI_RELU_BWD_AFFINE: return aux > 0.f ? v * a : 0.f;
+        case CGS_EPI_LRELU_BWD: return aux > 0.f ? v : 0.2f * v;
+        case CGS_EPI_TANH_BWD: return v * (1.f - aux * aux);
         default: return v;
     }
 }
@@ -137,21 +143,38 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
     const int RC = c.R * c.C;
     const int M = p.B * RC;
     const int nblk_n = p.Np / BN;
-    const int mb = blockIdx.x / nblk_n, nb = blockIdx.x - mb * nblk_n;
+    int mb = blockIdx.x / nblk_n;
+    const int nb = blockIdx.x - mb * nblk_n;
+    if (mb * BM >= M) return;
+    if (p.lpt) {     // B % BM == 0: m-tile = (pixel rank, image group); visit pixels heaviest-first (LPT schedule)
+        const int gpp = p.B / BM;                       // image groups (tiles) per pixel
+        const int rank = mb / gpp, grp = mb - rank * gpp;
+        mb = (int)p.perm[blockIdx.y][rank] * gpp + grp;
+    }
     const int m0 = mb * BM, n0 = nb * BN;
-    if (m0 >= M) return;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int h = lane >> 5, j = lane & 31;
 
+    // GEMM row m -> (image b, base pixel r, cc).  Image-major: m = b*RC + pixel (rows of a tile are neighbouring
+    // pixels: their taps overlap, L1/L2 reuse).  Pixel-major: m = pixel*B + b (rows of a tile are the SAME pixel of
+    // 128 images: a tap that falls in the zero padding does so for the whole tile and is skipped, below).
+#define DECODE_ROW(m_, b_, r_, cc_)                                        \
+    do {                                                                   \
+        int rem_;                                                          \
+        if (p.pix_major) { rem_ = (m_) / p.B; b_ = (m_) - rem_ * p.B; }    \
+        else { b_ = (m_) / RC; rem_ = (m_) - b_ * RC; }                    \
+        r_ = rem_ / c.C; cc_ = rem_ - r_ * c.C;                            \
+    } while (0)
+
     if (tid < BM) {
         const int m = m0 + tid;
         int pix = -1;
         if (m < M) {
-            const int b = m / RC, rem = m - b * RC;
-            const int r = rem / c.C, cc = rem - r * c.C;
+            int b, r, cc;
+            DECODE_ROW(m, b, r, cc);
             pix = (b * p.Hout + r * p.So + c.py) * p.Wout + cc * p.So + c.px;
         }
         rowpix[tid] = pix;
@@ -164,8 +187,8 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
     for (int i = 0; i < AI; ++i) {
         const int m = m0 + ar + 32 * i;
         if (m < M) {
-            const int b = m / RC, rem = m - b * RC;
-            const int r = rem / c.C, cc = rem - r * c.C;
+            int b, r, cc;
+            DECODE_ROW(m, b, r, cc);
             a_base[i] = b * p.Hin * p.Win; a_iy[i] = r * p.S + c.dy0; a_ix[i] = cc * p.S + c.dx0;
         } else {
             a_base[i] = 0; a_iy[i] = -(1 << 20); a_ix[i] = 0;    // always out of range -> zeros
@@ -173,6 +196,33 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
     }
     const float* wsrc = p.wp + c.w_off;
     const int nk = (c.K + BK - 1) / BK;
+
+    // zero-tap skipping (pixel-major, VEC): if every row of this tile is the same base pixel, a tap outside the
+    // image contributes exact zeros for all rows -> its Cred/32 K-chunks are not loaded or multiplied at all.
+    bool skip_ok = false;
+    int u_iy = 0, u_ix = 0;
+    if (VEC && p.pix_major) {
+        const int mlast = (m0 + BM - 1 < M ? m0 + BM - 1 : M - 1);
+        const int pf = m0 / p.B, pl = mlast / p.B;
+        if (pf == pl) {
+            skip_ok = true;
+            const int r = pf / c.C, cc = pf - r * c.C;
+            u_iy = r * p.S + c.dy0; u_ix = cc * p.S + c.dx0;
+        }
+    }
+    const int chunks_per_tap = VEC ? p.Cred / BK : 1;
+    // first K-chunk >= kt whose tap is inside the image for this tile (nk if none)
+    auto next_chunk = [&](int kt) -> int {
+        if (!skip_ok) return kt;
+        while (kt < nk) {
+            const int t = kt / chunks_per_tap;
+            const int ta = t / c.ntx, tb = t - ta * c.ntx;
+            const int iy = u_iy + ta * p.dstep, ix = u_ix + tb * p.dstep;
+            if ((unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win) break;
+            kt = (t + 1) * chunks_per_tap;
+        }
+        return kt < nk ? kt : nk;
+    };
 
     f32x4 ra[AI], rb[BI];
     // buffer descriptor over the input tensor (wave-uniform: built from kernel arguments only)
@@ -195,22 +245,23 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
                 ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, off, 0, 0));   \
             }                                                                                                   \
         } else {                                                                                                \
-            _Pragma("unroll") for (int i = 0; i < AI; ++i) {                                                    \
-                float v[4];                                                                                     \
-                _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                 \
-                    const int k = (kt_) * BK + aq * 4 + e;                                                      \
-                    float x = 0.f;                                                                              \
-                    if (k < c.K) {                                                                              \
-                        const int t = k / p.Cred, ci = k - t * p.Cred;                                          \
-                        const int ta = t / c.ntx, tb = t - ta * c.ntx;                                          \
-                        const int iy = a_iy[i] + ta * p.dstep, ix = a_ix[i] + tb * p.dstep;                     \
-                        if ((unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win)                   \
-                            x = p.in[(size_t)(a_base[i] + iy * p.Win + ix) * p.Cred + ci];                      \
-                    }                                                                                           \
-                    v[e] = x;                                                                                   \
+            /* generic K (Cred not a multiple of 32, e.g. 3 image channels): decode each of this thread's */   \
+            /* 4 k's once per tile (independent of the row), then gather element-wise */                        \
+            float va[AI][4];                                                                                    \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                     \
+                const int k = (kt_) * BK + aq * 4 + e;                                                          \
+                const bool kin = k < c.K;                                                                       \
+                const int t = kin ? k / p.Cred : 0, ci = k - t * p.Cred;                                        \
+                const int ta = t / c.ntx, tb = t - ta * c.ntx;                                                  \
+                const int dy = ta * p.dstep, dx = tb * p.dstep;                                                 \
+                _Pragma("unroll") for (int i = 0; i < AI; ++i) {                                                \
+                    const int iy = a_iy[i] + dy, ix = a_ix[i] + dx;                                             \
+                    const bool ok = kin && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;    \
+                    const unsigned off = ok ? (unsigned)((a_base[i] + iy * p.Win + ix) * p.Cred + ci) * 4u : 0xFFFFFFF0u; \
+                    va[i][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, off, 0, 0)); \
                 }                                                                                               \
-                ra[i] = f32x4{v[0], v[1], v[2], v[3]};                                                          \
             }                                                                                                   \
+            _Pragma("unroll") for (int i = 0; i < AI; ++i) ra[i] = f32x4{va[i][0], va[i][1], va[i][2], va[i][3]}; \
         }                                                                                                       \
         _Pragma("unroll") for (int i = 0; i < BI; ++i) {                                                        \
             const int idx = tid + 256 * i;                                                                      \
@@ -234,15 +285,16 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
 
-    if (nk > 0) {
-        LOAD_TILE(0);
+    int kt = next_chunk(0);
+    if (kt < nk) {
+        LOAD_TILE(kt);
         STORE_TILE(0);
     }
     __syncthreads();
 
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) LOAD_TILE(kt + 1);          // global loads in flight under the MFMA block
+    for (int buf = 0; kt < nk; buf ^= 1) {
+        const int kn = next_chunk(kt + 1);
+        if (kn < nk) LOAD_TILE(kn);                  // global loads in flight under the MFMA block
         const float* a = As + buf * BM * LDA + (wm * (BM / 2) + j) * LDA;
         const float* b = Bs + buf * BK * BN + (wn * (BN / 2) + j) * 4;
 #pragma unroll
@@ -263,12 +315,14 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[tm].w, fb[tn].w, acc[tm][tn], 0, 0, 0);
                 }
         }
-        if (kt + 1 < nk) STORE_TILE(buf ^ 1);
+        if (kn < nk) STORE_TILE(buf ^ 1);
         __syncthreads();
+        kt = kn;
     }
 
 #undef LOAD_TILE
 #undef STORE_TILE
+#undef DECODE_ROW
     // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
@@ -277,13 +331,19 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
         const float bias = p.bias ? p.bias[n] : 0.f;
         float ea = 1.f, eb = 0.f;
         if (p.epilogue == CGS_EPI_AFFINE_RELU) { ea = p.ep_a[n]; eb = p.ep_b[n]; }
+        if (p.epilogue == CGS_EPI_RELU_BWD_AFFINE) ea = p.ep_a[n];
+        const bool use_aux = p.epilogue >= CGS_EPI_RELU_BWD_AFFINE;
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = wm * (BM / 2) + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 const int pix = rowpix[row];
-                if (pix >= 0) p.out[(size_t)pix * p.N + n] = epilogue_apply(acc[tm][tn][r] + bias, p.epilogue, ea, eb);
+                if (pix >= 0) {
+                    const size_t o = (size_t)pix * p.N + n;
+                    const float aux = use_aux ? p.ep_aux[o] : 0.f;
+                    p.out[o] = epilogue_apply(acc[tm][tn][r] + bias, p.epilogue, ea, eb, aux);
+                }
             }
     }
 }
@@ -308,14 +368,46 @@ static int launch_cfg(const IgemmParams& p, hipStream_t s) {
     if (gx > 0x7fffffffL) return cgs_set_error(CGS_EINVAL, "igemm: grid too large");
     hipLaunchKernelGGL((igemm_kernel<BM, BN, VEC>), dim3((unsigned)gx, p.nclasses), dim3(256), smem, s, p);
     CGS_CHECK_LAUNCH("igemm");
+    cgs_note_kernel(BN == 128 ? (VEC ? "igemm_kernel<128,128,true>" : "igemm_kernel<128,128,false>")
+                              : (VEC ? "igemm_kernel<128,64,true>" : "igemm_kernel<128,64,false>"));
     return CGS_OK;
 }
 
-int cgs_igemm_launch(const IgemmParams& p, hipStream_t s) {
+int cgs_igemm_launch(const IgemmParams& p_in, hipStream_t s) {
+    IgemmParams p = p_in;
+    // pixel-major row order pays when the base-pixel grid is small (many padded taps per pixel, and the whole
+    // input stays in the 256 MiB Infinity Cache for the cross-tile re-reads) and the batch fills whole tiles
+    int maxRC = 0;
+    for (int i = 0; i < p.nclasses; ++i) maxRC = p.cls[i].R * p.cls[i].C > maxRC ? p.cls[i].R * p.cls[i].C : maxRC;
+    const size_t in_bytes = (size_t)p.B * p.Hin * p.Win * p.Cred * 4;
+    p.pix_major = (p.Cred % BK) == 0 && p.B >= 128 && maxRC <= 64 && maxRC > 1 && in_bytes <= (size_t)192 << 20;
+    p.lpt = p.pix_major && (p.B % 128) == 0;
+    if (p.lpt)
+        for (int ci = 0; ci < p.nclasses; ++ci) {
+            const IgemmClass& c = p.cls[ci];
+            int cnt[64];
+            for (int pix = 0; pix < c.R * c.C; ++pix) {
+                const int r = pix / c.C, cc = pix - r * c.C;
+                int ny = 0, nx = 0;
+                for (int ta = 0; ta < c.nty; ++ta) { const int iy = r * p.S + c.dy0 + ta * p.dstep; ny += (iy >= 0 && iy < p.Hin); }
+                for (int tb = 0; tb < c.ntx; ++tb) { const int ix = cc * p.S + c.dx0 + tb * p.dstep; nx += (ix >= 0 && ix < p.Win); }
+                cnt[pix] = ny * nx;
+                p.perm[ci][pix] = (unsigned char)pix;
+            }
+            for (int i = 1; i < c.R * c.C; ++i)       // insertion sort, descending tap count, stable
+                for (int j = i; j > 0 && cnt[p.perm[ci][j]] > cnt[p.perm[ci][j - 1]]; --j) {
+                    unsigned char t = p.perm[ci][j]; p.perm[ci][j] = p.perm[ci][j - 1]; p.perm[ci][j - 1] = t;
+                }
+        }
     if ((long)p.B * p.Hout * p.Wout * p.N * 4 > 0x7fffffffL || (long)p.B * p.Hin * p.Win * p.Cred * 4 > 0x7fffffffL)
         return cgs_set_error(CGS_EINVAL, "igemm: a tensor of one launch exceeds 2 GiB (the caller splits the batch)");
     const bool vec = (p.Cred % BK) == 0;
-    const bool wide = (p.Np % 128) == 0;
+    bool wide = (p.Np % 128) == 0;
+    if (wide && p.lpt) {      // uneven tiles need >= 2 rounds of blocks over the 512 block slots to balance: halve BN if short
+        long blocks = 0;
+        for (int i = 0; i < p.nclasses; ++i) blocks += ((long)p.B * p.cls[i].R * p.cls[i].C / 128) * (p.Np / 128);
+        if (blocks < 1024) wide = false;
+    }
     if (vec) return wide ? launch_cfg<128, 128, true>(p, s) : launch_cfg<128, 64, true>(p, s);
     return wide ? launch_cfg<128, 128, false>(p, s) : launch_cfg<128, 64, false>(p, s);
 }

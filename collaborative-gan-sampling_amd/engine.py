@@ -24,6 +24,8 @@ from .nets import ARCHS, _same_out
 # ----------------------------------------------------------------------------- stages
 class _Stage:
     out = None
+    bwd_epi = (L.EPI_NONE, None, None)   # (mode, a, aux): activation gradient of the stage BELOW, folded into this stage's bwd-data
+    pre_folded = False                   # True: the stage ABOVE already applied this stage's activation gradient
 
     def fwd(self, x):
         raise NotImplementedError
@@ -57,9 +59,10 @@ class _Conv(_Stage):
         return K.conv2d_fwd(x, self.w, self.b, self.s, self.s, self.epi, out=self.out)
 
     def bwd(self, dy):
-        if self.epi == L.EPI_LRELU:
+        if self.epi == L.EPI_LRELU and not self.pre_folded:
             dy = K.lrelu_bwd(dy, self.out, out=dy)
-        return K.conv2d_bwd_data(dy, self.w, self.in_hw, self.s, self.s, out=self.dx)
+        e, a, aux = self.bwd_epi
+        return K.conv2d_bwd_data(dy, self.w, self.in_hw, self.s, self.s, out=self.dx, epilogue=e, ep_a=a, ep_aux=aux)
 
 
 class _Deconv(_Stage):
@@ -75,11 +78,13 @@ class _Deconv(_Stage):
         return K.deconv2d_fwd(x, self.w, self.b, self.out_hw, self.s, self.s, self.epi, self.a, self.c, out=self.out)
 
     def bwd(self, dy):
-        if self.epi == L.EPI_AFFINE_RELU:
-            dy = K.affine_relu_bwd(dy, self.out, self.a, out=dy)
-        elif self.epi == L.EPI_TANH:
-            dy = K.tanh_bwd(dy, self.out, out=dy)
-        return K.deconv2d_bwd_data(dy, self.w, self.in_hw, self.s, self.s, out=self.dx)
+        if not self.pre_folded:
+            if self.epi == L.EPI_AFFINE_RELU:
+                dy = K.affine_relu_bwd(dy, self.out, self.a, out=dy)
+            elif self.epi == L.EPI_TANH:
+                dy = K.tanh_bwd(dy, self.out, out=dy)
+        e, a, aux = self.bwd_epi
+        return K.deconv2d_bwd_data(dy, self.w, self.in_hw, self.s, self.s, out=self.dx, epilogue=e, ep_a=a, ep_aux=aux)
 
 
 class _Linear(_Stage):
@@ -208,6 +213,23 @@ def compile_layers(layers, in_shape, P, scope, B, k, stride, bn_training, dev):
     return stages, shape
 
 
+def link_backward_fusion(stages):
+    """For each conv-family stage whose predecessor ends in relu(a*x+b) / lrelu / tanh, fold that activation's
+    gradient into this stage's backward-data epilogue (one elementwise pass over the gradient map less)."""
+    for below, above in zip(stages[:-1], stages[1:]):
+        if not isinstance(above, (_Conv, _Deconv)) or below.pre_folded:
+            continue
+        if isinstance(below, _Deconv) and below.epi == L.EPI_AFFINE_RELU:
+            above.bwd_epi = (L.EPI_RELU_BWD_AFFINE, below.a, below.out)
+        elif isinstance(below, _Deconv) and below.epi == L.EPI_TANH:
+            above.bwd_epi = (L.EPI_TANH_BWD, None, below.out)
+        elif isinstance(below, _Conv) and below.epi == L.EPI_LRELU:
+            above.bwd_epi = (L.EPI_LRELU_BWD, None, below.out)
+        else:
+            continue
+        below.pre_folded = True
+
+
 class Tape:
     """A compiled layer list: forward keeps what backward-data needs; no weight gradients."""
 
@@ -241,6 +263,7 @@ class RefineEngine:
             self.g_head = Tape(A["g_head"], (A["z_dim"],), params, "generator", B, A["k"], A["stride"], False, self.dev)
             self.g_tail = Tape(A["g_tail"], A["feature"], params, "generator", B, A["k"], A["stride"], False, self.dev)
             self.d = Tape(A["d"], A["img"], params, "discriminator", B, A["k"], A["stride"], True, self.dev)
+            link_backward_fusion(self.g_tail.stages + self.d.stages)     # across the G-tail / D seam too
             fs = (B,) + tuple(A["feature"])
             f32 = dict(dtype=torch.float32, device=self.dev)
             self.theta, self.mom, self.best_theta = torch.empty(fs, **f32), torch.empty(fs, **f32), torch.empty(fs, **f32)

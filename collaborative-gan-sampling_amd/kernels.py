@@ -36,20 +36,14 @@ def _stream():
 PROFILE = None
 
 
-def igemm_kernel_name(dirT, kh, kw, sh, sw, Cb, Cs, Hb, Wb, Hs, Ws, epilogue=0):
-    """Which kernel the C-ABI dispatcher (csrc/api.hip run_dir) picks for a conv-family call."""
-    if dirT and Cb <= 4 and sh == 2 and sw == 2 and Hb == 2 * Hs and Wb == 2 * Ws and Cs % 4 == 0 and epilogue != L.EPI_AFFINE_RELU:
-        return "convt_quad_mfma_kernel" if Cs % 16 == 0 else "convt_smalln_kernel"
-    cred, n = (Cs, Cb) if dirT else (Cb, Cs)
-    npad = (n + 63) // 64 * 64
-    return "igemm_kernel<128,%d,%s>" % (128 if npad % 128 == 0 else 64, "true" if cred % 32 == 0 else "false")
+PROFILE_BY_LAYER = False      # key the records by kernel + layer shape instead of kernel only
 
 
 class _Prof:
     __slots__ = ("name", "flops", "e0")
 
-    def __init__(self, name, flops):
-        self.name, self.flops, self.e0 = name, flops, None
+    def __init__(self, flops, tag=""):
+        self.name, self.flops, self.e0 = tag, flops, None
         if PROFILE is not None:
             self.e0 = torch.cuda.Event(enable_timing=True)
             self.e0.record()
@@ -58,7 +52,8 @@ class _Prof:
         if self.e0 is not None:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record()
-            rec = PROFILE.setdefault(self.name, [0.0, []])
+            kname = L.load().cgs_last_kernel().decode()        # the instantiation the dispatcher actually launched
+            rec = PROFILE.setdefault(kname + " " + self.name if PROFILE_BY_LAYER else kname, [0.0, []])
             rec[0] += self.flops
             rec[1].append((self.e0, e1))
 
@@ -114,7 +109,7 @@ def conv2d_fwd(x, w, bias, sh=2, sw=2, epilogue=L.EPI_NONE, ep_a=None, ep_b=None
     y = out if out is not None else torch.empty((B, same_out(H, sh), same_out(W, sw), Cout), dtype=torch.float32, device=x.device)
     ws, pre = WS.get(w, L.CONV_FWD, kh, kw, sh, sw, Cin, Cout)
     Ho, Wo = y.shape[1], y.shape[2]
-    pr = _Prof(igemm_kernel_name(False, kh, kw, sh, sw, Cin, Cout, H, W, Ho, Wo), 2.0 * B * Ho * Wo * Cout * kh * kw * Cin) if PROFILE is not None else None
+    pr = _Prof(2.0 * B * Ho * Wo * Cout * kh * kw * Cin, f"conv_fwd {H}x{W} {Cin}->{Cout}") if PROFILE is not None else None
     L.call("cgs_conv2d_nhwc_fwd", _ptr(x), _ptr(w), _ptr(bias), _ptr(y), B, H, W, Cin, Cout, kh, kw, sh, sw,
            epilogue, _ptr(ep_a), _ptr(ep_b), _ptr(ws), ws.numel() * 4, pre, _stream())
     if pr is not None:
@@ -122,8 +117,9 @@ def conv2d_fwd(x, w, bias, sh=2, sw=2, epilogue=L.EPI_NONE, ep_a=None, ep_b=None
     return y
 
 
-def conv2d_bwd_data(dy, w, in_hw, sh=2, sw=2, out=None):
-    """Input gradient of conv2d_fwd (Conv2DBackpropInput; sampling/collaborator.py:31)."""
+def conv2d_bwd_data(dy, w, in_hw, sh=2, sw=2, out=None, epilogue=L.EPI_NONE, ep_a=None, ep_aux=None):
+    """Input gradient of conv2d_fwd (Conv2DBackpropInput; sampling/collaborator.py:31).
+    ``epilogue`` = one of the *_BWD modes folds the activation gradient of the layer below in."""
     _chk(dy, "dy"); _chk(w, "w")
     kh, kw, Cin, Cout = w.shape
     B = dy.shape[0]
@@ -131,9 +127,9 @@ def conv2d_bwd_data(dy, w, in_hw, sh=2, sw=2, out=None):
     dx = out if out is not None else torch.empty((B, H, W, Cin), dtype=torch.float32, device=dy.device)
     ws, pre = WS.get(w, L.CONV_BWD_DATA, kh, kw, sh, sw, Cin, Cout)
     Ho, Wo = dy.shape[1], dy.shape[2]
-    pr = _Prof(igemm_kernel_name(True, kh, kw, sh, sw, Cin, Cout, H, W, Ho, Wo), 2.0 * B * Ho * Wo * Cout * kh * kw * Cin) if PROFILE is not None else None
+    pr = _Prof(2.0 * B * Ho * Wo * Cout * kh * kw * Cin, f"conv_bwd {H}x{W} {Cin}<-{Cout}") if PROFILE is not None else None
     L.call("cgs_conv2d_nhwc_bwd_data", _ptr(dy), _ptr(w), _ptr(dx), B, H, W, Cin, Cout, kh, kw, sh, sw,
-           _ptr(ws), ws.numel() * 4, pre, _stream())
+           epilogue, _ptr(ep_a), _ptr(ep_aux), _ptr(ws), ws.numel() * 4, pre, _stream())
     if pr is not None:
         pr.done()
     return dx
@@ -149,7 +145,7 @@ def deconv2d_fwd(x, w, bias, out_hw, sh=2, sw=2, epilogue=L.EPI_NONE, ep_a=None,
     Ho, Wo = out_hw
     y = out if out is not None else torch.empty((B, Ho, Wo, Cout), dtype=torch.float32, device=x.device)
     ws, pre = WS.get(w, L.DECONV_FWD, kh, kw, sh, sw, Cin, Cout)
-    pr = _Prof(igemm_kernel_name(True, kh, kw, sh, sw, Cout, Cin, Ho, Wo, H, W, epilogue), 2.0 * B * H * W * Cin * kh * kw * Cout) if PROFILE is not None else None
+    pr = _Prof(2.0 * B * H * W * Cin * kh * kw * Cout, f"deconv_fwd {H}x{W} {Cin}->{Cout}") if PROFILE is not None else None
     L.call("cgs_deconv2d_nhwc_fwd", _ptr(x), _ptr(w), _ptr(bias), _ptr(y), B, H, W, Cin, Ho, Wo, Cout, kh, kw, sh, sw,
            epilogue, _ptr(ep_a), _ptr(ep_b), _ptr(ws), ws.numel() * 4, pre, _stream())
     if pr is not None:
@@ -157,7 +153,7 @@ def deconv2d_fwd(x, w, bias, out_hw, sh=2, sw=2, epilogue=L.EPI_NONE, ep_a=None,
     return y
 
 
-def deconv2d_bwd_data(dy, w, in_hw, sh=2, sw=2, out=None):
+def deconv2d_bwd_data(dy, w, in_hw, sh=2, sw=2, out=None, epilogue=L.EPI_NONE, ep_a=None, ep_aux=None):
     """Input gradient of deconv2d_fwd: a strided 'SAME' conv of dy with the deconv weights."""
     _chk(dy, "dy"); _chk(w, "w")
     kh, kw, Cout, Cin = w.shape
@@ -165,9 +161,9 @@ def deconv2d_bwd_data(dy, w, in_hw, sh=2, sw=2, out=None):
     H, W = in_hw
     dx = out if out is not None else torch.empty((B, H, W, Cin), dtype=torch.float32, device=dy.device)
     ws, pre = WS.get(w, L.DECONV_BWD_DATA, kh, kw, sh, sw, Cin, Cout)
-    pr = _Prof(igemm_kernel_name(False, kh, kw, sh, sw, Cout, Cin, Ho, Wo, H, W), 2.0 * B * H * W * Cin * kh * kw * Cout) if PROFILE is not None else None
+    pr = _Prof(2.0 * B * H * W * Cin * kh * kw * Cout, f"deconv_bwd {H}x{W} {Cin}<-{Cout}") if PROFILE is not None else None
     L.call("cgs_deconv2d_nhwc_bwd_data", _ptr(dy), _ptr(w), _ptr(dx), B, H, W, Cin, Ho, Wo, Cout, kh, kw, sh, sw,
-           _ptr(ws), ws.numel() * 4, pre, _stream())
+           epilogue, _ptr(ep_a), _ptr(ep_aux), _ptr(ws), ws.numel() * 4, pre, _stream())
     if pr is not None:
         pr.done()
     return dx

@@ -11,6 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libcgs_hip.so")
 
 OK, EINVAL, EWORKSPACE, ELAUNCH = 0, -1, -2, -3
 EPI_NONE, EPI_LRELU, EPI_AFFINE_RELU, EPI_TANH = 0, 1, 2, 3
+EPI_RELU_BWD_AFFINE, EPI_LRELU_BWD, EPI_TANH_BWD = 4, 5, 6
 CONV_FWD, CONV_BWD_DATA, DECONV_FWD, DECONV_BWD_DATA = 0, 1, 2, 3
 
 _p, _i, _f, _z = C.c_void_p, C.c_int, C.c_float, C.c_size_t
@@ -19,11 +20,12 @@ _p, _i, _f, _z = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 SIGNATURES = {
     "cgs_version": (_i, []),
     "cgs_last_error": (C.c_char_p, []),
+    "cgs_last_kernel": (C.c_char_p, []),
     "cgs_conv_ws_bytes": (_z, [_i] * 7),
     "cgs_conv2d_nhwc_fwd": (_i, [_p] * 4 + [_i] * 9 + [_i, _p, _p, _p, _z, _i, _p]),
-    "cgs_conv2d_nhwc_bwd_data": (_i, [_p] * 3 + [_i] * 9 + [_p, _z, _i, _p]),
+    "cgs_conv2d_nhwc_bwd_data": (_i, [_p] * 3 + [_i] * 9 + [_i, _p, _p, _p, _z, _i, _p]),
     "cgs_deconv2d_nhwc_fwd": (_i, [_p] * 4 + [_i] * 11 + [_i, _p, _p, _p, _z, _i, _p]),
-    "cgs_deconv2d_nhwc_bwd_data": (_i, [_p] * 3 + [_i] * 11 + [_p, _z, _i, _p]),
+    "cgs_deconv2d_nhwc_bwd_data": (_i, [_p] * 3 + [_i] * 11 + [_i, _p, _p, _p, _z, _i, _p]),
     "cgs_linear_fwd": (_i, [_p] * 4 + [_i] * 4 + [_p, _z, _i, _p]),
     "cgs_linear_bwd_data": (_i, [_p] * 3 + [_i] * 3 + [_p, _z, _i, _p]),
     "cgs_bn_ws_bytes": (_z, [_i, _i]),

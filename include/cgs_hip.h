@@ -42,6 +42,11 @@ extern "C" {
 #define CGS_EPI_LRELU 1        /* max(v, leak*v), leak = 0.2        nsgan/ops.py:69-70            */
 #define CGS_EPI_AFFINE_RELU 2  /* relu(a[c]*v + b[c]) = inference-mode bn + relu, nsgan/GAN.py:96-98 */
 #define CGS_EPI_TANH 3         /* tanh(v)                            nsgan/GAN.py:100              */
+/* backward-data epilogues: the produced gradient is w.r.t. the OUTPUT of the layer below; these fold that
+ * layer's activation gradient in (aux = the layer-below's saved output, same shape as the result; no bias) */
+#define CGS_EPI_RELU_BWD_AFFINE 4  /* aux > 0 ? v*a[c] : 0     through relu(a*x+b)   nsgan/GAN.py:96-98 */
+#define CGS_EPI_LRELU_BWD 5        /* v * (aux > 0 ? 1 : 0.2)  through lrelu         nsgan/ops.py:69-70 */
+#define CGS_EPI_TANH_BWD 6         /* v * (1 - aux*aux)        through tanh          nsgan/GAN.py:100   */
 
 /* which transposition of the weights a conv-family call contracts over */
 #define CGS_CONV_FWD 0          /* tf.nn.conv2d                        nsgan/ops.py:41 */
@@ -51,6 +56,8 @@ extern "C" {
 
 int cgs_version(void);
 const char* cgs_last_error(void);
+/* Name of the compute kernel the calling thread's most recent conv-family call launched (for profiling). */
+const char* cgs_last_kernel(void);
 
 /* Bytes of workspace a conv-family call needs for its packed copy of the weights
  * (op = one of CGS_CONV_* above; Cin/Cout are those of the LAYER, i.e. of the
@@ -67,9 +74,11 @@ int cgs_conv2d_nhwc_fwd(const float* x, const float* w, const float* bias, float
                         void* ws, size_t ws_bytes, int ws_prepacked, void* stream);
 
 /* conv2d backward-data: dx[B,H,W,Cin] = d/dx of the conv above applied to dy[B,Ho,Wo,Cout].
- * Replaces the Conv2DBackpropInput node tf.gradients emits (sampling/collaborator.py:31). */
+ * Replaces the Conv2DBackpropInput node tf.gradients emits (sampling/collaborator.py:31).
+ * epilogue: CGS_EPI_NONE or one of the *_BWD modes (ep_aux [B,H,W,Cin], ep_a [Cin]). */
 int cgs_conv2d_nhwc_bwd_data(const float* dy, const float* w, float* dx,
                              int B, int H, int W, int Cin, int Cout, int kh, int kw, int sh, int sw,
+                             int epilogue, const float* ep_a, const float* ep_aux,
                              void* ws, size_t ws_bytes, int ws_prepacked, void* stream);
 
 /* deconv2d: y[B,Ho,Wo,Cout] = conv2d_transpose(x[B,H,W,Cin], w[kh,kw,Cout,Cin], output_shape, stride) + bias,
@@ -83,6 +92,7 @@ int cgs_deconv2d_nhwc_fwd(const float* x, const float* w, const float* bias, flo
 /* deconv2d backward-data: dx[B,H,W,Cin] from dy[B,Ho,Wo,Cout] (a strided 'SAME' conv with the deconv weights). */
 int cgs_deconv2d_nhwc_bwd_data(const float* dy, const float* w, float* dx,
                                int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int sh, int sw,
+                               int epilogue, const float* ep_a, const float* ep_aux,
                                void* ws, size_t ws_bytes, int ws_prepacked, void* stream);
 
 /* linear: y[B,out] = x[B,in] @ w[in,out] + bias, then epilogue (NONE or LRELU).

@@ -36,6 +36,9 @@ CONV_CASES = [  # B,H,W,Cin,Cout,k,s
     (2, 7, 9, 32, 40, 5, 2),         # odd sizes, N not a multiple of 64
     (1, 6, 5, 32, 64, 3, 1),         # stride 1
     (70, 4, 4, 256, 512, 5, 2),      # many images, M not a multiple of 128
+    (130, 8, 8, 64, 128, 5, 2),      # B >= 128, 4x4 grid: pixel-major rows + zero-tap skipping, tiles straddling 2 pixels
+    (256, 16, 16, 32, 64, 5, 2),     # pixel-major, 8x8 grid, whole tiles per pixel
+    (128, 6, 6, 32, 64, 4, 2),       # pixel-major with 4x4 kernels
 ]
 
 
@@ -74,6 +77,9 @@ DECONV_CASES = [  # B,H,W,Cin,Ho,Wo,Cout,k,s
     (2, 4, 5, 32, 7, 9, 3, 5, 2),         # odd output, N=3 -> MFMA fallback
     (2, 6, 5, 32, 6, 5, 64, 3, 1),        # stride 1
     (37, 4, 4, 512, 8, 8, 256, 5, 2),
+    (128, 4, 4, 64, 8, 8, 128, 5, 2),     # pixel-major (4x4 class grids), both directions
+    (160, 8, 8, 32, 16, 16, 64, 5, 2),    # pixel-major, tiles straddling pixels
+    (128, 7, 7, 32, 14, 14, 64, 4, 2),    # pixel-major 7x7 grid, 4x4 kernels
 ]
 
 
@@ -106,6 +112,45 @@ def test_deconv2d_bwd_data(B, H, W, Cin, Ho, Wo, Cout, k, s):
     (y * dy).sum().backward()
     got = K.deconv2d_bwd_data(dy.to(dev()), w.to(dev()), (H, W), s, s)
     close(got, x.grad, 2e-5)
+
+
+@pytest.mark.parametrize("mode", ["relu_affine", "lrelu", "tanh"])
+@pytest.mark.parametrize("case", [(3, 16, 16, 64, 128, 5, 2), (3, 32, 32, 3, 64, 5, 2), (5, 28, 28, 1, 64, 4, 2), (2, 7, 9, 32, 40, 5, 2)])
+def test_bwd_data_epilogues(case, mode):
+    """The folded activation-gradient epilogues of both backward-data directions (and of the quad small-N kernel)."""
+    from cgs_amd import kernels as K, lib
+    B, H, W, Cin, Cout, k, s = case
+    d = dev()
+    w = rnd((k, k, Cin, Cout), 2, 0.05)
+    Ho, Wo = -(-H // s), -(-W // s)
+    dy = rnd((B, Ho, Wo, Cout), 4)
+    aux = rnd((B, H, W, Cin), 5)
+    a = rnd((Cin,), 6).abs() + 0.5
+    x = rnd((B, H, W, Cin), 1).requires_grad_(True)
+    (R.conv2d(x, w, torch.zeros(Cout), s, s) * dy).sum().backward()
+    base = x.grad
+    if mode == "relu_affine":
+        want, args = torch.where(aux > 0, base * a, torch.zeros_like(base)), (lib.EPI_RELU_BWD_AFFINE, a.to(d), aux.to(d))
+    elif mode == "lrelu":
+        want, args = base * torch.where(aux > 0, 1.0, 0.2), (lib.EPI_LRELU_BWD, None, aux.to(d))
+    else:
+        want, args = base * (1 - aux * aux), (lib.EPI_TANH_BWD, None, aux.to(d))
+    got = K.conv2d_bwd_data(dy.to(d), w.to(d), (H, W), s, s, epilogue=args[0], ep_a=args[1], ep_aux=args[2])
+    close(got, want, 2e-5)
+    # the F direction: deconv bwd-data of a deconv whose weights are w viewed as [k,k,Cout_d=Cin,Cin_d=Cout]
+    xs = rnd((B, Ho, Wo, Cout), 7).requires_grad_(True)
+    yb = R.deconv2d(xs, w, torch.zeros(Cin), (B, H, W, Cin), s, s)
+    dyb = rnd(tuple(yb.shape), 8)
+    (yb * dyb).sum().backward()
+    auxs, a_s = rnd((B, Ho, Wo, Cout), 9), rnd((Cout,), 10).abs() + 0.5
+    if mode == "relu_affine":
+        want, args = torch.where(auxs > 0, xs.grad * a_s, torch.zeros_like(xs.grad)), (lib.EPI_RELU_BWD_AFFINE, a_s.to(d), auxs.to(d))
+    elif mode == "lrelu":
+        want, args = xs.grad * torch.where(auxs > 0, 1.0, 0.2), (lib.EPI_LRELU_BWD, None, auxs.to(d))
+    else:
+        want, args = xs.grad * (1 - auxs * auxs), (lib.EPI_TANH_BWD, None, auxs.to(d))
+    got = K.deconv2d_bwd_data(dyb.to(d), w.to(d), (Ho, Wo), s, s, epilogue=args[0], ep_a=args[1], ep_aux=args[2])
+    close(got, want, 2e-5)
 
 
 @pytest.mark.parametrize("B,K_,N", [(64, 6272, 1024), (64, 62, 1024), (33, 1024, 6272), (1024, 8192, 1), (7, 100, 8192), (5, 1023, 1)])

@@ -145,14 +145,6 @@ def test_layer_lists_agree_with_oracle_and_flop_model():
     assert abs(nets.refine_flops_per_sample("dcgan64", 20) / 1e9 - 22.522) < 0.01
 
 
-def test_kernel_name_mirror_of_dispatcher():
-    from cgs_amd import kernels as K
-    assert K.igemm_kernel_name(False, 5, 5, 2, 2, 64, 128, 32, 32, 16, 16) == "igemm_kernel<128,128,true>"
-    assert K.igemm_kernel_name(False, 5, 5, 2, 2, 3, 64, 64, 64, 32, 32) == "igemm_kernel<128,64,false>"
-    assert K.igemm_kernel_name(True, 5, 5, 2, 2, 3, 64, 64, 64, 32, 32) == "convt_quad_mfma_kernel"
-    assert K.igemm_kernel_name(True, 5, 5, 2, 2, 64, 128, 32, 32, 16, 16) == "igemm_kernel<128,64,true>"
-
-
 def _gloo_worker(rank, world, port, out):
     import torch.distributed as dist
     from cgs_amd import dist as D
