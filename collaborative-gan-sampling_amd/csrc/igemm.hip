@@ -130,10 +130,14 @@ __device__ __forceinline__ float epilogue_apply(float v, int mode, float a, floa
     }
 }
 
-template <int BM, int BN, bool VEC>
-__global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
-    constexpr int TM = BM / 64, TN = BN / 64;     // 32x32 MFMA tiles per wave
-    constexpr int AI = BM / 32, BI = BN / 32;     // float4 staged per thread (A rows / B columns)
+// NW waves per block, arranged 2 (M) x NW/2 (N); wave tile (BM/2) x (BN/(NW/2)).
+template <int BM, int BN, int NW, bool VEC>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 2) void igemm_kernel(IgemmParams p) {
+    constexpr int NT = 64 * NW;                   // threads per block
+    constexpr int WN = NW / 2;                    // waves along N
+    constexpr int TM = BM / 64, TN = BN / (32 * WN);   // 32x32 MFMA tiles per wave
+    constexpr int AI = BM * 8 / NT, BI = BN * 8 / NT;  // float4 staged per thread (A rows / B columns)
+    constexpr int AR = NT / 8;                    // A rows covered per staging pass
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                              // [2][BM][LDA]
     float* Bs = smem + 2 * BM * LDA;               // [2][BK/4][BN][4]
@@ -155,7 +159,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave - wm * WN;
     const int h = lane >> 5, j = lane & 31;
 
     // GEMM row m -> (image b, base pixel r, cc).  Image-major: m = b*RC + pixel (rows of a tile are neighbouring
@@ -185,7 +189,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
     int a_base[AI], a_iy[AI], a_ix[AI];
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
-        const int m = m0 + ar + 32 * i;
+        const int m = m0 + ar + AR * i;
         if (m < M) {
             int b, r, cc;
             DECODE_ROW(m, b, r, cc);
@@ -264,7 +268,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
             _Pragma("unroll") for (int i = 0; i < AI; ++i) ra[i] = f32x4{va[i][0], va[i][1], va[i][2], va[i][3]}; \
         }                                                                                                       \
         _Pragma("unroll") for (int i = 0; i < BI; ++i) {                                                        \
-            const int idx = tid + 256 * i;                                                                      \
+            const int idx = tid + NT * i;                                                                       \
             const int kq = idx / BN, n = idx - kq * BN;                                                         \
             rb[i] = *(const f32x4*)(wsrc + ((size_t)((kt_) * (BK / 4) + kq) * p.Np + n0 + n) * 4);            \
         }                                                                                                       \
@@ -273,8 +277,8 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
     do {                                                                                                        \
         float* a_ = As + (buf_) * BM * LDA;                                                                     \
         float* b_ = Bs + (buf_) * BK * BN;                                                                      \
-        _Pragma("unroll") for (int i = 0; i < AI; ++i) *(f32x4*)(a_ + (ar + 32 * i) * LDA + aq * 4) = ra[i];    \
-        _Pragma("unroll") for (int i = 0; i < BI; ++i) *(f32x4*)(b_ + (tid + 256 * i) * 4) = rb[i];             \
+        _Pragma("unroll") for (int i = 0; i < AI; ++i) *(f32x4*)(a_ + (ar + AR * i) * LDA + aq * 4) = ra[i];    \
+        _Pragma("unroll") for (int i = 0; i < BI; ++i) *(f32x4*)(b_ + (tid + NT * i) * 4) = rb[i];              \
     } while (0)
 
     f32x16 acc[TM][TN];
@@ -296,7 +300,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
         const int kn = next_chunk(kt + 1);
         if (kn < nk) LOAD_TILE(kn);                  // global loads in flight under the MFMA block
         const float* a = As + buf * BM * LDA + (wm * (BM / 2) + j) * LDA;
-        const float* b = Bs + buf * BK * BN + (wn * (BN / 2) + j) * 4;
+        const float* b = Bs + buf * BK * BN + (wn * (BN / WN) + j) * 4;
 #pragma unroll
         for (int jj = 0; jj < BK / 8; ++jj) {
             const int kq = 2 * jj + h;
@@ -326,7 +330,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
     // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
-        const int n = n0 + wn * (BN / 2) + tn * 32 + j;
+        const int n = n0 + wn * (BN / WN) + tn * 32 + j;
         if (n >= p.N) continue;
         const float bias = p.bias ? p.bias[n] : 0.f;
         float ea = 1.f, eb = 0.f;
@@ -348,12 +352,12 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
     }
 }
 
-template <int BM, int BN, bool VEC>
+template <int BM, int BN, int NW, bool VEC>
 static int launch_cfg(const IgemmParams& p, hipStream_t s) {
     constexpr size_t smem = (size_t)(2 * BM * LDA + 2 * BK * BN) * sizeof(float) + BM * sizeof(int);
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)igemm_kernel<BM, BN, VEC>,
+        hipError_t e = hipFuncSetAttribute((const void*)igemm_kernel<BM, BN, NW, VEC>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return cgs_set_error(CGS_ELAUNCH, "igemm smem attr: %s", hipGetErrorString(e));
         attr_done = true;
@@ -366,10 +370,11 @@ static int launch_cfg(const IgemmParams& p, hipStream_t s) {
     if (maxM == 0) return CGS_OK;
     const long gx = (maxM + BM - 1) / BM * (p.Np / BN);
     if (gx > 0x7fffffffL) return cgs_set_error(CGS_EINVAL, "igemm: grid too large");
-    hipLaunchKernelGGL((igemm_kernel<BM, BN, VEC>), dim3((unsigned)gx, p.nclasses), dim3(256), smem, s, p);
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, NW, VEC>), dim3((unsigned)gx, p.nclasses), dim3(64 * NW), smem, s, p);
     CGS_CHECK_LAUNCH("igemm");
-    cgs_note_kernel(BN == 128 ? (VEC ? "igemm_kernel<128,128,true>" : "igemm_kernel<128,128,false>")
-                              : (VEC ? "igemm_kernel<128,64,true>" : "igemm_kernel<128,64,false>"));
+    cgs_note_kernel(BN == 128 ? (VEC ? "igemm_kernel<128,128,4,true>" : "igemm_kernel<128,128,4,false>")
+                    : NW == 2 ? (VEC ? "igemm_kernel<128,64,2,true>" : "igemm_kernel<128,64,2,false>")
+                              : (VEC ? "igemm_kernel<128,64,4,true>" : "igemm_kernel<128,64,4,false>"));
     return CGS_OK;
 }
 
@@ -408,6 +413,6 @@ int cgs_igemm_launch(const IgemmParams& p_in, hipStream_t s) {
         for (int i = 0; i < p.nclasses; ++i) blocks += ((long)p.B * p.cls[i].R * p.cls[i].C / 128) * (p.Np / 128);
         if (blocks < 1024) wide = false;
     }
-    if (vec) return wide ? launch_cfg<128, 128, true>(p, s) : launch_cfg<128, 64, true>(p, s);
-    return wide ? launch_cfg<128, 128, false>(p, s) : launch_cfg<128, 64, false>(p, s);
+    if (vec) return wide ? launch_cfg<128, 128, 4, true>(p, s) : launch_cfg<128, 64, 4, true>(p, s);
+    return wide ? launch_cfg<128, 128, 4, false>(p, s) : launch_cfg<128, 64, 4, false>(p, s);
 }
