@@ -80,7 +80,7 @@ static int run_dir(const CgsLayer& L, bool dirT, int B, const float* in, const f
         p.in = in + (size_t)b0 * (in_img / 4);
         p.out = out + (size_t)b0 * (out_img / 4);
         p.ep_aux = ep_aux ? ep_aux + (size_t)b0 * (out_img / 4) : nullptr;
-        int rc = cgs_igemm_launch(p, s);
+        int rc = cgs_igemm_launch(p, (char*)ws + need, ws_bytes - need, s);
         if (rc) return rc;
     }
     return CGS_OK;
@@ -88,7 +88,31 @@ static int run_dir(const CgsLayer& L, bool dirT, int B, const float* in, const f
 
 extern "C" {
 
+static size_t conv_packed_bytes(int op, int kh, int kw, int sh, int sw, int Cin, int Cout);
+
 size_t cgs_conv_ws_bytes(int op, int kh, int kw, int sh, int sw, int Cin, int Cout) {
+    return conv_packed_bytes(op, kh, kw, sh, sw, Cin, Cout);
+}
+
+size_t cgs_conv_ws_bytes_for(int op, int B, int H, int W, int Cin, int Cout, int kh, int kw, int sh, int sw) {
+    const size_t packed = conv_packed_bytes(op, kh, kw, sh, sw, Cin, Cout);
+    if (B <= 0 || H <= 0 || W <= 0 || packed == 0) return packed;
+    // H, W are the op's INPUT spatial size for conv fwd / deconv fwd and for their backward-datas the size of
+    // the tensor the gradient is taken w.r.t. (the arguments of the entry points)
+    const bool deconv = (op == CGS_DECONV_FWD || op == CGS_DECONV_BWD_DATA);
+    const bool dirT = (op == CGS_CONV_BWD_DATA || op == CGS_DECONV_FWD);
+    CgsLayer L;
+    L.kh = kh; L.kw = kw; L.sh = sh; L.sw = sw;
+    if (!deconv) { L.Hb = H; L.Wb = W; L.Cb = Cin; L.Hs = cgs_ceil_div(H, sh); L.Ws = cgs_ceil_div(W, sw); L.Cs = Cout; }
+    else { L.Hs = H; L.Ws = W; L.Cs = Cin; L.Hb = H * sh; L.Wb = W * sw; L.Cb = Cout; }   // bound: output = stride * input
+    if (dirT && (sh > 2 || sw > 2)) return packed;
+    IgemmParams p;
+    p.B = B;
+    if (dirT) cgs_geom_T(L, p); else cgs_geom_F(L, p);
+    return packed + cgs_igemm_splitk_bytes(p);
+}
+
+static size_t conv_packed_bytes(int op, int kh, int kw, int sh, int sw, int Cin, int Cout) {
     if (kh <= 0 || kw <= 0 || sh <= 0 || sw <= 0 || Cin <= 0 || Cout <= 0) return 0;
     // weights are [kh][kw][Cb][Cs]: conv Cb=Cin,Cs=Cout; deconv Cb=Cout,Cs=Cin
     const bool deconv = (op == CGS_DECONV_FWD || op == CGS_DECONV_BWD_DATA);

@@ -50,6 +50,7 @@ struct IgemmClass {
     int ky0, kx0;    // weight tap of (ta,tb) = (ky0 + ta*kstep, kx0 + tb*kstep)
     int K;           // nty*ntx*Cred
     int w_off;       // float offset of this class' packed weights
+    int slab_off;    // float offset of this class' split-K slabs
 };
 
 struct IgemmParams {
@@ -65,6 +66,8 @@ struct IgemmParams {
     int S, So, dstep, kstep;
     int epilogue;
     int pix_major;       // GEMM rows ordered (pixel, image) instead of (image, pixel): enables zero-tap skipping
+    int splitk;          // > 1: blockIdx.z splits the K tiles; raw partial tiles go to slab, reduced by a second kernel
+    float* slab;         // [class][split][M_c][Np]
     int lpt;             // pixel-major only: m-tiles visit the pixels in perm[] order (most valid taps first)
     int nclasses;
     IgemmClass cls[CGS_MAX_CLASSES];
@@ -78,7 +81,8 @@ size_t cgs_packed_floats(const IgemmParams& p);
 
 // launchers
 int cgs_pack_weights(const IgemmParams& p, const CgsLayer& L, bool dirT, const float* w, float* packed, hipStream_t s);
-int cgs_igemm_launch(const IgemmParams& p, hipStream_t s);
+int cgs_igemm_launch(const IgemmParams& p, void* slab, size_t slab_bytes, hipStream_t s);
+size_t cgs_igemm_splitk_bytes(const IgemmParams& p);   // slab bytes the launch would like (0 = no split-K)
 size_t cgs_convt_quad_ws_floats_bound(int kh, int kw, int Cs);
 int cgs_convt_quad_launch(const CgsLayer& L, int B, const float* in, const float* w, const float* bias, float* out,
                           int epilogue, const float* ep_a, const float* ep_aux, float* ws, size_t ws_bytes, int prepacked,

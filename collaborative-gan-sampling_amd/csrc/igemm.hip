@@ -199,7 +199,14 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 2) void igemm_kernel(IgemmPa
         }
     }
     const float* wsrc = p.wp + c.w_off;
-    const int nk = (c.K + BK - 1) / BK;
+    const int nk_all = (c.K + BK - 1) / BK;
+    // split-K: this block owns K tiles [kbeg, nk)
+    int kbeg = 0, nk = nk_all;
+    if (p.splitk > 1) {
+        const int cps = (nk_all + p.splitk - 1) / p.splitk;
+        kbeg = blockIdx.z * cps;
+        nk = kbeg + cps < nk_all ? kbeg + cps : nk_all;
+    }
 
     // zero-tap skipping (pixel-major, VEC): if every row of this tile is the same base pixel, a tap outside the
     // image contributes exact zeros for all rows -> its Cred/32 K-chunks are not loaded or multiplied at all.
@@ -289,7 +296,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 2) void igemm_kernel(IgemmPa
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
 
-    int kt = next_chunk(0);
+    int kt = next_chunk(kbeg);
     if (kt < nk) {
         LOAD_TILE(kt);
         STORE_TILE(0);
@@ -328,6 +335,21 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 2) void igemm_kernel(IgemmPa
 #undef STORE_TILE
 #undef DECODE_ROW
     // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    if (p.splitk > 1) {      // raw partial tile -> slab[class][split][m][Np]; bias / epilogue happen in the reduce kernel
+        float* slab = p.slab + c.slab_off + (size_t)blockIdx.z * M * p.Np;
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const int n = n0 + wn * (BN / WN) + tn * 32 + j;
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wm * (BM / 2) + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (m < M) slab[(size_t)m * p.Np + n] = acc[tm][tn][r];
+                }
+        }
+        return;
+    }
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
         const int n = n0 + wn * (BN / WN) + tn * 32 + j;
@@ -352,6 +374,65 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 2) void igemm_kernel(IgemmPa
     }
 }
 
+// out[pix(m)][n] = epi(bias[n] + sum_s slab[s][m][n]): fixed summation order -> deterministic
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(IgemmParams p) {
+    const IgemmClass& c = p.cls[blockIdx.y];
+    const int RC = c.R * c.C;
+    const int M = p.B * RC;
+    const int nq = p.Np / 4;
+    const long total = (long)M * nq;
+    const float* slab = p.slab + c.slab_off;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int m = (int)(i / nq), n = (int)(i - (long)m * nq) * 4;
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        for (int sidx = 0; sidx < p.splitk; ++sidx) a += *(const f32x4*)(slab + ((size_t)sidx * M + m) * p.Np + n);
+        int b, r, cc, rem;
+        if (p.pix_major) { rem = m / p.B; b = m - rem * p.B; } else { b = m / RC; rem = m - b * RC; }
+        r = rem / c.C; cc = rem - r * c.C;
+        const size_t o = (size_t)((b * p.Hout + r * p.So + c.py) * p.Wout + cc * p.So + c.px) * p.N;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (n + e >= p.N) break;
+            const float bias = p.bias ? p.bias[n + e] : 0.f;
+            float ea = 1.f, eb = 0.f;
+            if (p.epilogue == CGS_EPI_AFFINE_RELU) { ea = p.ep_a[n + e]; eb = p.ep_b[n + e]; }
+            if (p.epilogue == CGS_EPI_RELU_BWD_AFFINE) ea = p.ep_a[n + e];
+            const float aux = p.epilogue >= CGS_EPI_RELU_BWD_AFFINE ? p.ep_aux[o + n + e] : 0.f;
+            p.out[o + n + e] = epilogue_apply(a[e] + bias, p.epilogue, ea, eb, aux);
+        }
+    }
+}
+
+static long igemm_blocks(const IgemmParams& p, int BN) {
+    long blocks = 0;
+    for (int i = 0; i < p.nclasses; ++i) blocks += (((long)p.B * p.cls[i].R * p.cls[i].C + 127) / 128) * (p.Np / BN);
+    return blocks;
+}
+
+// split factor for grids that leave most of the 256 CUs (x2 block slots) idle
+static int choose_splitk(const IgemmParams& p) {
+    const int BN = (p.Np % 128) == 0 ? 128 : 64;
+    const long blocks = igemm_blocks(p, BN);
+    int nk_min = 1 << 30;
+    for (int i = 0; i < p.nclasses; ++i) {
+        const int nk = cgs_ceil_div(p.cls[i].K, BK);
+        if (p.cls[i].R * p.cls[i].C > 0 && nk < nk_min) nk_min = nk;
+    }
+    if (blocks == 0 || blocks >= 256 || nk_min < 8) return 1;
+    long s = (512 + blocks - 1) / blocks;
+    if (s > nk_min / 4) s = nk_min / 4;
+    if (s > 64) s = 64;
+    return s < 2 ? 1 : (int)s;
+}
+
+size_t cgs_igemm_splitk_bytes(const IgemmParams& p) {
+    const int s = choose_splitk(p);
+    if (s <= 1) return 0;
+    size_t n = 0;
+    for (int i = 0; i < p.nclasses; ++i) n += (size_t)s * p.B * p.cls[i].R * p.cls[i].C * p.Np;
+    return n * sizeof(float);
+}
+
 template <int BM, int BN, int NW, bool VEC>
 static int launch_cfg(const IgemmParams& p, hipStream_t s) {
     constexpr size_t smem = (size_t)(2 * BM * LDA + 2 * BK * BN) * sizeof(float) + BM * sizeof(int);
@@ -370,16 +451,24 @@ static int launch_cfg(const IgemmParams& p, hipStream_t s) {
     if (maxM == 0) return CGS_OK;
     const long gx = (maxM + BM - 1) / BM * (p.Np / BN);
     if (gx > 0x7fffffffL) return cgs_set_error(CGS_EINVAL, "igemm: grid too large");
-    hipLaunchKernelGGL((igemm_kernel<BM, BN, NW, VEC>), dim3((unsigned)gx, p.nclasses), dim3(64 * NW), smem, s, p);
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, NW, VEC>), dim3((unsigned)gx, p.nclasses, p.splitk > 1 ? p.splitk : 1), dim3(64 * NW), smem, s, p);
     CGS_CHECK_LAUNCH("igemm");
+    if (p.splitk > 1) {
+        long tot = 0;
+        for (int i = 0; i < p.nclasses; ++i) { long t = (long)p.B * p.cls[i].R * p.cls[i].C * (p.Np / 4); if (t > tot) tot = t; }
+        unsigned rb = (unsigned)((tot + 255) / 256 > 2048 ? 2048 : (tot + 255) / 256);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rb, p.nclasses), dim3(256), 0, s, p);
+        CGS_CHECK_LAUNCH("splitk_reduce");
+    }
     cgs_note_kernel(BN == 128 ? (VEC ? "igemm_kernel<128,128,4,true>" : "igemm_kernel<128,128,4,false>")
                     : NW == 2 ? (VEC ? "igemm_kernel<128,64,2,true>" : "igemm_kernel<128,64,2,false>")
                               : (VEC ? "igemm_kernel<128,64,4,true>" : "igemm_kernel<128,64,4,false>"));
     return CGS_OK;
 }
 
-int cgs_igemm_launch(const IgemmParams& p_in, hipStream_t s) {
+int cgs_igemm_launch(const IgemmParams& p_in, void* slab, size_t slab_bytes, hipStream_t s) {
     IgemmParams p = p_in;
+    p.splitk = 1; p.slab = nullptr;
     // pixel-major row order pays when the base-pixel grid is small (many padded taps per pixel, and the whole
     // input stays in the 256 MiB Infinity Cache for the cross-tile re-reads) and the batch fills whole tiles
     int maxRC = 0;
@@ -406,6 +495,17 @@ int cgs_igemm_launch(const IgemmParams& p_in, hipStream_t s) {
         }
     if ((long)p.B * p.Hout * p.Wout * p.N * 4 > 0x7fffffffL || (long)p.B * p.Hin * p.Win * p.Cred * 4 > 0x7fffffffL)
         return cgs_set_error(CGS_EINVAL, "igemm: a tensor of one launch exceeds 2 GiB (the caller splits the batch)");
+    {   // split-K for under-filled grids, if the caller's workspace has room for the partial slabs
+        const size_t need = cgs_igemm_splitk_bytes(p);
+        if (need && slab && slab_bytes >= need) {
+            p.splitk = choose_splitk(p); p.slab = (float*)slab;
+            size_t off = 0;
+            for (int i = 0; i < p.nclasses; ++i) {
+                p.cls[i].slab_off = (int)off;
+                off += (size_t)p.splitk * p.B * p.cls[i].R * p.cls[i].C * p.Np;
+            }
+        }
+    }
     const bool vec = (p.Cred % BK) == 0;
     bool wide = (p.Np % 128) == 0;
     if (wide && p.lpt) {      // uneven tiles need >= 2 rounds of blocks over the 512 block slots to balance: halve BN if short

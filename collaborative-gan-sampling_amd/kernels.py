@@ -69,12 +69,13 @@ class _WsCache:
     def __init__(self):
         self._d = {}
 
-    def get(self, w, op, kh, kw, sh, sw, cin, cout):
-        key = (w.data_ptr(), op, kh, kw, sh, sw, cin, cout, w.device.index)
+    def get(self, w, op, kh, kw, sh, sw, cin, cout, bhw=(0, 0, 0)):
+        """``bhw`` = (B, H, W) of the call: sizes the optional split-K slab area behind the packed weights."""
+        key = (w.data_ptr(), op, kh, kw, sh, sw, cin, cout, w.device.index, bhw)
         hit = self._d.get(key)
         if hit is not None and hit[0]() is w and hit[1] == w._version:
             return hit[2], 1
-        nbytes = L.conv_ws_bytes(op, kh, kw, sh, sw, cin, cout)
+        nbytes = L.conv_ws_bytes_for(op, bhw[0], bhw[1], bhw[2], cin, cout, kh, kw, sh, sw)
         ws = torch.empty(max(nbytes, 16) // 4, dtype=torch.float32, device=w.device)
         if len(self._d) > 512:
             self._d.clear()
@@ -107,7 +108,7 @@ def conv2d_fwd(x, w, bias, sh=2, sw=2, epilogue=L.EPI_NONE, ep_a=None, ep_b=None
     if Cin2 != Cin:
         raise L.CgsError(f"conv2d: weight Cin {Cin2} != input channels {Cin}")
     y = out if out is not None else torch.empty((B, same_out(H, sh), same_out(W, sw), Cout), dtype=torch.float32, device=x.device)
-    ws, pre = WS.get(w, L.CONV_FWD, kh, kw, sh, sw, Cin, Cout)
+    ws, pre = WS.get(w, L.CONV_FWD, kh, kw, sh, sw, Cin, Cout, (B, H, W))
     Ho, Wo = y.shape[1], y.shape[2]
     pr = _Prof(2.0 * B * Ho * Wo * Cout * kh * kw * Cin, f"conv_fwd {H}x{W} {Cin}->{Cout}") if PROFILE is not None else None
     L.call("cgs_conv2d_nhwc_fwd", _ptr(x), _ptr(w), _ptr(bias), _ptr(y), B, H, W, Cin, Cout, kh, kw, sh, sw,
@@ -125,7 +126,7 @@ def conv2d_bwd_data(dy, w, in_hw, sh=2, sw=2, out=None, epilogue=L.EPI_NONE, ep_
     B = dy.shape[0]
     H, W = in_hw
     dx = out if out is not None else torch.empty((B, H, W, Cin), dtype=torch.float32, device=dy.device)
-    ws, pre = WS.get(w, L.CONV_BWD_DATA, kh, kw, sh, sw, Cin, Cout)
+    ws, pre = WS.get(w, L.CONV_BWD_DATA, kh, kw, sh, sw, Cin, Cout, (B, H, W))
     Ho, Wo = dy.shape[1], dy.shape[2]
     pr = _Prof(2.0 * B * Ho * Wo * Cout * kh * kw * Cin, f"conv_bwd {H}x{W} {Cin}<-{Cout}") if PROFILE is not None else None
     L.call("cgs_conv2d_nhwc_bwd_data", _ptr(dy), _ptr(w), _ptr(dx), B, H, W, Cin, Cout, kh, kw, sh, sw,
@@ -144,7 +145,7 @@ def deconv2d_fwd(x, w, bias, out_hw, sh=2, sw=2, epilogue=L.EPI_NONE, ep_a=None,
         raise L.CgsError(f"deconv2d: weight Cin {Cin2} != input channels {Cin}")
     Ho, Wo = out_hw
     y = out if out is not None else torch.empty((B, Ho, Wo, Cout), dtype=torch.float32, device=x.device)
-    ws, pre = WS.get(w, L.DECONV_FWD, kh, kw, sh, sw, Cin, Cout)
+    ws, pre = WS.get(w, L.DECONV_FWD, kh, kw, sh, sw, Cin, Cout, (B, H, W))
     pr = _Prof(2.0 * B * H * W * Cin * kh * kw * Cout, f"deconv_fwd {H}x{W} {Cin}->{Cout}") if PROFILE is not None else None
     L.call("cgs_deconv2d_nhwc_fwd", _ptr(x), _ptr(w), _ptr(bias), _ptr(y), B, H, W, Cin, Ho, Wo, Cout, kh, kw, sh, sw,
            epilogue, _ptr(ep_a), _ptr(ep_b), _ptr(ws), ws.numel() * 4, pre, _stream())
@@ -160,7 +161,7 @@ def deconv2d_bwd_data(dy, w, in_hw, sh=2, sw=2, out=None, epilogue=L.EPI_NONE, e
     B, Ho, Wo, _ = dy.shape
     H, W = in_hw
     dx = out if out is not None else torch.empty((B, H, W, Cin), dtype=torch.float32, device=dy.device)
-    ws, pre = WS.get(w, L.DECONV_BWD_DATA, kh, kw, sh, sw, Cin, Cout)
+    ws, pre = WS.get(w, L.DECONV_BWD_DATA, kh, kw, sh, sw, Cin, Cout, (B, H, W))
     pr = _Prof(2.0 * B * H * W * Cin * kh * kw * Cout, f"deconv_bwd {H}x{W} {Cin}<-{Cout}") if PROFILE is not None else None
     L.call("cgs_deconv2d_nhwc_bwd_data", _ptr(dy), _ptr(w), _ptr(dx), B, H, W, Cin, Ho, Wo, Cout, kh, kw, sh, sw,
            epilogue, _ptr(ep_a), _ptr(ep_aux), _ptr(ws), ws.numel() * 4, pre, _stream())
@@ -180,7 +181,7 @@ def linear_fwd(x, w, bias, epilogue=L.EPI_NONE, out=None):
     if N == 1:
         L.call("cgs_linear_fwd", _ptr(x), _ptr(w), _ptr(bias), _ptr(y), B, K, N, epilogue, None, 0, 0, _stream())
         return y
-    ws, pre = WS.get(w, L.CONV_FWD, 1, 1, 1, 1, K, N)
+    ws, pre = WS.get(w, L.CONV_FWD, 1, 1, 1, 1, K, N, (B, 1, 1))
     L.call("cgs_linear_fwd", _ptr(x), _ptr(w), _ptr(bias), _ptr(y), B, K, N, epilogue, _ptr(ws), ws.numel() * 4, pre, _stream())
     return y
 
@@ -193,7 +194,7 @@ def linear_bwd_data(dy, w, out=None):
     if N == 1:
         L.call("cgs_linear_bwd_data", _ptr(dy), _ptr(w), _ptr(dx), B, K, N, None, 0, 0, _stream())
         return dx
-    ws, pre = WS.get(w, L.CONV_BWD_DATA, 1, 1, 1, 1, K, N)
+    ws, pre = WS.get(w, L.CONV_BWD_DATA, 1, 1, 1, 1, K, N, (B, 1, 1))
     L.call("cgs_linear_bwd_data", _ptr(dy), _ptr(w), _ptr(dx), B, K, N, _ptr(ws), ws.numel() * 4, pre, _stream())
     return dx
 

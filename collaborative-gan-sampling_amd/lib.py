@@ -22,6 +22,7 @@ SIGNATURES = {
     "cgs_last_error": (C.c_char_p, []),
     "cgs_last_kernel": (C.c_char_p, []),
     "cgs_conv_ws_bytes": (_z, [_i] * 7),
+    "cgs_conv_ws_bytes_for": (_z, [_i] * 10),
     "cgs_conv2d_nhwc_fwd": (_i, [_p] * 4 + [_i] * 9 + [_i, _p, _p, _p, _z, _i, _p]),
     "cgs_conv2d_nhwc_bwd_data": (_i, [_p] * 3 + [_i] * 9 + [_i, _p, _p, _p, _z, _i, _p]),
     "cgs_deconv2d_nhwc_fwd": (_i, [_p] * 4 + [_i] * 11 + [_i, _p, _p, _p, _z, _i, _p]),
@@ -77,6 +78,10 @@ def call(name, *args):
 
 def conv_ws_bytes(op, kh, kw, sh, sw, cin, cout):
     return int(load().cgs_conv_ws_bytes(op, kh, kw, sh, sw, cin, cout))
+
+
+def conv_ws_bytes_for(op, b, h, w, cin, cout, kh, kw, sh, sw):
+    return int(load().cgs_conv_ws_bytes_for(op, b, h, w, cin, cout, kh, kw, sh, sw))
 
 
 def bn_ws_bytes(m, c):

@@ -63,6 +63,11 @@ const char* cgs_last_kernel(void);
  * (op = one of CGS_CONV_* above; Cin/Cout are those of the LAYER, i.e. of the
  * forward op, for the backward variants too). */
 size_t cgs_conv_ws_bytes(int op, int kh, int kw, int sh, int sw, int Cin, int Cout);
+/* Same, plus room for the split-K partial slabs the library uses when the launch would otherwise
+ * leave most CUs idle (small batch x small spatial size, e.g. the MNIST fc layers at batch 64).
+ * B, H, W as passed to the entry point.  Optional: with only cgs_conv_ws_bytes() bytes the call runs un-split.
+ * Layout: [packed weights | slabs]; ws_prepacked refers to the first part only. */
+size_t cgs_conv_ws_bytes_for(int op, int B, int H, int W, int Cin, int Cout, int kh, int kw, int sh, int sw);
 
 /* conv2d: y[B,Ho,Wo,Cout] = conv(x[B,H,W,Cin], w[kh,kw,Cin,Cout], stride, 'SAME') + bias, then epilogue.
  * Replaces tf.nn.conv2d + tf.nn.bias_add at nsgan/ops.py:41-44 (Ho = ceil(H/sh)).
