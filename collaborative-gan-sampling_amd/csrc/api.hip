@@ -63,7 +63,8 @@ static int run_dir(const CgsLayer& L, bool dirT, int B, const float* in, const f
     if (dirT) cgs_geom_T(L, p); else cgs_geom_F(L, p);
     const size_t need = cgs_packed_floats(p) * sizeof(float);
     if (!ws || ws_bytes < need) return cgs_set_error(CGS_EWORKSPACE, "%s: workspace %zu < %zu bytes", who, ws_bytes, need);
-    if (((uintptr_t)ws & 15) || ((uintptr_t)in & 15) || ((uintptr_t)out & 3))
+    if (((uintptr_t)ws & 15) || ((uintptr_t)in & 15) || ((uintptr_t)out & 15) || ((uintptr_t)bias & 15) ||
+        ((uintptr_t)ep_a & 15) || ((uintptr_t)ep_b & 15) || ((uintptr_t)ep_aux & 15))
         return cgs_set_error(CGS_EINVAL, "%s: pointers must be 16-byte aligned", who);
     p.wp = (const float*)ws;
     if (!prepacked) {

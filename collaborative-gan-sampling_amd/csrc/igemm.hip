@@ -355,9 +355,57 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 2) void igemm_kernel(IgemmPa
         }
         return;
     }
+    constexpr int WTN = BN / WN;                 // columns of a wave tile
+    if ((p.N & 3) == 0) {
+        // Wide epilogue: the accumulators hold column strips (one column per lane); stage the wave tile through
+        // LDS (the K-loop buffers are free now) so that each lane owns 4 consecutive channels of a row and
+        // the aux loads / output stores are 16 bytes per lane, 256 contiguous bytes per 16 lanes: 4x fewer
+        // store (and aux load) instructions than the per-register scalar form below.
+        constexpr int LDE = WTN + 4;
+        static_assert((size_t)NW * (BM / 2) * LDE <= (size_t)(2 * BM * LDA + 2 * BK * BN), "epilogue staging must fit the K-loop LDS");
+        float* E = smem + wave * (BM / 2) * LDE;  // this wave's [BM/2][LDE] staging tile
+        // all waves are past the loop's final barrier; rowpix lives behind the staging area
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    E[(tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * LDE + tn * 32 + j] = acc[tm][tn][r];
+        // same wave reads what it wrote: LDS ops of one wave complete in order, only the compiler must not reorder
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        constexpr int LPR = WTN / 4;              // lanes per row (16 for 64 columns, 8 for 32)
+        constexpr int RPP = 64 / LPR;             // rows per pass
+        const int c4 = (lane % LPR) * 4, rsub = lane / LPR;
+        const int n = n0 + wn * WTN + c4;
+        if (n < p.N) {
+            f32x4 bias = {0.f, 0.f, 0.f, 0.f}, ea = {1.f, 1.f, 1.f, 1.f}, eb = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias) bias = *(const f32x4*)(p.bias + n);
+            if (p.epilogue == CGS_EPI_AFFINE_RELU) { ea = *(const f32x4*)(p.ep_a + n); eb = *(const f32x4*)(p.ep_b + n); }
+            if (p.epilogue == CGS_EPI_RELU_BWD_AFFINE) ea = *(const f32x4*)(p.ep_a + n);
+            const bool use_aux = p.epilogue >= CGS_EPI_RELU_BWD_AFFINE;
+#pragma unroll 4
+            for (int it = 0; it < (BM / 2) / RPP; ++it) {
+                const int lrow = it * RPP + rsub;
+                const int pix = rowpix[wm * (BM / 2) + lrow];
+                if (pix < 0) continue;
+                const f32x4 v = *(const f32x4*)(E + lrow * LDE + c4);
+                const size_t o = (size_t)pix * p.N + n;
+                f32x4 aux = {0.f, 0.f, 0.f, 0.f};
+                if (use_aux) aux = *(const f32x4*)(p.ep_aux + o);
+                f32x4 y;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[e] = epilogue_apply(v[e] + bias[e], p.epilogue, ea[e], eb[e], aux[e]);
+                *(f32x4*)(p.out + o) = y;
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
-        const int n = n0 + wn * (BN / WN) + tn * 32 + j;
+        const int n = n0 + wn * WTN + tn * 32 + j;
         if (n >= p.N) continue;
         const float bias = p.bias ? p.bias[n] : 0.f;
         float ea = 1.f, eb = 0.f;
