@@ -29,8 +29,7 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-static constexpr int BK = CGS_BK;
-static constexpr int LDA = BK + 4;   // padded A row (floats): 144 B, keeps b128 reads conflict-free
+static constexpr int BK = CGS_BK;     // K padding granule of the packed weights (the kernels tile K by 32 or 16)
 
 // ------------------------------------------------------------------------------------------------
 // geometry
@@ -131,13 +130,16 @@ __device__ __forceinline__ float epilogue_apply(float v, int mode, float a, floa
 }
 
 // NW waves per block, arranged 2 (M) x NW/2 (N); wave tile (BM/2) x (BN/(NW/2)).
-template <int BM, int BN, int NW, bool VEC>
-__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 2) void igemm_kernel(IgemmParams p) {
+template <int BM, int BN, int NW, bool VEC, int TBK>
+__global__ __launch_bounds__(64 * NW, 2) void igemm_kernel(IgemmParams p) {
+    constexpr int BK = TBK;                       // K tile (shadows the packing granule; TBK divides it)
+    constexpr int LDA = BK + 4;                   // padded A row (floats): keeps the b128 fragment reads conflict-free
     constexpr int NT = 64 * NW;                   // threads per block
     constexpr int WN = NW / 2;                    // waves along N
     constexpr int TM = BM / 64, TN = BN / (32 * WN);   // 32x32 MFMA tiles per wave
-    constexpr int AI = BM * 8 / NT, BI = BN * 8 / NT;  // float4 staged per thread (A rows / B columns)
-    constexpr int AR = NT / 8;                    // A rows covered per staging pass
+    constexpr int QPR = BK / 4;                   // k-quads per A row chunk
+    constexpr int AI = BM * QPR / NT, BI = BN * QPR / NT;  // float4 staged per thread (A rows / B columns)
+    constexpr int AR = NT / QPR;                  // A rows covered per staging pass
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                              // [2][BM][LDA]
     float* Bs = smem + 2 * BM * LDA;               // [2][BK/4][BN][4]
@@ -190,7 +192,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 2) void igemm_kernel(IgemmPa
     }
 
     // A staging: thread -> k-quad aq of rows ar + 32*i
-    const int aq = tid & 7, ar = tid >> 3;
+    const int aq = tid % QPR, ar = tid / QPR;
     int a_base[AI], a_iy[AI], a_ix[AI];
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
@@ -362,44 +364,50 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 2) void igemm_kernel(IgemmPa
         // the aux loads / output stores are 16 bytes per lane, 256 contiguous bytes per 16 lanes: 4x fewer
         // store (and aux load) instructions than the per-register scalar form below.
         constexpr int LDE = WTN + 4;
-        static_assert((size_t)NW * (BM / 2) * LDE <= (size_t)(2 * BM * LDA + 2 * BK * BN), "epilogue staging must fit the K-loop LDS");
-        float* E = smem + wave * (BM / 2) * LDE;  // this wave's [BM/2][LDE] staging tile
-        // all waves are past the loop's final barrier; rowpix lives behind the staging area
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    E[(tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * LDE + tn * 32 + j] = acc[tm][tn][r];
-        // same wave reads what it wrote: LDS ops of one wave complete in order, only the compiler must not reorder
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        static_assert((size_t)NW * 32 * LDE <= (size_t)(2 * BM * LDA + 2 * BK * BN), "epilogue staging must fit the K-loop LDS");
+        float* E = smem + wave * 32 * LDE;        // this wave's [32][LDE] staging tile (one 32-row MFMA tile at a time)
         constexpr int LPR = WTN / 4;              // lanes per row (16 for 64 columns, 8 for 32)
         constexpr int RPP = 64 / LPR;             // rows per pass
         const int c4 = (lane % LPR) * 4, rsub = lane / LPR;
         const int n = n0 + wn * WTN + c4;
+        f32x4 bias = {0.f, 0.f, 0.f, 0.f}, ea = {1.f, 1.f, 1.f, 1.f}, eb = {0.f, 0.f, 0.f, 0.f};
         if (n < p.N) {
-            f32x4 bias = {0.f, 0.f, 0.f, 0.f}, ea = {1.f, 1.f, 1.f, 1.f}, eb = {0.f, 0.f, 0.f, 0.f};
             if (p.bias) bias = *(const f32x4*)(p.bias + n);
             if (p.epilogue == CGS_EPI_AFFINE_RELU) { ea = *(const f32x4*)(p.ep_a + n); eb = *(const f32x4*)(p.ep_b + n); }
             if (p.epilogue == CGS_EPI_RELU_BWD_AFFINE) ea = *(const f32x4*)(p.ep_a + n);
-            const bool use_aux = p.epilogue >= CGS_EPI_RELU_BWD_AFFINE;
-#pragma unroll 4
-            for (int it = 0; it < (BM / 2) / RPP; ++it) {
-                const int lrow = it * RPP + rsub;
-                const int pix = rowpix[wm * (BM / 2) + lrow];
-                if (pix < 0) continue;
-                const f32x4 v = *(const f32x4*)(E + lrow * LDE + c4);
-                const size_t o = (size_t)pix * p.N + n;
-                f32x4 aux = {0.f, 0.f, 0.f, 0.f};
-                if (use_aux) aux = *(const f32x4*)(p.ep_aux + o);
-                f32x4 y;
+        }
+        const bool use_aux = p.epilogue >= CGS_EPI_RELU_BWD_AFFINE;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) y[e] = epilogue_apply(v[e] + bias[e], p.epilogue, ea[e], eb[e], aux[e]);
-                *(f32x4*)(p.out + o) = y;
+        for (int tm = 0; tm < TM; ++tm) {
+            // all waves are past the loop's final barrier (K-loop buffers are dead); rowpix lives behind them
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    E[((r & 3) + 8 * (r >> 2) + 4 * h) * LDE + tn * 32 + j] = acc[tm][tn][r];
+            // the same wave reads what it wrote: LDS ops of one wave complete in order; only the compiler must keep it
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (n < p.N) {
+#pragma unroll
+                for (int it = 0; it < 32 / RPP; ++it) {
+                    const int lrow = it * RPP + rsub;
+                    const int pix = rowpix[wm * (BM / 2) + tm * 32 + lrow];
+                    if (pix < 0) continue;
+                    const f32x4 v = *(const f32x4*)(E + lrow * LDE + c4);
+                    const size_t o = (size_t)pix * p.N + n;
+                    f32x4 aux = {0.f, 0.f, 0.f, 0.f};
+                    if (use_aux) aux = *(const f32x4*)(p.ep_aux + o);
+                    f32x4 y;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) y[e] = epilogue_apply(v[e] + bias[e], p.epilogue, ea[e], eb[e], aux[e]);
+                    *(f32x4*)(p.out + o) = y;
+                }
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
         return;
     }
@@ -486,12 +494,12 @@ size_t cgs_igemm_splitk_bytes(const IgemmParams& p) {
     return n * sizeof(float);
 }
 
-template <int BM, int BN, int NW, bool VEC>
+template <int BM, int BN, int NW, bool VEC, int TBK>
 static int launch_cfg(const IgemmParams& p, hipStream_t s) {
-    constexpr size_t smem = (size_t)(2 * BM * LDA + 2 * BK * BN) * sizeof(float) + BM * sizeof(int);
+    constexpr size_t smem = (size_t)(2 * BM * (TBK + 4) + 2 * TBK * BN) * sizeof(float) + BM * sizeof(int);
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)igemm_kernel<BM, BN, NW, VEC>,
+        hipError_t e = hipFuncSetAttribute((const void*)igemm_kernel<BM, BN, NW, VEC, TBK>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return cgs_set_error(CGS_ELAUNCH, "igemm smem attr: %s", hipGetErrorString(e));
         attr_done = true;
@@ -504,7 +512,7 @@ static int launch_cfg(const IgemmParams& p, hipStream_t s) {
     if (maxM == 0) return CGS_OK;
     const long gx = (maxM + BM - 1) / BM * (p.Np / BN);
     if (gx > 0x7fffffffL) return cgs_set_error(CGS_EINVAL, "igemm: grid too large");
-    hipLaunchKernelGGL((igemm_kernel<BM, BN, NW, VEC>), dim3((unsigned)gx, p.nclasses, p.splitk > 1 ? p.splitk : 1), dim3(64 * NW), smem, s, p);
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, NW, VEC, TBK>), dim3((unsigned)gx, p.nclasses, p.splitk > 1 ? p.splitk : 1), dim3(64 * NW), smem, s, p);
     CGS_CHECK_LAUNCH("igemm");
     if (p.splitk > 1) {
         long tot = 0;
@@ -566,6 +574,7 @@ int cgs_igemm_launch(const IgemmParams& p_in, void* slab, size_t slab_bytes, hip
         for (int i = 0; i < p.nclasses; ++i) blocks += ((long)p.B * p.cls[i].R * p.cls[i].C / 128) * (p.Np / 128);
         if (blocks < 1024) wide = false;
     }
-    if (vec) return wide ? launch_cfg<128, 128, 4, true>(p, s) : launch_cfg<128, 64, 4, true>(p, s);
-    return wide ? launch_cfg<128, 128, 4, false>(p, s) : launch_cfg<128, 64, 4, false>(p, s);
+    // K tile: 32 when every tile lies inside one tap (VEC); 16 for the generic-K gather (small K: less padding waste)
+    if (vec) return wide ? launch_cfg<128, 128, 4, true, 32>(p, s) : launch_cfg<128, 64, 4, true, 32>(p, s);
+    return wide ? launch_cfg<128, 128, 4, false, 16>(p, s) : launch_cfg<128, 64, 4, false, 16>(p, s);
 }
