@@ -142,6 +142,135 @@ __global__ __launch_bounds__(256) void convt_quad_mfma_kernel(QuadParams p) {
         }
 }
 
+// ------------------------------------------------------------------------------------------------
+// LDS-patch variant (Ws % 32 == 0, Hs % 8 == 0): a block owns an 8 x 32 tile of quads of one image.  Per
+// 16-channel chunk the (8+ny-1) x (32+nx-1) input patch is staged ONCE in LDS (double buffered, the next chunk's
+// global loads in flight under the MFMAs) and every neighbour's A fragment is a conflict-free ds_read_b128 from it:
+// each input element leaves L2 ~1.3x instead of 9x.  The 4 image rows x 64 pixels x N channels a wave produces
+// are transposed through LDS and stored (and the aux tensor loaded) as 16-byte accesses of whole 768-byte rows.
+// ------------------------------------------------------------------------------------------------
+template <int NPAD>   // NPAD = N (<= 4)
+__global__ __launch_bounds__(256, 2) void convt_quad_lds_kernel(QuadParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, i = lane & 15;
+    const int K = p.ny * p.nx * p.Cs;
+    const int PH = 8 + p.ny - 1, PW = 32 + p.nx - 1;       // patch rows / cols (pixels)
+    const int patch_f4 = PH * PW * 4;                      // float4 per 16-channel patch
+    float* Bs = smem;                                      // [K/4][16][4]
+    float* Ps = smem + (size_t)K * 16;                     // [2][PH][PW][16]
+    for (int q = tid; q < K * 4; q += 256) ((f32x4*)Bs)[q] = ((const f32x4*)p.wq)[q];
+
+    const int tiles_x = p.Ws >> 5, tiles_y = p.Hs >> 3;
+    const int tpi = tiles_x * tiles_y;
+    const int b = blockIdx.x / tpi, trem = blockIdx.x - b * tpi;
+    const int r0 = (trem / tiles_x) * 8, c0 = (trem - (trem / tiles_x) * tiles_x) * 32;
+
+    const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)p.in, 0, (int)((unsigned)p.B * (unsigned)p.Hs * (unsigned)p.Ws * (unsigned)p.Cs * 4u), 0x00020000);
+    constexpr int PL = 6;                                  // float4 staged per thread: ceil(10*34*4 / 256)
+    f32x4 st[PL];
+    const int nchunk = p.Cs >> 4;
+#define LOAD_PATCH(ch_)                                                                                   \
+    _Pragma("unroll") for (int u = 0; u < PL; ++u) {                                                       \
+        const int q = tid + 256 * u;                                                                       \
+        unsigned off = 0xFFFFFFF0u;                                                                        \
+        if (q < patch_f4) {                                                                                \
+            const int pixel = q >> 2, c4 = q & 3;                                                          \
+            const int pr = pixel / PW, pc = pixel - pr * PW;                                               \
+            const int iy = r0 + pr + p.dmin_y, ix = c0 + pc + p.dmin_x;                                    \
+            if ((unsigned)iy < (unsigned)p.Hs && (unsigned)ix < (unsigned)p.Ws)                            \
+                off = (unsigned)(((b * p.Hs + iy) * p.Ws + ix) * p.Cs + (ch_) * 16 + c4 * 4) * 4u;          \
+        }                                                                                                  \
+        st[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, off, 0, 0));      \
+    }
+#define STORE_PATCH(buf_)                                                                                  \
+    _Pragma("unroll") for (int u = 0; u < PL; ++u) {                                                       \
+        const int q = tid + 256 * u;                                                                       \
+        if (q < patch_f4) ((f32x4*)(Ps + (size_t)(buf_) * patch_f4 * 4))[q] = st[u];                       \
+    }
+
+    f32x4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    LOAD_PATCH(0);
+    STORE_PATCH(0);
+    __syncthreads();
+    for (int ch = 0; ch < nchunk; ++ch) {
+        const int buf = ch & 1;
+        if (ch + 1 < nchunk) { LOAD_PATCH(ch + 1); }
+        const float* P = Ps + (size_t)buf * patch_f4 * 4;
+        for (int a = 0; a < p.ny; ++a)
+            for (int bq = 0; bq < p.nx; ++bq) {
+                const int it = (a * p.nx + bq) * nchunk + ch;          // k-quad group index of (neighbour, chunk)
+                const f32x4 fb = *(const f32x4*)(Bs + ((size_t)(it * 4 + g) * 16 + i) * 4);
+                f32x4 fa[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int pr = 2 * wave + (t >> 1) + a, pc = 16 * (t & 1) + i + bq;
+                    fa[t] = *(const f32x4*)(P + ((size_t)(pr * PW + pc) * 4 + g) * 4);
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[t].x, fb.x, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[t].y, fb.y, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[t].z, fb.z, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[t].w, fb.w, acc[t], 0, 0, 0);
+                }
+            }
+        if (ch + 1 < nchunk) { STORE_PATCH(buf ^ 1); }
+        __syncthreads();
+    }
+#undef LOAD_PATCH
+#undef STORE_PATCH
+
+    // ---- epilogue: transpose the wave's 4 image rows x (64 px x N) through LDS, then 16-byte row accesses ----
+    constexpr int N = NPAD;
+    const int rowf = 64 * N;                               // floats per output image row of the tile
+    float* E = Ps + (size_t)wave * 4 * rowf;               // [4 image rows][64*N]   (patch buffers are dead: barrier above)
+    const int cls = i / N, n = i - cls * N;
+    if (cls < 4) {
+        const int py = cls >> 1, px = cls & 1;
+        const float bias = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = 16 * (t & 1) + g * 4 + r;    // quad column inside the tile
+                E[(2 * (t >> 1) + py) * rowf + (2 * c + px) * N + n] = acc[t][r] + bias;
+            }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int f4_per_row = rowf / 4;                       // 48 for N = 3
+    const float ea = 1.f;
+    (void)ea;
+    for (int q = lane; q < 4 * f4_per_row; q += 64) {
+        const int yr = q / f4_per_row, xq = q - yr * f4_per_row;
+        const int y = 2 * (r0 + 2 * wave) + yr;
+        const size_t o = ((size_t)(b * 2 * p.Hs + y) * (2 * p.Ws) + 2 * c0) * N + xq * 4;
+        f32x4 v = *(const f32x4*)(E + yr * rowf + xq * 4);
+        if (p.epilogue == CGS_EPI_TANH) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
+        } else if (p.epilogue == CGS_EPI_LRELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.2f * v[e]);
+        } else if (p.epilogue >= CGS_EPI_RELU_BWD_AFFINE) {
+            const f32x4 y4 = *(const f32x4*)(p.ep_aux + o);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (p.epilogue == CGS_EPI_TANH_BWD) v[e] *= (1.f - y4[e] * y4[e]);
+                else if (p.epilogue == CGS_EPI_LRELU_BWD) v[e] = y4[e] > 0.f ? v[e] : 0.2f * v[e];
+                else v[e] = y4[e] > 0.f ? v[e] * p.ep_a[(xq * 4 + e) % N] : 0.f;
+            }
+        }
+        *(f32x4*)(p.out + o) = v;
+    }
+}
+
 static void quad_range(int k, int pad, int& lo, int& hi) {
     lo = 1 << 20; hi = -(1 << 20);
     for (int par = 0; par < 2; ++par)
@@ -176,6 +305,36 @@ int cgs_convt_quad_launch(const CgsLayer& L, int B, const float* in, const float
         hipLaunchKernelGGL(pack_quad_weights_kernel, dim3((unsigned)((K * 16 + 255) / 256)), dim3(256), 0, s, w, ws, L.kh, L.kw,
                            L.Cb, L.Cs, pt, pl, p.dmin_y, p.ny, p.dmin_x, p.nx);
         CGS_CHECK_LAUNCH("pack_quad_weights");
+    }
+    const long total_q = (long)B * L.Hs * L.Ws;
+    if (total_q == 0) return CGS_OK;
+    // LDS-patch variant: 8 x 32 quad tiles; needs 16-byte aligned output rows (64*N floats per tile row)
+    if ((L.Ws % 32) == 0 && (L.Hs % 8) == 0 && p.ny <= 3 && p.nx <= 3 && ((64 * L.Cb) % 4) == 0 &&
+        ((2 * L.Ws * L.Cb) % 4) == 0) {
+        const int PH = 8 + p.ny - 1, PW = 32 + p.nx - 1;
+        const size_t smem = need + (size_t)2 * PH * PW * 16 * sizeof(float);
+        const long blocks = (long)B * (L.Hs / 8) * (L.Ws / 32);
+#define QUAD_LDS_CASE(NN)                                                                                          \
+    case NN: {                                                                                                     \
+        static bool done_ = false;                                                                                 \
+        if (!done_) {                                                                                              \
+            hipError_t e = hipFuncSetAttribute((const void*)convt_quad_lds_kernel<NN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            if (e != hipSuccess) return cgs_set_error(CGS_ELAUNCH, "convt_quad_lds smem attr: %s", hipGetErrorString(e)); \
+            done_ = true;                                                                                          \
+        }                                                                                                          \
+        hipLaunchKernelGGL(convt_quad_lds_kernel<NN>, dim3((unsigned)blocks), dim3(256), smem, s, p);              \
+        break;                                                                                                     \
+    }
+        if (smem <= 160 * 1024 && (size_t)4 * 4 * 64 * L.Cb <= (size_t)2 * PH * PW * 16) {
+            switch (L.Cb) {
+                QUAD_LDS_CASE(1) QUAD_LDS_CASE(2) QUAD_LDS_CASE(3) QUAD_LDS_CASE(4)
+                default: return cgs_set_error(CGS_EINVAL, "convt_quad: N=%d", L.Cb);
+            }
+#undef QUAD_LDS_CASE
+            CGS_CHECK_LAUNCH("convt_quad_lds");
+            cgs_note_kernel("convt_quad_lds_kernel");
+            return CGS_OK;
+        }
     }
     constexpr int MT = 4;
     static bool attr_done = false;

@@ -177,6 +177,16 @@ __global__ void refine_select_scalar_kernel(const float* __restrict__ logit, con
     if (upd) { best_logit[b] = logit[b]; best_step[b] = (float)(step + 1); }
 }
 
+int cgs_refine_select_rows(const float* src, const float* logit, const int32_t* forced, int step_index, float* dst,
+                           const float* best_logit, int B, int F, void* stream) {
+    if (B <= 0 || F <= 0 || B > 65535) return cgs_set_error(CGS_EINVAL, "refine_select_rows: B=%d F=%d", B, F);
+    int bx = cgs_ceil_div(F, 256 * 4);
+    if (bx < 1) bx = 1;
+    hipLaunchKernelGGL(refine_select_copy_kernel, dim3(bx, B), dim3(256), 0, (hipStream_t)stream, src, logit, forced, step_index, dst, best_logit, B, F);
+    CGS_CHECK_LAUNCH("refine_select_rows");
+    return CGS_OK;
+}
+
 int cgs_refine_select(const float* theta, const float* logit, const int32_t* forced, int step_index, float* best_theta,
                       float* best_logit, float* best_step, int B, int F, void* stream) {
     if (B <= 0 || F <= 0 || B > 65535) return cgs_set_error(CGS_EINVAL, "refine_select: B=%d F=%d", B, F);

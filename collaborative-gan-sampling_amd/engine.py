@@ -304,19 +304,22 @@ class RefineEngine:
     # -- the K-step program -------------------------------------------------------------------
     def _program(self, steps, rate, alpha, probabilistic, vmin, vmax):
         th = self.theta
+        render = self.g_tail.stages[-1].out                         # x = G_tail(theta) of the current step
         self.forward_logits(th, self.logit)
         self.default_logit.copy_(self.logit)
         self.best_logit.copy_(self.logit)
         self.best_theta.copy_(th)
+        self.images.copy_(render)
         self.best_step.fill_(1.0)                                   # collaborator.py:60 (starts at 1)
+        forced = self.forced if probabilistic else None
         for i in range(steps):
             g = self.backward_to_feature()
             K.refine_update(th, self.mom, g, rate, alpha, first=(i == 0), vmin=vmin, vmax=vmax)
             self.forward_logits(th, self.logit)                     # the K-th gradient is never formed (Q4)
-            K.refine_select(th, self.logit, self.forced if probabilistic else None, i,
-                            self.best_theta, self.best_logit, self.best_step)
-        img = self.g_tail.forward(self.best_theta)                  # collaborator.py:88
-        self.images.copy_(img)
+            # collaborator.py:88 renders G_tail(best_theta) once more at the end; the very same image was already
+            # rendered in the step that selected it, so it is kept by the same row-select instead (bit-identical)
+            K.refine_select_rows(render, self.logit, forced, i, self.images, self.best_logit)
+            K.refine_select(th, self.logit, forced, i, self.best_theta, self.best_logit, self.best_step)
 
     def refine(self, feature0, steps, rate, method="momentum", mode="deterministic", indices=None,
                vmin=None, vmax=None):

@@ -322,3 +322,11 @@ def refine_select(theta, logit, forced, step_index, best_theta, best_logit, best
     B = theta.shape[0]
     L.call("cgs_refine_select", _ptr(theta), _ptr(logit), _ptr(forced), step_index, _ptr(best_theta), _ptr(best_logit),
            _ptr(best_step), B, theta.numel() // B, _stream())
+
+
+def refine_select_rows(src, logit, forced, step_index, dst, best_logit):
+    """Copy the rows of ``src`` whose sample is selected at this step into ``dst`` (predicate of refine_select;
+    call before it, which updates best_logit)."""
+    B = src.shape[0]
+    L.call("cgs_refine_select_rows", _ptr(src), _ptr(logit), _ptr(forced), step_index, _ptr(dst), _ptr(best_logit),
+           B, src.numel() // B, _stream())

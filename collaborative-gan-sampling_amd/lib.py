@@ -44,6 +44,7 @@ SIGNATURES = {
     "cgs_bce_ones_grad_rowmean": (_i, [_p, _p, _p, _i, _i, _p]),
     "cgs_refine_update": (_i, [_p, _p, _p, _f, _f, _i, _i, _f, _f, _z, _p]),
     "cgs_refine_select": (_i, [_p, _p, _p, _i, _p, _p, _p, _i, _i, _p]),
+    "cgs_refine_select_rows": (_i, [_p, _p, _p, _i, _p, _p, _i, _i, _p]),
 }
 
 _lib = None

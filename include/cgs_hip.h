@@ -157,6 +157,10 @@ int cgs_refine_update(float* theta, float* m, const float* g, float rate, float 
  * forced = the probabilistic-mode index vector (int32, device) or NULL for deterministic mode. */
 int cgs_refine_select(const float* theta, const float* logit, const int32_t* forced, int step_index,
                       float* best_theta, float* best_logit, float* best_step, int B, int F, void* stream);
+/* The row copy of cgs_refine_select alone (same predicate, best_logit is only read): lets a second per-sample
+ * tensor -- e.g. the rendered image of the step -- follow the same selection.  Call it BEFORE cgs_refine_select. */
+int cgs_refine_select_rows(const float* src, const float* logit, const int32_t* forced, int step_index, float* dst,
+                           const float* best_logit, int B, int F, void* stream);
 
 #ifdef __cplusplus
 }

@@ -39,6 +39,9 @@ CONV_CASES = [  # B,H,W,Cin,Cout,k,s
     (130, 8, 8, 64, 128, 5, 2),      # B >= 128, 4x4 grid: pixel-major rows + zero-tap skipping, tiles straddling 2 pixels
     (256, 16, 16, 32, 64, 5, 2),     # pixel-major, 8x8 grid, whole tiles per pixel
     (128, 6, 6, 32, 64, 4, 2),       # pixel-major with 4x4 kernels
+    (3, 64, 64, 3, 64, 5, 2),        # dcgan64 d_h0: bwd-data = LDS-patch quad kernel (32x32 quads)
+    (2, 64, 32, 1, 32, 4, 2),        # 1 channel, 4x4 kernel, 32x16 quads -> global-load quad kernel (Ws % 32 != 0)
+    (2, 16, 64, 2, 16, 5, 2),        # 2 channels, 8x32 quads: LDS-patch kernel with a single 16-channel chunk
 ]
 
 
@@ -80,6 +83,8 @@ DECONV_CASES = [  # B,H,W,Cin,Ho,Wo,Cout,k,s
     (128, 4, 4, 64, 8, 8, 128, 5, 2),     # pixel-major (4x4 class grids), both directions
     (160, 8, 8, 32, 16, 16, 64, 5, 2),    # pixel-major, tiles straddling pixels
     (128, 7, 7, 32, 14, 14, 64, 4, 2),    # pixel-major 7x7 grid, 4x4 kernels
+    (3, 32, 32, 64, 64, 64, 3, 5, 2),     # dcgan64 g_h4: LDS-patch quad kernel
+    (2, 8, 32, 32, 16, 64, 4, 4, 2),      # N = 4, 4x4 kernel, LDS-patch
 ]
 
 
@@ -115,7 +120,8 @@ def test_deconv2d_bwd_data(B, H, W, Cin, Ho, Wo, Cout, k, s):
 
 
 @pytest.mark.parametrize("mode", ["relu_affine", "lrelu", "tanh"])
-@pytest.mark.parametrize("case", [(3, 16, 16, 64, 128, 5, 2), (3, 32, 32, 3, 64, 5, 2), (5, 28, 28, 1, 64, 4, 2), (2, 7, 9, 32, 40, 5, 2)])
+@pytest.mark.parametrize("case", [(3, 16, 16, 64, 128, 5, 2), (3, 32, 32, 3, 64, 5, 2), (5, 28, 28, 1, 64, 4, 2), (2, 7, 9, 32, 40, 5, 2),
+                                  (2, 64, 64, 3, 64, 5, 2)])
 def test_bwd_data_epilogues(case, mode):
     """The folded activation-gradient epilogues of both backward-data directions (and of the quad small-N kernel)."""
     from cgs_amd import kernels as K, lib
