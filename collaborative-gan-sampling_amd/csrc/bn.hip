@@ -8,7 +8,7 @@
 // double and finishes the statistics.  Run-to-run results are bit-identical.
 #include "cgs_internal.h"
 
-#define BN_MAX_BLOCKS 1024
+#define BN_MAX_BLOCKS 512
 
 struct BnGeom {
     int G;               // stage-1 blocks
@@ -19,7 +19,7 @@ static BnGeom bn_geom(int M, int C) {
     // a block covers whole rows; aim at >= 8 rows per block pass and <= BN_MAX_BLOCKS blocks
     BnGeom g;
     int rpb = cgs_ceil_div(M, BN_MAX_BLOCKS);
-    if (rpb < 32) rpb = 32;
+    if (rpb < 16) rpb = 16;
     g.rows_per_block = rpb;
     g.G = cgs_ceil_div(M, rpb);
     (void)C;
@@ -32,43 +32,60 @@ size_t cgs_bn_ws_bytes(int M, int C) {
 }
 
 // MODE 0: a = x, b = x*x.   MODE 1: a = dy', b = dy'*xhat  (dy' = dy * lrelu'(scale*x+shift))
+// 16-byte loads: a thread owns 4 consecutive channels and strides over the block's rows; the row groups of a
+// block are combined through LDS in a fixed order (deterministic).  C % 4 == 0.
 template <int MODE>
 __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                          const float* __restrict__ stat /* [4][C]: mean, invstd, scale, shift */,
                                                          float leak, float* __restrict__ part, int M, int C,
                                                          int rows_per_block) {
-    __shared__ float red[2][256];
+    __shared__ float4 red[2][256];
     const int tid = threadIdx.x;
     const int r0 = blockIdx.x * rows_per_block;
     const int r1 = min(M, r0 + rows_per_block);
-    // threads-per-row: largest power of two <= min(C, 256)
+    const int CQ = C >> 2;
+    // threads-per-row: largest power of two <= min(CQ, 256)
     int tpr = 1;
-    while (tpr * 2 <= C && tpr * 2 <= 256) tpr *= 2;
+    while (tpr * 2 <= CQ && tpr * 2 <= 256) tpr *= 2;
     const int rg = tid / tpr, RG = 256 / tpr, tc = tid - rg * tpr;
-    for (int c0 = 0; c0 < C; c0 += tpr) {
-        const int c = c0 + tc;
-        float sa = 0.f, sb = 0.f;
-        if (c < C) {
-            float mean = 0.f, invstd = 0.f, scale = 0.f, shift = 0.f;
-            if (MODE == 1) { mean = stat[c]; invstd = stat[C + c]; scale = stat[2 * C + c]; shift = stat[3 * C + c]; }
+    for (int q0 = 0; q0 < CQ; q0 += tpr) {
+        const int cq = q0 + tc;
+        float4 sa = make_float4(0.f, 0.f, 0.f, 0.f), sb = sa;
+        if (cq < CQ) {
+            float4 mean = sa, invstd = sa, scale = sa, shift = sa;
+            if (MODE == 1) {
+                mean = ((const float4*)stat)[cq]; invstd = ((const float4*)(stat + C))[cq];
+                scale = ((const float4*)(stat + 2 * C))[cq]; shift = ((const float4*)(stat + 3 * C))[cq];
+            }
             for (int r = r0 + rg; r < r1; r += RG) {
-                const float xv = x[(size_t)r * C + c];
+                const float4 xv = ((const float4*)(x + (size_t)r * C))[cq];
                 if (MODE == 0) {
-                    sa += xv; sb = fmaf(xv, xv, sb);
+                    sa.x += xv.x; sa.y += xv.y; sa.z += xv.z; sa.w += xv.w;
+                    sb.x = fmaf(xv.x, xv.x, sb.x); sb.y = fmaf(xv.y, xv.y, sb.y); sb.z = fmaf(xv.z, xv.z, sb.z); sb.w = fmaf(xv.w, xv.w, sb.w);
                 } else {
-                    const float u = fmaf(xv, scale, shift);
-                    const float d = dy[(size_t)r * C + c] * (u > 0.f ? 1.f : leak);
-                    sa += d; sb = fmaf(d, (xv - mean) * invstd, sb);
+                    const float4 dv = ((const float4*)(dy + (size_t)r * C))[cq];
+#define P1(f)                                                                   \
+                    {                                                           \
+                        const float u = fmaf(xv.f, scale.f, shift.f);           \
+                        const float d = dv.f * (u > 0.f ? 1.f : leak);          \
+                        sa.f += d; sb.f = fmaf(d, (xv.f - mean.f) * invstd.f, sb.f); \
+                    }
+                    P1(x) P1(y) P1(z) P1(w)
+#undef P1
                 }
             }
         }
         red[0][tid] = sa; red[1][tid] = sb;
         __syncthreads();
-        if (rg == 0 && c < C) {
-            float ta = 0.f, tb = 0.f;
-            for (int g = 0; g < RG; ++g) { ta += red[0][g * tpr + tc]; tb += red[1][g * tpr + tc]; }
-            part[((size_t)blockIdx.x * 2 + 0) * C + c] = ta;
-            part[((size_t)blockIdx.x * 2 + 1) * C + c] = tb;
+        if (rg == 0 && cq < CQ) {
+            float4 ta = make_float4(0.f, 0.f, 0.f, 0.f), tb = ta;
+            for (int gq = 0; gq < RG; ++gq) {
+                const float4 a = red[0][gq * tpr + tc], b = red[1][gq * tpr + tc];
+                ta.x += a.x; ta.y += a.y; ta.z += a.z; ta.w += a.w;
+                tb.x += b.x; tb.y += b.y; tb.z += b.z; tb.w += b.w;
+            }
+            ((float4*)(part + ((size_t)blockIdx.x * 2 + 0) * C))[cq] = ta;
+            ((float4*)(part + ((size_t)blockIdx.x * 2 + 1) * C))[cq] = tb;
         }
         __syncthreads();
     }
