@@ -27,6 +27,17 @@ import numpy as np
 import torch
 
 PEAK_FP32_MATRIX_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+# HBM-side bytes per launch from rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in separate runs of this same
+# command, FETCH_SIZE doubled per the gfx950 correction of the guide); collected offline, see profiles/README.md
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "traffic.json")
+
+
+def measured_traffic(kernel):
+    try:
+        with open(TRAFFIC_JSON) as f:
+            return json.load(f).get(kernel, {}).get("hbm_bytes_per_launch_corrected")
+    except (OSError, ValueError):
+        return None
 
 
 def cpu_baseline(arch, refine_steps, rate, budget_batch=64):
@@ -147,7 +158,8 @@ def main():
             ms = sum(a.elapsed_time(b) for a, b in evs)
             ach = fl / ms / 1e9
             out["roofline"] = {"kernel": name, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MATRIX_TFLOPS,
-                               "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MATRIX_TFLOPS, 4), "traffic": None,
+                               "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MATRIX_TFLOPS, 4),
+                               "traffic": measured_traffic(name) if args.arch == "dcgan64" and B == 1024 else None,
                                "launches": len(evs), "avg_launch_us": round(1e3 * ms / len(evs), 2),
                                "flop_per_launch_avg": round(fl / len(evs), 0)}
             out["kernels"] = per

@@ -332,7 +332,7 @@ int cgs_convt_quad_launch(const CgsLayer& L, int B, const float* in, const float
             }
 #undef QUAD_LDS_CASE
             CGS_CHECK_LAUNCH("convt_quad_lds");
-            cgs_note_kernel("convt_quad_lds_kernel");
+            cgs_note_kernel(L.Cb == 3 ? "convt_quad_lds_kernel<3>" : L.Cb == 1 ? "convt_quad_lds_kernel<1>" : L.Cb == 2 ? "convt_quad_lds_kernel<2>" : "convt_quad_lds_kernel<4>");
             return CGS_OK;
         }
     }

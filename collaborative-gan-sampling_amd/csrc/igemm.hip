@@ -88,7 +88,14 @@ __global__ void pack_weights_kernel(IgemmParams p, const float* __restrict__ w, 
         const int k = (int)((i >> 2) / p.Np) * 4 + e;
         float v = 0.f;
         if (k < c.K && n < p.N) {
-            const int t = k / p.Cred, ci = k - t * p.Cred;
+            int t, ci;
+            if ((p.Cred % BK) == 0) {      // K order (32-channel chunk, tap, channel in chunk): see igemm_kernel
+                const int ntaps = c.nty * c.ntx;
+                const int kt = k / BK, chunk = kt / ntaps;
+                t = kt - chunk * ntaps; ci = chunk * BK + (k - kt * BK);
+            } else {
+                t = k / p.Cred; ci = k - t * p.Cred;
+            }
             const int ta = t / c.ntx, tb = t - ta * c.ntx;
             const int tap = (c.ky0 + ta * p.kstep) * kw + (c.kx0 + tb * p.kstep);
             const size_t src = dirT ? ((size_t)tap * Cb + n) * Cs + ci      // reduce over Cs, n indexes Cb
@@ -228,16 +235,20 @@ __global__ __launch_bounds__(64 * NW, 2) void igemm_kernel(IgemmParams p) {
             u_iy = r * p.S + c.dy0; u_ix = cc * p.S + c.dx0;
         }
     }
-    const int chunks_per_tap = VEC ? p.Cred / BK : 1;
-    // first K-chunk >= kt whose tap is inside the image for this tile (nk if none)
+    // VEC K order: K tile kt = chunk * ntaps + tap, i.e. the taps are the INNER loop of each 32-channel chunk.
+    // The 25 (9/6/6/4) taps of a tile re-read one input patch; with the taps inner only a 32-channel slice of the
+    // patch is live at a time, so the working set of an XCD's resident blocks fits its 4 MiB L2 and the tap
+    // re-reads hit there instead of going out to the Infinity Cache / HBM.
+    const int ntaps = c.nty * c.ntx;
+    // first K tile >= kt whose tap is inside the image for this tile (nk if none)
     auto next_chunk = [&](int kt) -> int {
         if (!skip_ok) return kt;
         while (kt < nk) {
-            const int t = kt / chunks_per_tap;
+            const int t = kt % ntaps;
             const int ta = t / c.ntx, tb = t - ta * c.ntx;
             const int iy = u_iy + ta * p.dstep, ix = u_ix + tb * p.dstep;
             if ((unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win) break;
-            kt = (t + 1) * chunks_per_tap;
+            ++kt;
         }
         return kt < nk ? kt : nk;
     };
@@ -250,8 +261,8 @@ __global__ __launch_bounds__(64 * NW, 2) void igemm_kernel(IgemmParams p) {
 #define LOAD_TILE(kt_)                                                                                          \
     do {                                                                                                        \
         if constexpr (VEC) {                                                                                    \
-            const int k0 = (kt_) * BK;                                                                          \
-            const int t = k0 / p.Cred, ci = k0 - t * p.Cred + aq * 4;                                           \
+            const int chunk_ = (kt_) / ntaps, t = (kt_) - chunk_ * ntaps;                                       \
+            const int ci = chunk_ * BK + aq * 4;                                                                \
             const int ta = t / c.ntx, tb = t - ta * c.ntx;                                                      \
             const int dy = ta * p.dstep, dx = tb * p.dstep;                                                     \
             _Pragma("unroll") for (int i = 0; i < AI; ++i) {                                                    \
@@ -521,9 +532,10 @@ static int launch_cfg(const IgemmParams& p, hipStream_t s) {
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rb, p.nclasses), dim3(256), 0, s, p);
         CGS_CHECK_LAUNCH("splitk_reduce");
     }
-    cgs_note_kernel(BN == 128 ? (VEC ? "igemm_kernel<128,128,4,true>" : "igemm_kernel<128,128,4,false>")
-                    : NW == 2 ? (VEC ? "igemm_kernel<128,64,2,true>" : "igemm_kernel<128,64,2,false>")
-                              : (VEC ? "igemm_kernel<128,64,4,true>" : "igemm_kernel<128,64,4,false>"));
+    // the name rocprofv3 prints for this instantiation
+    static char name[64];
+    snprintf(name, sizeof(name), "igemm_kernel<%d, %d, %d, %s, %d>", BM, BN, NW, VEC ? "true" : "false", TBK);
+    cgs_note_kernel(name);
     return CGS_OK;
 }
 
