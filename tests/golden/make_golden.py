@@ -17,6 +17,7 @@ Fixtures:
   g6_rejector.npz      Rejector.sampling accept behaviour over 3 calls
   g7_mh.npz            IndependenceSampler.sampling over 2 calls
   g8_toy.npz           ToyDataset.next_batch draws
+  g9_metrics.npz       utils_sampling 2-D metrics (distance / good rate / KL / JS)
 """
 import os
 import sys
@@ -263,9 +264,34 @@ def g8_toy():
     save("g8_toy.npz", **out)
 
 
+def g9_metrics():
+    """2-D quality metrics of sampling/utils_sampling.py:132-184 on seeded clouds."""
+    import importlib
+    for name in ("matplotlib", "matplotlib.pyplot", "matplotlib.gridspec"):      # plotting deps are irrelevant here
+        if name not in sys.modules:
+            try:
+                importlib.import_module(name)
+            except ImportError:
+                sys.modules[name] = types.ModuleType(name)
+    import utils_sampling as U           # reference sampling/utils_sampling.py
+    rs = np.random.RandomState(3)
+    d = Datasets.ToyDataset(distr="Imbal-8Gaussians", scale=10.0, ratio=0.9)
+    np.random.seed(1)
+    real = d.next_batch(2000)
+    model = np.concatenate([d.next_batch(1500)[::-1] + rs.randn(1500, 2) * 0.05, rs.randn(500, 2) * 4.0])
+    thres = d.std * 4
+    md, good = U.metrics_distance(model, d.centeroids, thres)
+    fv, fa = U.freq_category(model, d.centeroids, thres)
+    save("g9_metrics.npz", real=real, model=model, centeroids=d.centeroids, thres=np.array([thres]),
+         mean_dist=np.array([md]), rate_good=np.array([good]), freqs_valid=fv, freqs_all=fa,
+         kl=np.array([U.metrics_diversity(real, model, d.centeroids, thres)]),
+         js=np.array([U.metrics_distribution(real, model, d.centeroids, thres)]),
+         far_kl=np.array([U.metrics_diversity(real, model + 100.0, d.centeroids, thres)]))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    g1_refiner_cpu(); g2_policy(); g6_rejector(); g7_mh(); g8_toy()
+    g1_refiner_cpu(); g2_policy(); g6_rejector(); g7_mh(); g8_toy(); g9_metrics()
     for K in (1, 5, 20):
         collab_case("mnist", 8, K, "deterministic", 0.1, seed=100 + K)
     collab_case("mnist", 8, 5, "probabilistic", 0.1, seed=7)

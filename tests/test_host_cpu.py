@@ -109,6 +109,59 @@ def test_independence_sampler_exact_vs_reference():
         mh.sampling(np.zeros((2, 1)), np.array([[0.5], [1.5]]))
 
 
+def test_metrics_match_reference():
+    from cgs_amd import metrics as Mx
+    g = load_golden("g9_metrics.npz")
+    thres = float(g["thres"][0])
+    md, good = Mx.metrics_distance(g["model"], g["centeroids"], thres)
+    assert abs(md - g["mean_dist"][0]) < 1e-12 and good == g["rate_good"][0]
+    fv, fa = Mx.freq_category(g["model"], g["centeroids"], thres)
+    np.testing.assert_allclose(fv, g["freqs_valid"], rtol=0, atol=1e-15)
+    np.testing.assert_allclose(fa, g["freqs_all"], rtol=0, atol=1e-15)
+    assert abs(Mx.metrics_diversity(g["real"], g["model"], g["centeroids"], thres) - g["kl"][0]) < 1e-12
+    assert abs(Mx.metrics_distribution(g["real"], g["model"], g["centeroids"], thres) - g["js"][0]) < 1e-12
+    assert abs(Mx.metrics_diversity(g["real"], g["model"] + 100.0, g["centeroids"], thres) - g["far_kl"][0]) < 1e-12
+    rs = np.random.RandomState(0)
+    a = rs.randn(4000, 6)
+    assert Mx.frechet_distance(a, a) < 1e-6
+    assert abs(Mx.frechet_distance(a, a + 2.0) - 6 * 4.0) < 1e-6                 # pure mean shift: |d mu|^2
+
+
+def test_toy_datasets_match_reference():
+    from cgs_amd.datasets import ToyDataset, NoiseDataset
+    g = load_golden("g8_toy.npz")
+    for distr, ratio, B in (("Imbal-8Gaussians", 0.9, 512), ("8Gaussians", 0.5, 100), ("25Gaussians", 0.5, 60)):
+        np.random.seed(2019)
+        d = ToyDataset(distr=distr, scale=10.0, ratio=ratio)
+        np.testing.assert_array_equal(d.next_batch(B), g[distr])
+    np.random.seed(2019)
+    np.testing.assert_array_equal(NoiseDataset().next_batch(33), g["noise"])
+    assert abs(ToyDataset("Imbal-8Gaussians", 10.0, 0.9).std - 0.02 * 10.0 / 1.414) < 1e-15
+
+
+def test_collaborate_fill_loop():
+    """The accept/reject fill loop (nsgan/GAN.py:398-426) with a scripted proposer: exact bookkeeping."""
+    from cgs_amd.evaluate import collaborate
+    from cgs_amd.sampling import IndependenceSampler
+    rs = np.random.RandomState(0)
+    B = 50
+    calls = []
+
+    def propose():
+        calls.append(1)
+        return rs.randn(B, 3).astype(np.float32)
+
+    score = lambda batch: rs.beta(2, 2, size=(len(batch), 1))
+    np.random.seed(1)
+    out, eff = collaborate(propose, score, IndependenceSampler(T=20), 30, 0.5)
+    assert out.shape == (30, 3) and 0 < eff <= 1.0
+    assert abs(eff - (lambda acc, prop: acc / prop)(round(eff * (30 + B * len(calls))), 30 + B * len(calls))) < 1e-12
+    # efficiency cut-off: with min_efficiency = 0.9 the budget (eval_size / 0.9) is exhausted at once -> whole batches are taken
+    calls.clear()
+    out2, eff2 = collaborate(propose, score, IndependenceSampler(T=20), 120, 0.5, min_efficiency=0.9)
+    assert len(calls) >= 2 and out2.shape == (120, 3)
+
+
 def test_c_abi_library_exports_every_declared_symbol():
     from cgs_amd import lib
     header = open(os.path.join(ROOT, "include", "cgs_hip.h")).read()
