@@ -162,6 +162,26 @@ def test_collaborate_fill_loop():
     assert len(calls) >= 2 and out2.shape == (120, 3)
 
 
+def test_checkpoint_roundtrip_and_tf_name_cleaning(tmp_path):
+    from cgs_amd import checkpoint as C
+    P = {k: v.numpy() for k, v in N.init_params("mnist", 3, True).items()}
+    for ext in ("safetensors", "npz"):
+        path = str(tmp_path / f"m.{ext}")
+        C.save(path, P)
+        Q = C.load(path)
+        assert set(Q) == set(P) and all(np.array_equal(P[k], Q[k]) for k in P)
+        assert C.check_against_arch(Q, "mnist")
+    tf_dump = {k + ":0": v for k, v in P.items()}
+    tf_dump["discriminator/d_conv1/w/Adam:0"] = np.zeros(3); tf_dump["beta1_power:0"] = np.zeros(())
+    assert set(C.clean_tf_names(tf_dump)) == set(P)
+    bad = dict(P); bad.pop("generator/g_dc4/w")
+    with pytest.raises(KeyError):
+        C.check_against_arch(bad, "mnist")
+    bad = dict(P); bad["generator/g_dc4/w"] = np.zeros((4, 4, 1, 32), np.float32)
+    with pytest.raises(ValueError):
+        C.check_against_arch(bad, "mnist")
+
+
 def test_c_abi_library_exports_every_declared_symbol():
     from cgs_amd import lib
     header = open(os.path.join(ROOT, "include", "cgs_hip.h")).read()
