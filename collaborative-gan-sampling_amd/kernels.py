@@ -91,7 +91,8 @@ _bn_ws = {}
 
 
 def _bn_workspace(M, C, device):
-    key = (C, device.index)
+    key = (C, device.index, torch.cuda.current_stream(device).cuda_stream)     # one scratch area per stream
+
     ws = _bn_ws.get(key)
     if ws is None:
         ws = torch.empty(L.bn_ws_bytes(M, C) // 4, dtype=torch.float32, device=device)
