@@ -8,7 +8,7 @@
 // double and finishes the statistics.  Run-to-run results are bit-identical.
 #include "cgs_internal.h"
 
-#define BN_MAX_BLOCKS 512
+#define BN_MAX_BLOCKS CGS_BN_MAX_BLOCKS
 
 struct BnGeom {
     int G;               // stage-1 blocks
@@ -212,5 +212,26 @@ int cgs_bn_train_lrelu_bwd_data(const float* dy, const float* x, const float* ga
     const size_t n4 = (size_t)M * C / 4;
     hipLaunchKernelGGL(bn_apply_bwd_kernel, dim3(ew_blocks(n4)), dim3(256), 0, s, dy, x, stat, stat2, leak, dx, n4, C);
     CGS_CHECK_LAUNCH("bn_train_lrelu_bwd_data");
+    return CGS_OK;
+}
+
+
+// bias gradient db[c] (+)= sum_m dy[m][c]: the same two-stage deterministic column reduction
+__global__ void colsum_finalize_kernel(const float* __restrict__ part, int G, int C, float* __restrict__ db, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double a = 0.0;
+    for (int g = 0; g < G; ++g) a += (double)part[((size_t)g * 2 + 0) * C + c];
+    db[c] = accumulate ? db[c] + (float)a : (float)a;
+}
+
+int cgs_bias_grad(const float* dy, float* db, int M, int C, int accumulate, void* ws, size_t ws_bytes, void* stream) {
+    if (M <= 0 || C <= 0 || (C & 3)) return cgs_set_error(CGS_EINVAL, "bias_grad: M=%d C=%d (C must be a multiple of 4)", M, C);
+    if (ws_bytes < cgs_bn_ws_bytes(M, C)) return cgs_set_error(CGS_EWORKSPACE, "bias_grad: workspace %zu < %zu", ws_bytes, cgs_bn_ws_bytes(M, C));
+    hipStream_t s = (hipStream_t)stream;
+    const BnGeom g = bn_geom(M, C);
+    hipLaunchKernelGGL(bn_partial_kernel<0>, dim3(g.G), dim3(256), 0, s, dy, nullptr, nullptr, 0.f, (float*)ws, M, C, g.rows_per_block);
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cgs_ceil_div(C, 128)), dim3(128), 0, s, (const float*)ws, g.G, C, db, accumulate);
+    CGS_CHECK_LAUNCH("bias_grad");
     return CGS_OK;
 }

@@ -39,6 +39,7 @@ struct CgsLayer {
     int Hb, Wb, Cb, Hs, Ws, Cs;
 };
 
+#define CGS_BN_MAX_BLOCKS 512   // stage-1 partial blocks of the per-channel reductions (bn.hip workspace layout)
 #define CGS_BK 32           // K-tile of the implicit GEMM
 #define CGS_MAX_CLASSES 4   // stride <= 2 for the T direction
 

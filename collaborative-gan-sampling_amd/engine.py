@@ -56,6 +56,7 @@ class _Conv(_Stage):
         self.dx = torch.empty((B,) + tuple(in_shape), dtype=torch.float32, device=dev)
 
     def fwd(self, x):
+        self.x_in = x
         return K.conv2d_fwd(x, self.w, self.b, self.s, self.s, self.epi, out=self.out)
 
     def bwd(self, dy):
@@ -94,6 +95,7 @@ class _Linear(_Stage):
         self.dx = torch.empty((B, w.shape[0]), dtype=torch.float32, device=dev)
 
     def fwd(self, x):
+        self.x_in = x
         return K.linear_fwd(x, self.w, self.b, self.epi, out=self.out)
 
     def bwd(self, dy):
@@ -360,6 +362,13 @@ class RefineEngine:
                     self._graphs[key] = g
                 g.replay()
         return self.images, self.default_logit, self.best_logit, self.best_step, self.best_theta
+
+    def refresh_weights(self):
+        """Call after the parameter tensors were updated in place (``shaping.DShaper.step``): re-packs every layer's
+        weights into the existing workspaces (one eager forward + backward), so captured hipGraphs stay valid."""
+        K.WS.invalidate()
+        with torch.cuda.device(self.dev):
+            self.compute_forward_logits_and_grad(self.theta)
 
     def refine_from_z(self, z, steps, rate, **kw):
         """Propose (G head) + refine + render: one whole unit of the BASELINE metric."""

@@ -73,14 +73,22 @@ class _WsCache:
         """``bhw`` = (B, H, W) of the call: sizes the optional split-K slab area behind the packed weights."""
         key = (w.data_ptr(), op, kh, kw, sh, sw, cin, cout, w.device.index, bhw)
         hit = self._d.get(key)
-        if hit is not None and hit[0]() is w and hit[1] == w._version:
-            return hit[2], 1
+        if hit is not None and hit[0]() is w:
+            if hit[1] == w._version:
+                return hit[2], 1
+            self._d[key] = (hit[0], w._version, hit[2])      # stale: re-pack into the SAME buffer (hipGraphs keep its address)
+            return hit[2], 0
         nbytes = L.conv_ws_bytes_for(op, bhw[0], bhw[1], bhw[2], cin, cout, kh, kw, sh, sw)
         ws = torch.empty(max(nbytes, 16) // 4, dtype=torch.float32, device=w.device)
         if len(self._d) > 512:
             self._d.clear()
         self._d[key] = (weakref.ref(w), w._version, ws)
         return ws, 0
+
+    def invalidate(self):
+        """Weights were updated in place by a kernel torch does not see (the Adam step): every packed copy is stale."""
+        for key, (ref, _, ws) in list(self._d.items()):
+            self._d[key] = (ref, -1, ws)
 
     def clear(self):
         self._d.clear()
@@ -331,3 +339,74 @@ def refine_select_rows(src, logit, forced, step_index, dst, best_logit):
     B = src.shape[0]
     L.call("cgs_refine_select_rows", _ptr(src), _ptr(logit), _ptr(forced), step_index, _ptr(dst), _ptr(best_logit),
            B, src.numel() // B, _stream())
+
+
+# ----------------------------------------------------------------------------- D shaping step (weight gradients, Adam)
+_wgrad_ws = {}
+
+
+def _wgrad_workspace(nbytes, device):
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    ws = _wgrad_ws.get(key)
+    if ws is None or ws.numel() * 4 < nbytes:
+        ws = torch.empty(max(nbytes, 16) // 4 + 4, dtype=torch.float32, device=device)
+        _wgrad_ws[key] = ws
+    return ws
+
+
+def conv2d_bwd_weight(x, dy, kh, kw, sh=2, sw=2, out=None, accumulate=False):
+    """dw[kh,kw,Cin,Cout] (+)= weight gradient of conv2d_fwd (Conv2DBackpropFilter)."""
+    _chk(x, "x"); _chk(dy, "dy")
+    B, H, W, Cin = x.shape
+    Cout = dy.shape[3]
+    dw = out if out is not None else torch.empty((kh, kw, Cin, Cout), dtype=torch.float32, device=x.device)
+    ws = _wgrad_workspace(int(L.load().cgs_conv_wgrad_ws_bytes(B, H, W, Cin, Cout, kh, kw, sh, sw)), x.device)
+    L.call("cgs_conv2d_nhwc_bwd_weight", _ptr(x), _ptr(dy), _ptr(dw), B, H, W, Cin, Cout, kh, kw, sh, sw,
+           1 if accumulate else 0, _ptr(ws), ws.numel() * 4, _stream())
+    return dw
+
+
+def linear_bwd_weight(x, dy, out=None, accumulate=False):
+    """dw[in,out] (+)= x^T dy."""
+    _chk(x, "x"); _chk(dy, "dy")
+    B, K = x.shape
+    N = dy.shape[1]
+    dw = out if out is not None else torch.empty((K, N), dtype=torch.float32, device=x.device)
+    ws = _wgrad_workspace(int(L.load().cgs_conv_wgrad_ws_bytes(B, 1, 1, K, N, 1, 1, 1, 1)), x.device)
+    L.call("cgs_linear_bwd_weight", _ptr(x), _ptr(dy), _ptr(dw), B, K, N, 1 if accumulate else 0, _ptr(ws), ws.numel() * 4, _stream())
+    return dw
+
+
+def bias_grad(dy, out=None, accumulate=False):
+    """db[C] (+)= sum of dy over every axis but the last."""
+    _chk(dy, "dy")
+    C = dy.shape[-1]
+    M = dy.numel() // C
+    db = out if out is not None else torch.empty(C, dtype=torch.float32, device=dy.device)
+    if C % 4 != 0:                                   # the single-logit head: a B-element sum
+        s = dy.reshape(M, C).sum(0)
+        db.copy_(db + s if accumulate else s)
+        return db
+    ws = _bn_workspace(M, C, dy.device)
+    L.call("cgs_bias_grad", _ptr(dy), _ptr(db), M, C, 1 if accumulate else 0, _ptr(ws), ws.numel() * 4, _stream())
+    return db
+
+
+def bn_train_param_grads(x, dgamma, dbeta, accumulate=False):
+    """(dgamma, dbeta) (+)= from the statistics the bn_train_lrelu_bwd_data call JUST made on ``x`` left in its workspace."""
+    C = x.shape[-1]
+    M = x.numel() // C
+    ws = _bn_workspace(M, C, x.device)
+    L.call("cgs_bn_train_param_grads", _ptr(ws), M, C, _ptr(dgamma), _ptr(dbeta), 1 if accumulate else 0, _stream())
+
+
+def bce_logits_grad(logits, target, scale, dlogits=None, loss=None):
+    """dlogits = scale*(sigmoid(l) - target); loss[0] = scale * sum BCE(l, target)."""
+    _chk(logits, "logits")
+    dl = dlogits if dlogits is not None else torch.empty_like(logits)
+    L.call("cgs_bce_logits_grad", _ptr(logits), float(target), float(scale), _ptr(dl), _ptr(loss), logits.numel(), _stream())
+    return dl
+
+
+def adam_step(w, g, m, v, lr_t, beta1, beta2, eps):
+    L.call("cgs_adam_step", _ptr(w), _ptr(g), _ptr(m), _ptr(v), float(lr_t), float(beta1), float(beta2), float(eps), w.numel(), _stream())

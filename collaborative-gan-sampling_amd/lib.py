@@ -45,6 +45,13 @@ SIGNATURES = {
     "cgs_refine_update": (_i, [_p, _p, _p, _f, _f, _i, _i, _f, _f, _z, _p]),
     "cgs_refine_select": (_i, [_p, _p, _p, _i, _p, _p, _p, _i, _i, _p]),
     "cgs_refine_select_rows": (_i, [_p, _p, _p, _i, _p, _p, _i, _i, _p]),
+    "cgs_conv_wgrad_ws_bytes": (_z, [_i] * 9),
+    "cgs_conv2d_nhwc_bwd_weight": (_i, [_p] * 3 + [_i] * 9 + [_i, _p, _z, _p]),
+    "cgs_linear_bwd_weight": (_i, [_p] * 3 + [_i] * 3 + [_i, _p, _z, _p]),
+    "cgs_bias_grad": (_i, [_p, _p, _i, _i, _i, _p, _z, _p]),
+    "cgs_bn_train_param_grads": (_i, [_p, _i, _i, _p, _p, _i, _p]),
+    "cgs_bce_logits_grad": (_i, [_p, _f, _f, _p, _p, _i, _p]),
+    "cgs_adam_step": (_i, [_p, _p, _p, _p, _f, _f, _f, _f, _z, _p]),
 }
 
 _lib = None

@@ -162,6 +162,29 @@ int cgs_refine_select(const float* theta, const float* logit, const int32_t* for
 int cgs_refine_select_rows(const float* src, const float* logit, const int32_t* forced, int step_index, float* dst,
                            const float* best_logit, int B, int F, void* stream);
 
+/* ---- discriminator shaping step (the caller after the refinement path: nsgan/GAN.py:270-272, 126-146) ----------
+ * Weight gradients of D's layers, the BCE seed with 0/1 targets, and the Adam update.  NOT part of the frozen-weight
+ * refinement loop; provided so the method's only training step (shape D on refined samples) runs on the same ABI. */
+/* dw[kh,kw,Cin,Cout] (+)= d/dw of conv2d_nhwc_fwd(x, w) contracted with dy[B,Ho,Wo,Cout] (Conv2DBackpropFilter). */
+size_t cgs_conv_wgrad_ws_bytes(int B, int H, int W, int Cin, int Cout, int kh, int kw, int sh, int sw);
+int cgs_conv2d_nhwc_bwd_weight(const float* x, const float* dy, float* dw, int B, int H, int W, int Cin, int Cout,
+                               int kh, int kw, int sh, int sw, int accumulate, void* ws, size_t ws_bytes, void* stream);
+/* dw[in,out] (+)= x[B,in]^T dy[B,out]   (ws: cgs_conv_wgrad_ws_bytes(B,1,1,in,out,1,1,1,1)). */
+int cgs_linear_bwd_weight(const float* x, const float* dy, float* dw, int B, int in, int out, int accumulate,
+                          void* ws, size_t ws_bytes, void* stream);
+/* db[C] (+)= column sums of dy[M,C]   (ws: cgs_bn_ws_bytes(M, C)). */
+int cgs_bias_grad(const float* dy, float* db, int M, int C, int accumulate, void* ws, size_t ws_bytes, void* stream);
+/* dgamma, dbeta (+)= from the statistics the immediately preceding cgs_bn_train_lrelu_bwd_data call left in ITS
+ * workspace `bwd_ws` (same M, C). */
+int cgs_bn_train_param_grads(const void* bwd_ws, int M, int C, float* dgamma, float* dbeta, int accumulate, void* stream);
+/* dlogits[i] = scale*(sigmoid(logits[i]) - target); loss_sum[0] = scale * sum_i BCE(logits[i], target) (may be NULL).
+ * tf.nn.sigmoid_cross_entropy_with_logits + reduce_mean (nsgan/GAN.py:126-131) with scale = 1/n. */
+int cgs_bce_logits_grad(const float* logits, float target, float scale, float* dlogits, float* loss_sum, int n, void* stream);
+/* Adam (tf.train.AdamOptimizer semantics, nsgan/GAN.py:141-146): m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
+ * w -= lr_t * m / (sqrt(v) + eps), lr_t = lr*sqrt(1-b2^t)/(1-b1^t) supplied by the caller. */
+int cgs_adam_step(float* w, const float* g, float* m, float* v, float lr_t, float beta1, float beta2, float eps,
+                  size_t n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -185,3 +185,24 @@ def test_full_size_properties(arch, B, K):
     _, _, _, osp, ofp = eng.refine(f0, K, 0.1, mode="probabilistic", indices=idx0)
     lm, grad = eng.compute_forward_logits_and_grad(f0)
     assert (osp == 1).all() and torch.allclose(ofp, f0 - 0.1 * grad, rtol=0, atol=1e-6)
+
+
+def test_collaborative_fill_loop_on_device():
+    """refine -> D-score -> MH accept -> fill (nsgan/GAN.py:398-426) driven by the device engine."""
+    from cgs_amd.engine import RefineEngine
+    from cgs_amd.evaluate import collaborate, engine_proposer, MIN_EFFICIENCY
+    from cgs_amd.nets import to_device
+    from cgs_amd.sampling import IndependenceSampler
+    d = dev()
+    P = N.init_params("mnist", 2019, True)
+    eng = RefineEngine("mnist", to_device(P, d), 32, d)
+    propose, score = engine_proposer(eng, 3, 0.1, rng=np.random.RandomState(5))
+    batch = propose()
+    assert batch.shape == (32, 28, 28, 1) and np.abs(batch).max() <= 1.0
+    sig = score(batch)
+    with torch.no_grad():
+        want = torch.sigmoid(N.discriminator("mnist", P, torch.from_numpy(batch))).numpy()
+    np.testing.assert_allclose(sig, want, rtol=0, atol=2e-5)                     # scoring = D on batch statistics
+    np.random.seed(3)
+    out, eff = collaborate(propose, score, IndependenceSampler(T=20), 40, float(sig.mean()), min_efficiency=MIN_EFFICIENCY)
+    assert out.shape == (40, 28, 28, 1) and 0.0 < eff <= 1.0 and np.isfinite(out).all()

@@ -1,0 +1,130 @@
+"""the discriminator shaping step (weight gradients + Adam) against torch autograd on the CPU oracle."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import nets_ref as N
+from oracle import ops_ref as R
+
+
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def rnd(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).float()
+
+
+def close(got, want, tol):
+    got, want = got.detach().cpu().double(), want.detach().cpu().double()
+    err = (got - want).abs().max().item()
+    ref = want.abs().max().item() + 1e-30
+    assert err <= tol * ref, f"max|delta|={err:.3e} vs max|ref|={ref:.3e}"
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,s", [(3, 16, 16, 64, 128, 5, 2), (4, 28, 28, 1, 64, 4, 2), (2, 32, 32, 3, 64, 5, 2),
+                                               (2, 7, 9, 32, 40, 5, 2), (40, 8, 8, 128, 96, 5, 2), (2, 6, 5, 16, 8, 3, 1)])
+def test_conv_weight_and_bias_grads(B, H, W, Cin, Cout, k, s):
+    from cgs_amd import kernels as K
+    x = rnd((B, H, W, Cin), 1)
+    w = rnd((k, k, Cin, Cout), 2, 0.05).requires_grad_(True)
+    b = torch.zeros(Cout, requires_grad=True)
+    y = R.conv2d(x, w, b, s, s)
+    dy = rnd(tuple(y.shape), 3)
+    (y * dy).sum().backward()
+    d = dev()
+    gw = K.conv2d_bwd_weight(x.to(d), dy.to(d), k, k, s, s)
+    close(gw, w.grad, 3e-5)
+    gw2 = K.conv2d_bwd_weight(x.to(d), dy.to(d), k, k, s, s, out=gw.clone(), accumulate=True)
+    close(gw2, 2 * w.grad, 3e-5)
+    if Cout % 4 == 0:
+        close(K.bias_grad(dy.to(d)), b.grad, 1e-5)
+
+
+@pytest.mark.parametrize("B,Kin,Nout", [(64, 6272, 1024), (33, 1024, 1), (16, 100, 40)])
+def test_linear_weight_grad(B, Kin, Nout):
+    from cgs_amd import kernels as K
+    x, dy = rnd((B, Kin), 1), rnd((B, Nout), 2)
+    close(K.linear_bwd_weight(x.to(dev()), dy.to(dev())), x.t() @ dy, 3e-5)
+
+
+@pytest.mark.parametrize("arch,B", [("mnist", 16), ("dcgan32", 8)])
+def test_d_shaping_step_matches_autograd(arch, B):
+    from cgs_amd.nets import to_device
+    from cgs_amd.shaping import DShaper
+    P = N.init_params(arch, 2019, True)
+    real = rnd((B,) + tuple(N.ARCHS[arch]["img"]), 1).clamp(-1, 1)
+    fake = torch.tanh(rnd((B,) + tuple(N.ARCHS[arch]["img"]), 2))
+    Pg = {k: (v.clone().requires_grad_(True) if k.startswith("discriminator/") and "moving" not in k else v) for k, v in P.items()}
+    bce = torch.nn.functional.binary_cross_entropy_with_logits
+    lr = N.discriminator(arch, Pg, real)
+    lf = N.discriminator(arch, Pg, fake)
+    loss = bce(lr, torch.ones_like(lr)) + bce(lf, torch.zeros_like(lf))                 # nsgan/GAN.py:126-131
+    loss.backward()
+    d = dev()
+    Pd = to_device(P, d)
+    sh = DShaper(arch, Pd, B, d, learning_rate=1e-3)
+    got_loss = sh.loss_and_grads(real.to(d), fake.to(d))
+    assert abs(got_loss.item() - loss.item()) < 1e-5 * max(1.0, abs(loss.item()))
+    names = [k for k in Pg if Pg[k].requires_grad]
+    checked = 0
+    for st in sh.tape.stages:
+        for attr in ("w", "b", "gamma", "beta"):
+            if hasattr(st, "g_" + attr):
+                p = getattr(st, attr)
+                name = [k for k in names if Pd[k] is p][0]
+                g_ref = Pg[name].grad
+                tol = 2e-4
+                if float(g_ref.abs().max()) < 1e-6:                    # bias in front of a batch norm: exactly-zero gradient
+                    assert float(getattr(st, "g_" + attr).abs().max()) < 1e-4
+                else:
+                    close(getattr(st, "g_" + attr), g_ref, tol)
+                checked += 1
+    assert checked == len(names)
+    # one Adam step (tf.train.AdamOptimizer formula) on a copy of the weights
+    before = {k: Pd[k].clone() for k in names}
+    sh.step(real.to(d), fake.to(d))
+    lr_t = 1e-3 * math.sqrt(1 - 0.999) / (1 - 0.5)
+    for k in names:
+        g = Pg[k].grad
+        want = before[k].cpu() - lr_t * (0.5 * g) / (torch.sqrt(0.001 * g * g) + 1e-8)
+        tol = 5e-3 if float(g.abs().max()) > 1e-6 else 1.0
+        if tol < 1.0:
+            close(Pd[k], want, tol)
+    # the refiner sees the shaped weights
+    from cgs_amd.engine import RefineEngine
+    eng = RefineEngine(arch, Pd, B, d)
+    z = rnd((B, N.ARCHS[arch]["z_dim"]), 5).clamp(-1, 1).to(d)
+    f0 = eng.input_to_feature(z).clone()
+    l0 = eng.compute_forward_logits_and_grad(f0)[0].clone()
+    sh.step(real.to(d), fake.to(d))
+    eng.refresh_weights()
+    l1 = eng.compute_forward_logits_and_grad(f0)[0].clone()
+    assert not torch.equal(l0, l1)
+    Pnow = {k: v.cpu() for k, v in Pd.items()}
+    with torch.no_grad():
+        want = N.discriminator(arch, Pnow, N.feature_to_data(arch, Pnow, f0.cpu())).reshape(B)
+    close(l1, want, 2e-4)
+
+
+def test_shape_step_loop_runs_and_lowers_d_loss_on_refined():
+    """A few shaping iterations (refine probabilistically -> D Adam step): D learns to score the refined batch lower."""
+    from cgs_amd.engine import RefineEngine
+    from cgs_amd.nets import to_device
+    from cgs_amd.shaping import DShaper, shape_step
+    d = dev()
+    B, arch = 16, "mnist"
+    Pd = to_device(N.init_params(arch, 2019, True), d)
+    eng = RefineEngine(arch, Pd, B, d)
+    sh = DShaper(arch, Pd, B, d, learning_rate=2e-3)
+    real = rnd((B, 28, 28, 1), 1).clamp(-1, 1).to(d)
+    z = rnd((B, 62), 2).clamp(-1, 1).to(d)
+    np.random.seed(0)
+    losses = [float(shape_step(eng, sh, z, real, 3, 0.1)) for _ in range(6)]
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]
