@@ -107,14 +107,15 @@ def main():
     n_batches = args.steps + args.warmup
     rs = np.random.RandomState(2019 + rank)                            # rank-offset seed: disjoint z shards
     z = torch.from_numpy(rs.uniform(-1, 1, (n_batches, B, A["z_dim"])).astype(np.float32)).to(dev)
-    pool = torch.empty((world * B,) + tuple(A["img"]), dtype=torch.float32, device=dev) if use_dist else None
+    pools = [torch.empty((world * B,) + tuple(A["img"]), dtype=torch.float32, device=dev) if use_dist else None
+             for _ in engines]                                           # one node-wide pool buffer per batch in flight
 
     def step(i):
         e, st = engines[i % len(engines)], streams[i % len(engines)]
         with torch.cuda.stream(st):
             img = e.refine_from_z(z[i], Ksteps, args.rate)[0]
             if use_dist:
-                dist.all_gather_into_tensor(pool, img)                 # RCCL over xGMI: the refined sample pool
+                dist.all_gather_into_tensor(pools[i % len(engines)], img)      # RCCL over xGMI: the refined sample pool
         return img
 
     for i in range(args.warmup):
