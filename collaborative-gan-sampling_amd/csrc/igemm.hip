@@ -23,6 +23,7 @@
 // conflict-free).
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "cgs_internal.h"
 
@@ -136,6 +137,28 @@ __device__ __forceinline__ float epilogue_apply(float v, int mode, float a, floa
     }
 }
 
+// Row pass of the wide epilogue for ONE epilogue mode (compile-time): branch-free inner loops and a compact
+// instruction footprint.  (With the mode as a run-time switch inside the unrolled loops the epilogue was ~21k lines
+// of ISA with 1.6k branches and took 20 us per block, 10 % of the block's life.)
+template <int EPI, int ROWS, int RPP, int LDE>
+__device__ __forceinline__ void epilogue_rows(const IgemmParams& p, const float* E, const int* rowpix_tile, int rsub, int c4,
+                                              int n, f32x4 bias, f32x4 ea, f32x4 eb) {
+#pragma unroll
+    for (int it = 0; it < ROWS / RPP; ++it) {
+        const int lrow = it * RPP + rsub;
+        const int pix = rowpix_tile[lrow];
+        if (pix < 0) continue;
+        const f32x4 v = *(const f32x4*)(E + lrow * LDE + c4);
+        const size_t o = (size_t)pix * p.N + n;
+        f32x4 aux = {0.f, 0.f, 0.f, 0.f};
+        if (EPI >= CGS_EPI_RELU_BWD_AFFINE) aux = *(const f32x4*)(p.ep_aux + o);
+        f32x4 y;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] = epilogue_apply(v[e] + bias[e], EPI, ea[e], eb[e], aux[e]);
+        *(f32x4*)(p.out + o) = y;
+    }
+}
+
 // NW waves per block, arranged 2 (M) x NW/2 (N); wave tile (BM/2) x (BN/(NW/2)).
 template <int BM, int BN, int NW, bool VEC, int TBK>
 __global__ __launch_bounds__(64 * NW, 2) void igemm_kernel(IgemmParams p) {
@@ -150,7 +173,9 @@ __global__ __launch_bounds__(64 * NW, 2) void igemm_kernel(IgemmParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                              // [2][BM][LDA]
     float* Bs = smem + 2 * BM * LDA;               // [2][BK/4][BN][4]
-    int* rowpix = (int*)(Bs + 2 * BK * BN);        // [BM] output pixel index of each tile row, -1 = out of range
+    constexpr int KLOOP_F = 2 * BM * LDA + 2 * BK * BN;              // floats of the K-loop double buffers
+    constexpr int STAGE_F = NW * (BM / 2) * (BN / WN + 4);            // floats of the epilogue staging tiles
+    int* rowpix = (int*)(smem + (KLOOP_F > STAGE_F ? KLOOP_F : STAGE_F));   // [BM] output pixel of each tile row, -1 = out of range
 
     // block id -> (m-tile, n-tile); class = blockIdx.y (heaviest class first).  An XCD-aware id remap (contiguous
     // tile runs per XCD, classes interleaved) was measured: within +-0.5 % for the remap alone, 25-50 % SLOWER with
@@ -172,6 +197,11 @@ __global__ __launch_bounds__(64 * NW, 2) void igemm_kernel(IgemmParams p) {
     const int m0 = mb * BM, n0 = nb * BN;
 
     const int tid = threadIdx.x;
+#ifdef CGS_DIAG_STAMPS      // diagnostic build only (tools/clock_probe.py): per-block timeline stamps into the workspace tail
+    const bool stamp = p.slab != nullptr && p.splitk == 1 && tid == 0;
+    unsigned long long sr_in = 0;
+    if (stamp) sr_in = __builtin_amdgcn_s_memrealtime();
+#endif
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave - wm * WN;
     const int h = lane >> 5, j = lane & 31;
@@ -314,6 +344,10 @@ __global__ __launch_bounds__(64 * NW, 2) void igemm_kernel(IgemmParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
 
+#ifdef CGS_DIAG_STAMPS
+    unsigned long long sr_loop0 = 0;
+    if (stamp) sr_loop0 = __builtin_amdgcn_s_memrealtime();
+#endif
     int kt = next_chunk(kbeg);
     if (kt < nk) {
         LOAD_TILE(kt);
@@ -321,34 +355,46 @@ __global__ __launch_bounds__(64 * NW, 2) void igemm_kernel(IgemmParams p) {
     }
     __syncthreads();
 
+    // One basic block per K tile (no branches inside): the next tile's global loads are issued after the first MFMA
+    // group and staged to LDS before the last one, so the scheduler can slot them into the shadow of the 64-cycle MFMAs
+    // instead of running them as a separate phase (the two blocks resident on a CU run in lockstep, so a separate
+    // non-MFMA phase of one coincides with the other's and the matrix pipe idles).  After the last tile the "next"
+    // tile is a harmless reload of that last tile into the dead buffer.
+#define MFMA_GROUP(jj_)                                                                                         \
+    do {                                                                                                        \
+        const int kq = 2 * (jj_) + h;                                                                           \
+        f32x4 fa[TM], fb[TN];                                                                                   \
+        _Pragma("unroll") for (int tm = 0; tm < TM; ++tm) fa[tm] = *(const f32x4*)(a + tm * 32 * LDA + kq * 4); \
+        _Pragma("unroll") for (int tn = 0; tn < TN; ++tn) fb[tn] = *(const f32x4*)(b + (kq * BN + tn * 32) * 4); \
+        _Pragma("unroll") for (int tm = 0; tm < TM; ++tm)                                                       \
+            _Pragma("unroll") for (int tn = 0; tn < TN; ++tn) {                                                 \
+                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[tm].x, fb[tn].x, acc[tm][tn], 0, 0, 0);   \
+                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[tm].y, fb[tn].y, acc[tm][tn], 0, 0, 0);   \
+                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[tm].z, fb[tn].z, acc[tm][tn], 0, 0, 0);   \
+                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[tm].w, fb[tn].w, acc[tm][tn], 0, 0, 0);   \
+            }                                                                                                   \
+    } while (0)
+    constexpr int NG = BK / 8;                       // MFMA groups per tile
     for (int buf = 0; kt < nk; buf ^= 1) {
         const int kn = next_chunk(kt + 1);
-        if (kn < nk) LOAD_TILE(kn);                  // global loads in flight under the MFMA block
+        const int kl = kn < nk ? kn : kt;            // tile to prefetch (the current one again after the last)
         const float* a = As + buf * BM * LDA + (wm * (BM / 2) + j) * LDA;
         const float* b = Bs + buf * BK * BN + (wn * (BN / WN) + j) * 4;
+        MFMA_GROUP(0);
+        LOAD_TILE(kl);
 #pragma unroll
-        for (int jj = 0; jj < BK / 8; ++jj) {
-            const int kq = 2 * jj + h;
-            f32x4 fa[TM], fb[TN];
-#pragma unroll
-            for (int tm = 0; tm < TM; ++tm) fa[tm] = *(const f32x4*)(a + tm * 32 * LDA + kq * 4);
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn) fb[tn] = *(const f32x4*)(b + (kq * BN + tn * 32) * 4);
-#pragma unroll
-            for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-                for (int tn = 0; tn < TN; ++tn) {
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[tm].x, fb[tn].x, acc[tm][tn], 0, 0, 0);
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[tm].y, fb[tn].y, acc[tm][tn], 0, 0, 0);
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[tm].z, fb[tn].z, acc[tm][tn], 0, 0, 0);
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[tm].w, fb[tn].w, acc[tm][tn], 0, 0, 0);
-                }
-        }
-        if (kn < nk) STORE_TILE(buf ^ 1);
+        for (int jj = 1; jj < NG - 1; ++jj) MFMA_GROUP(jj);
+        STORE_TILE(buf ^ 1);
+        if (NG > 1) MFMA_GROUP(NG - 1);
         __syncthreads();
         kt = kn;
     }
+#undef MFMA_GROUP
 
+#ifdef CGS_DIAG_STAMPS
+    unsigned long long sr_loop1 = 0;
+    if (stamp) sr_loop1 = __builtin_amdgcn_s_memrealtime();
+#endif
 #undef LOAD_TILE
 #undef STORE_TILE
 #undef DECODE_ROW
@@ -375,54 +421,48 @@ __global__ __launch_bounds__(64 * NW, 2) void igemm_kernel(IgemmParams p) {
         // the aux loads / output stores are 16 bytes per lane, 256 contiguous bytes per 16 lanes: 4x fewer
         // store (and aux load) instructions than the per-register scalar form below.
         constexpr int LDE = WTN + 4;
-        static_assert((size_t)NW * 32 * LDE <= (size_t)(2 * BM * LDA + 2 * BK * BN), "epilogue staging must fit the K-loop LDS");
-        float* E = smem + wave * 32 * LDE;        // this wave's [32][LDE] staging tile (one 32-row MFMA tile at a time)
+        float* E = smem + wave * (BM / 2) * LDE;  // this wave's [BM/2][LDE] staging tile (launch_cfg sizes the LDS for it)
         constexpr int LPR = WTN / 4;              // lanes per row (16 for 64 columns, 8 for 32)
         constexpr int RPP = 64 / LPR;             // rows per pass
         const int c4 = (lane % LPR) * 4, rsub = lane / LPR;
         const int n = n0 + wn * WTN + c4;
-        f32x4 bias = {0.f, 0.f, 0.f, 0.f}, ea = {1.f, 1.f, 1.f, 1.f}, eb = {0.f, 0.f, 0.f, 0.f};
-        if (n < p.N) {
-            if (p.bias) bias = *(const f32x4*)(p.bias + n);
-            if (p.epilogue == CGS_EPI_AFFINE_RELU) { ea = *(const f32x4*)(p.ep_a + n); eb = *(const f32x4*)(p.ep_b + n); }
-            if (p.epilogue == CGS_EPI_RELU_BWD_AFFINE) ea = *(const f32x4*)(p.ep_a + n);
-        }
-        const bool use_aux = p.epilogue >= CGS_EPI_RELU_BWD_AFFINE;
+        // all waves are past the loop's final barrier: the K-loop buffers are dead (rowpix lives behind the staging area)
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm) {
-            // all waves are past the loop's final barrier (K-loop buffers are dead); rowpix lives behind them
+        for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    E[((r & 3) + 8 * (r >> 2) + 4 * h) * LDE + tn * 32 + j] = acc[tm][tn][r];
-            // the same wave reads what it wrote: LDS ops of one wave complete in order; only the compiler must keep it
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            if (n < p.N) {
-#pragma unroll
-                for (int it = 0; it < 32 / RPP; ++it) {
-                    const int lrow = it * RPP + rsub;
-                    const int pix = rowpix[wm * (BM / 2) + tm * 32 + lrow];
-                    if (pix < 0) continue;
-                    const f32x4 v = *(const f32x4*)(E + lrow * LDE + c4);
-                    const size_t o = (size_t)pix * p.N + n;
-                    f32x4 aux = {0.f, 0.f, 0.f, 0.f};
-                    if (use_aux) aux = *(const f32x4*)(p.ep_aux + o);
-                    f32x4 y;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) y[e] = epilogue_apply(v[e] + bias[e], p.epilogue, ea[e], eb[e], aux[e]);
-                    *(f32x4*)(p.out + o) = y;
-                }
+                    E[(tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * LDE + tn * 32 + j] = acc[tm][tn][r];
+        // the same wave reads what it wrote: LDS ops of one wave complete in order; only the compiler must keep it
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (n < p.N) {
+            f32x4 bias = {0.f, 0.f, 0.f, 0.f}, ea = {1.f, 1.f, 1.f, 1.f}, eb = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias) bias = *(const f32x4*)(p.bias + n);
+            if (p.epilogue == CGS_EPI_AFFINE_RELU) { ea = *(const f32x4*)(p.ep_a + n); eb = *(const f32x4*)(p.ep_b + n); }
+            if (p.epilogue == CGS_EPI_RELU_BWD_AFFINE) ea = *(const f32x4*)(p.ep_a + n);
+            const int* rp = rowpix + wm * (BM / 2);
+            switch (p.epilogue) {     // wave-uniform; each case is one compact branch-free row loop
+                case CGS_EPI_NONE: epilogue_rows<CGS_EPI_NONE, BM / 2, RPP, LDE>(p, E, rp, rsub, c4, n, bias, ea, eb); break;
+                case CGS_EPI_LRELU: epilogue_rows<CGS_EPI_LRELU, BM / 2, RPP, LDE>(p, E, rp, rsub, c4, n, bias, ea, eb); break;
+                case CGS_EPI_AFFINE_RELU: epilogue_rows<CGS_EPI_AFFINE_RELU, BM / 2, RPP, LDE>(p, E, rp, rsub, c4, n, bias, ea, eb); break;
+                case CGS_EPI_TANH: epilogue_rows<CGS_EPI_TANH, BM / 2, RPP, LDE>(p, E, rp, rsub, c4, n, bias, ea, eb); break;
+                case CGS_EPI_RELU_BWD_AFFINE: epilogue_rows<CGS_EPI_RELU_BWD_AFFINE, BM / 2, RPP, LDE>(p, E, rp, rsub, c4, n, bias, ea, eb); break;
+                case CGS_EPI_LRELU_BWD: epilogue_rows<CGS_EPI_LRELU_BWD, BM / 2, RPP, LDE>(p, E, rp, rsub, c4, n, bias, ea, eb); break;
+                default: epilogue_rows<CGS_EPI_TANH_BWD, BM / 2, RPP, LDE>(p, E, rp, rsub, c4, n, bias, ea, eb); break;
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
+#ifdef CGS_DIAG_STAMPS
+        if (stamp) {
+            unsigned long long* dbg = (unsigned long long*)p.slab + (size_t)blockIdx.x * 4;
+            dbg[0] = sr_in; dbg[1] = sr_loop0; dbg[2] = sr_loop1; dbg[3] = __builtin_amdgcn_s_memrealtime();
+        }
+#endif
         return;
     }
-#pragma unroll
+#pragma unroll     // (must stay fully unrolled: a run-time tn would index the accumulator array and push it to scratch)
     for (int tn = 0; tn < TN; ++tn) {
         const int n = n0 + wn * WTN + tn * 32 + j;
         if (n >= p.N) continue;
@@ -507,7 +547,8 @@ size_t cgs_igemm_splitk_bytes(const IgemmParams& p) {
 
 template <int BM, int BN, int NW, bool VEC, int TBK>
 static int launch_cfg(const IgemmParams& p, hipStream_t s) {
-    constexpr size_t smem = (size_t)(2 * BM * (TBK + 4) + 2 * TBK * BN) * sizeof(float) + BM * sizeof(int);
+    constexpr size_t kloop_f = (size_t)2 * BM * (TBK + 4) + 2 * TBK * BN, stage_f = (size_t)NW * (BM / 2) * (BN / (NW / 2) + 4);
+    constexpr size_t smem = (kloop_f > stage_f ? kloop_f : stage_f) * sizeof(float) + BM * sizeof(int);
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void*)igemm_kernel<BM, BN, NW, VEC, TBK>,
@@ -542,6 +583,9 @@ static int launch_cfg(const IgemmParams& p, hipStream_t s) {
 int cgs_igemm_launch(const IgemmParams& p_in, void* slab, size_t slab_bytes, hipStream_t s) {
     IgemmParams p = p_in;
     p.splitk = 1; p.slab = nullptr;
+#ifdef CGS_DIAG_STAMPS
+    if (getenv("CGS_STAMP") && slab && slab_bytes >= 64) p.slab = (float*)slab;
+#endif
     // pixel-major row order pays when the base-pixel grid is small (many padded taps per pixel, and the whole
     // input stays in the 256 MiB Infinity Cache for the cross-tile re-reads) and the batch fills whole tiles
     int maxRC = 0;
