@@ -264,3 +264,33 @@ def test_errors_are_loud():
         K.conv2d_fwd(torch.zeros(1, 4, 4, 8, device=d), torch.zeros(5, 5, 4, 8, device=d), None)   # Cin mismatch
     with pytest.raises(lib.CgsError):
         K.deconv2d_fwd(torch.zeros(1, 4, 4, 8, device=d), torch.zeros(5, 5, 8, 8, device=d), None, (9, 9))  # bad SAME geometry
+
+
+def test_edge_shapes_and_argument_errors():
+    """Ragged / degenerate cases through the C ABI: batch 1, 1x1 spatial, kernel smaller than stride (parity classes
+    with no tap get bias only), misaligned pointers, too-small workspace."""
+    from cgs_amd import kernels as K, lib
+    d = dev()
+    # B = 1, 1x1 input
+    x, w, b = rnd((1, 1, 1, 32), 1), rnd((5, 5, 32, 64), 2, 0.05), rnd((64,), 3)
+    close(K.conv2d_fwd(x.to(d), w.to(d), b.to(d)), R.conv2d(x, w, b, 2, 2), 2e-5)
+    # 1x1 kernel with stride 2 in the transposed direction: three of the four parity classes have no tap -> bias only
+    xs, wt, bt = rnd((2, 4, 4, 32), 4), rnd((1, 1, 64, 32), 5, 0.1), rnd((64,), 6)
+    close(K.deconv2d_fwd(xs.to(d), wt.to(d), bt.to(d), (8, 8)), R.deconv2d(xs, wt, bt, (2, 8, 8, 64), 2, 2), 2e-5)
+    # single output channel linear with odd K, batch 1
+    xl, wl, bl = rnd((1, 77), 7), rnd((77, 1), 8), rnd((1,), 9)
+    close(K.linear_fwd(xl.to(d), wl.to(d), bl.to(d)), R.linear(xl, wl, bl), 2e-5)
+    # misaligned activation pointer is rejected, not mis-read
+    buf = torch.zeros(1 * 8 * 8 * 32 + 1, device=d)
+    with pytest.raises(lib.CgsError):
+        K.conv2d_fwd(buf[1:].view(1, 8, 8, 32), w.to(d), b.to(d))
+    # workspace too small is an error code, not a crash
+    xd, wd = torch.zeros(1, 8, 8, 32, device=d), w.to(d)
+    yd = torch.empty(1, 4, 4, 64, device=d)
+    small = torch.empty(16, device=d)
+    rc = lib.load().cgs_conv2d_nhwc_fwd(xd.data_ptr(), wd.data_ptr(), None, yd.data_ptr(), 1, 8, 8, 32, 64, 5, 5, 2, 2, 0, None, None,
+                                       small.data_ptr(), small.numel() * 4, 0, None)
+    assert rc == lib.EWORKSPACE and b"workspace" in lib.load().cgs_last_error()
+    rc = lib.load().cgs_conv2d_nhwc_fwd(xd.data_ptr(), wd.data_ptr(), None, yd.data_ptr(), 0, 8, 8, 32, 64, 5, 5, 2, 2, 0, None, None,
+                                       small.data_ptr(), small.numel() * 4, 0, None)
+    assert rc == lib.EINVAL
