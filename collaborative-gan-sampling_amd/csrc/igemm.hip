@@ -177,7 +177,9 @@ __global__ __launch_bounds__(64 * NW, 2) void igemm_kernel(IgemmParams p) {
     constexpr int STAGE_F = NW * (BM / 2) * (BN / WN + 4);            // floats of the epilogue staging tiles
     int* rowpix = (int*)(smem + (KLOOP_F > STAGE_F ? KLOOP_F : STAGE_F));   // [BM] output pixel of each tile row, -1 = out of range
 
-    // block id -> (m-tile, n-tile); class = blockIdx.y (heaviest class first).  An XCD-aware id remap (contiguous
+    // block id -> (m-tile, n-tile); class = blockIdx.y (heaviest class first).  Measured and rejected: computing all
+    // parity classes of a tile back to back in one block (FETCH_SIZE only -10 %: the patch does not survive in the
+    // 4 MiB L2 across a class pass; 2-4 % slower).  An XCD-aware id remap (contiguous
     // tile runs per XCD, classes interleaved) was measured: within +-0.5 % for the remap alone, 25-50 % SLOWER with
     // the classes interleaved -- this kernel is MFMA-bound and its fetch latency is already hidden.
     const int nblk_n = p.Np / BN;
