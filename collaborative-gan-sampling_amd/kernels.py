@@ -71,7 +71,8 @@ class _WsCache:
 
     def get(self, w, op, kh, kw, sh, sw, cin, cout, bhw=(0, 0, 0)):
         """``bhw`` = (B, H, W) of the call: sizes the optional split-K slab area behind the packed weights."""
-        key = (w.data_ptr(), op, kh, kw, sh, sw, cin, cout, w.device.index, bhw)
+        # one packed copy per HIP stream: the pack kernel is ordered only with later work of the stream that ran it
+        key = (w.data_ptr(), op, kh, kw, sh, sw, cin, cout, w.device.index, bhw, torch.cuda.current_stream(w.device).cuda_stream)
         hit = self._d.get(key)
         if hit is not None and hit[0]() is w:
             if hit[1] == w._version:
