@@ -90,3 +90,24 @@ int cgs_convt_quad_launch(const CgsLayer& L, int B, const float* in, const float
                           hipStream_t s);
 int cgs_convt_smalln_launch(const CgsLayer& L, int B, const float* in, const float* w, const float* bias,
                             float* out, int epilogue, hipStream_t s);
+
+// fused epilogue math shared by the conv-family kernels (device code only)
+#ifdef __HIPCC__
+__device__ __forceinline__ float epilogue_apply(float v, int mode, float a, float b, float aux) {
+    switch (mode) {
+        case CGS_EPI_LRELU: return fmaxf(v, 0.2f * v);
+        case CGS_EPI_AFFINE_RELU: return fmaxf(fmaf(a, v, b), 0.f);
+        case CGS_EPI_TANH: return tanhf(v);
+        case CGS_EPI_RELU_BWD_AFFINE: return aux > 0.f ? v * a : 0.f;
+        case CGS_EPI_LRELU_BWD: return aux > 0.f ? v : 0.2f * v;
+        case CGS_EPI_TANH_BWD: return v * (1.f - aux * aux);
+        default: return v;
+    }
+}
+#endif
+
+int cgs_conv_patch_ok(const CgsLayer& L, int epilogue);
+size_t cgs_conv_patch_ws_floats(const CgsLayer& L);
+int cgs_conv_patch_launch(const CgsLayer& L, int B, const float* in, const float* w, const float* bias, float* out, int epilogue,
+                          const float* ep_a, const float* ep_b, const float* ep_aux, float* ws, size_t ws_bytes, int prepacked,
+                          hipStream_t s);

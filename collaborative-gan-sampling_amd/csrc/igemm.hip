@@ -125,18 +125,6 @@ int cgs_pack_weights(const IgemmParams& p, const CgsLayer& L, bool dirT, const f
 // ------------------------------------------------------------------------------------------------
 // main kernel
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float epilogue_apply(float v, int mode, float a, float b, float aux) {
-    switch (mode) {
-        case CGS_EPI_LRELU: return fmaxf(v, 0.2f * v);
-        case CGS_EPI_AFFINE_RELU: return fmaxf(fmaf(a, v, b), 0.f);
-        case CGS_EPI_TANH: return tanhf(v);
-        case CGS_EPI_RELU_BWD_AFFINE: return aux > 0.f ? v * a : 0.f;
-        case CGS_EPI_LRELU_BWD: return aux > 0.f ? v : 0.2f * v;
-        case CGS_EPI_TANH_BWD: return v * (1.f - aux * aux);
-        default: return v;
-    }
-}
-
 // Row pass of the wide epilogue for ONE epilogue mode (compile-time): branch-free inner loops and a compact
 // instruction footprint.  (With the mode as a run-time switch inside the unrolled loops the epilogue was ~21k lines
 // of ISA with 1.6k branches and took 20 us per block, 10 % of the block's life.)
