@@ -40,6 +40,10 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
                                                          float leak, float* __restrict__ part, int M, int C,
                                                          int rows_per_block) {
     __shared__ float4 red[2][256];
+    // blockIdx.y = independent group (instance norm: one per sample; batch norm: a single group)
+    x += (size_t)blockIdx.y * M * C;
+    if (MODE == 1) { dy += (size_t)blockIdx.y * M * C; stat += (size_t)blockIdx.y * 4 * C; }
+    part += (size_t)blockIdx.y * gridDim.x * 2 * C;
     const int tid = threadIdx.x;
     const int r0 = blockIdx.x * rows_per_block;
     const int r1 = min(M, r0 + rows_per_block);
@@ -101,6 +105,9 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
                                                           float eps, float* __restrict__ stat, float* __restrict__ mean_out,
                                                           float* __restrict__ invstd_out) {
     __shared__ double red[2][16][17];
+    part += (size_t)blockIdx.y * G * 2 * C;
+    stat += (size_t)blockIdx.y * (MODE == 0 ? 4 : 2) * C;
+    if (MODE == 0) { mean_out += (size_t)blockIdx.y * C; invstd_out += (size_t)blockIdx.y * C; }
     const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + cl;
     double a = 0.0, b = 0.0;
@@ -125,11 +132,12 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
 }
 
 // y = lrelu(scale*x + shift)
-__global__ __launch_bounds__(256) void bn_apply_fwd_kernel(const float* __restrict__ x, const float* __restrict__ stat,
-                                                           float leak, float* __restrict__ y, size_t n4, int C) {
-    const float* scale = stat + 2 * C;
-    const float* shift = stat + 3 * C;
+__global__ __launch_bounds__(256) void bn_apply_fwd_kernel(const float* __restrict__ x, const float* __restrict__ stat0,
+                                                           float leak, float* __restrict__ y, size_t n4, int C, size_t group_n4) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const float* stat = stat0 + (i / group_n4) * 4 * C;
+        const float* scale = stat + 2 * C;
+        const float* shift = stat + 3 * C;
         const int c = (int)((i * 4) % C);
         const float4 v = ((const float4*)x)[i];
         const float4 sc = *(const float4*)(scale + c), sh = *(const float4*)(shift + c);
@@ -143,9 +151,11 @@ __global__ __launch_bounds__(256) void bn_apply_fwd_kernel(const float* __restri
 
 // dx = gamma*invstd*(dy' - m1 - xhat*m2)
 __global__ __launch_bounds__(256) void bn_apply_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
-                                                           const float* __restrict__ stat, const float* __restrict__ stat2,
-                                                           float leak, float* __restrict__ dx, size_t n4, int C) {
+                                                           const float* __restrict__ stat0, const float* __restrict__ stat20,
+                                                           float leak, float* __restrict__ dx, size_t n4, int C, size_t group_n4) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const float* stat = stat0 + (i / group_n4) * 4 * C;
+        const float* stat2 = stat20 + (i / group_n4) * 2 * C;
         const int c = (int)((i * 4) % C);
         const float4 xv = ((const float4*)x)[i], dv = ((const float4*)dy)[i];
         const float4 mean = *(const float4*)(stat + c), inv = *(const float4*)(stat + C + c);
@@ -183,7 +193,7 @@ int cgs_bn_train_lrelu_fwd(const float* x, const float* gamma, const float* beta
     hipLaunchKernelGGL(bn_partial_kernel<0>, dim3(g.G), dim3(256), 0, s, x, nullptr, nullptr, leak, part, M, C, g.rows_per_block);
     hipLaunchKernelGGL(bn_finalize_kernel<0>, dim3(cgs_ceil_div(C, 16)), dim3(256), 0, s, part, g.G, M, C, gamma, beta, eps, stat, mean, invstd);
     const size_t n4 = (size_t)M * C / 4;
-    hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3(ew_blocks(n4)), dim3(256), 0, s, x, stat, leak, y, n4, C);
+    hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3(ew_blocks(n4)), dim3(256), 0, s, x, stat, leak, y, n4, C, n4);
     CGS_CHECK_LAUNCH("bn_train_lrelu_fwd");
     return CGS_OK;
 }
@@ -192,6 +202,7 @@ __global__ void bn_restat_kernel(const float* __restrict__ mean, const float* __
                                  const float* __restrict__ beta, float* __restrict__ stat, int C) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
+    mean += (size_t)blockIdx.y * C; invstd += (size_t)blockIdx.y * C; stat += (size_t)blockIdx.y * 4 * C;
     const float scale = gamma[c] * invstd[c];
     stat[c] = mean[c]; stat[C + c] = invstd[c]; stat[2 * C + c] = scale; stat[3 * C + c] = beta[c] - mean[c] * scale;
 }
@@ -210,7 +221,7 @@ int cgs_bn_train_lrelu_bwd_data(const float* dy, const float* x, const float* ga
     hipLaunchKernelGGL(bn_partial_kernel<1>, dim3(g.G), dim3(256), 0, s, x, dy, stat, leak, part, M, C, g.rows_per_block);
     hipLaunchKernelGGL(bn_finalize_kernel<1>, dim3(cgs_ceil_div(C, 16)), dim3(256), 0, s, part, g.G, M, C, nullptr, nullptr, 0.f, stat2, nullptr, nullptr);
     const size_t n4 = (size_t)M * C / 4;
-    hipLaunchKernelGGL(bn_apply_bwd_kernel, dim3(ew_blocks(n4)), dim3(256), 0, s, dy, x, stat, stat2, leak, dx, n4, C);
+    hipLaunchKernelGGL(bn_apply_bwd_kernel, dim3(ew_blocks(n4)), dim3(256), 0, s, dy, x, stat, stat2, leak, dx, n4, C, n4);
     CGS_CHECK_LAUNCH("bn_train_lrelu_bwd_data");
     return CGS_OK;
 }
@@ -233,5 +244,64 @@ int cgs_bias_grad(const float* dy, float* db, int M, int C, int accumulate, void
     hipLaunchKernelGGL(bn_partial_kernel<0>, dim3(g.G), dim3(256), 0, s, dy, nullptr, nullptr, 0.f, (float*)ws, M, C, g.rows_per_block);
     hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cgs_ceil_div(C, 128)), dim3(128), 0, s, (const float*)ws, g.G, C, db, accumulate);
     CGS_CHECK_LAUNCH("bias_grad");
+    return CGS_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Instance norm (+ lrelu / relu): the same kernels with one independent group per sample (blockIdx.y) -- statistics
+// over the H*W pixels of each (sample, channel).  Used by CycleGAN-style generators / PatchGAN discriminators
+// (BASELINE config 5; no reference code exists for them).
+// ------------------------------------------------------------------------------------------------
+static BnGeom in_geom(int B, int HW) {
+    BnGeom g;
+    int maxb = 2048 / (B > 0 ? B : 1);
+    if (maxb < 1) maxb = 1;
+    if (maxb > BN_MAX_BLOCKS) maxb = BN_MAX_BLOCKS;
+    int rpb = cgs_ceil_div(HW, maxb);
+    if (rpb < 16) rpb = 16;
+    g.rows_per_block = rpb;
+    g.G = cgs_ceil_div(HW, rpb);
+    return g;
+}
+
+size_t cgs_instnorm_ws_bytes(int B, int HW, int C) {
+    if (B <= 0 || HW <= 0 || C <= 0) return 0;
+    const BnGeom g = in_geom(B, HW);
+    return ((size_t)B * g.G * 2 * C + (size_t)B * 6 * C) * sizeof(float);   // partials | stat[B][4][C] | stat2[B][2][C]
+}
+
+int cgs_instnorm_lrelu_fwd(const float* x, const float* scale, const float* offset, float eps, float leak, float* y,
+                           float* mean, float* invstd, int B, int HW, int C, void* ws, size_t ws_bytes, void* stream) {
+    if (B <= 0 || HW <= 0 || C <= 0 || (C & 3) || B > 65535) return cgs_set_error(CGS_EINVAL, "instnorm fwd: B=%d HW=%d C=%d", B, HW, C);
+    if (ws_bytes < cgs_instnorm_ws_bytes(B, HW, C)) return cgs_set_error(CGS_EWORKSPACE, "instnorm fwd: workspace %zu < %zu", ws_bytes, cgs_instnorm_ws_bytes(B, HW, C));
+    hipStream_t s = (hipStream_t)stream;
+    const BnGeom g = in_geom(B, HW);
+    float* part = (float*)ws;
+    float* stat = part + (size_t)B * g.G * 2 * C;
+    hipLaunchKernelGGL(bn_partial_kernel<0>, dim3(g.G, B), dim3(256), 0, s, x, nullptr, nullptr, leak, part, HW, C, g.rows_per_block);
+    hipLaunchKernelGGL(bn_finalize_kernel<0>, dim3(cgs_ceil_div(C, 16), B), dim3(256), 0, s, part, g.G, HW, C, scale, offset, eps, stat, mean, invstd);
+    const size_t n4 = (size_t)B * HW * C / 4, gn4 = (size_t)HW * C / 4;
+    hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3(ew_blocks(n4)), dim3(256), 0, s, x, stat, leak, y, n4, C, gn4);
+    CGS_CHECK_LAUNCH("instnorm_lrelu_fwd");
+    return CGS_OK;
+}
+
+int cgs_instnorm_lrelu_bwd_data(const float* dy, const float* x, const float* scale, const float* offset, const float* mean,
+                                const float* invstd, float leak, float* dx, int B, int HW, int C, void* ws, size_t ws_bytes,
+                                void* stream) {
+    if (B <= 0 || HW <= 0 || C <= 0 || (C & 3) || B > 65535) return cgs_set_error(CGS_EINVAL, "instnorm bwd: B=%d HW=%d C=%d", B, HW, C);
+    if (ws_bytes < cgs_instnorm_ws_bytes(B, HW, C)) return cgs_set_error(CGS_EWORKSPACE, "instnorm bwd: workspace %zu < %zu", ws_bytes, cgs_instnorm_ws_bytes(B, HW, C));
+    hipStream_t s = (hipStream_t)stream;
+    const BnGeom g = in_geom(B, HW);
+    float* part = (float*)ws;
+    float* stat = part + (size_t)B * g.G * 2 * C;
+    float* stat2 = stat + (size_t)B * 4 * C;
+    hipLaunchKernelGGL(bn_restat_kernel, dim3(cgs_ceil_div(C, 128), B), dim3(128), 0, s, mean, invstd, scale, offset, stat, C);
+    hipLaunchKernelGGL(bn_partial_kernel<1>, dim3(g.G, B), dim3(256), 0, s, x, dy, stat, leak, part, HW, C, g.rows_per_block);
+    hipLaunchKernelGGL(bn_finalize_kernel<1>, dim3(cgs_ceil_div(C, 16), B), dim3(256), 0, s, part, g.G, HW, C, nullptr, nullptr, 0.f, stat2, nullptr, nullptr);
+    const size_t n4 = (size_t)B * HW * C / 4, gn4 = (size_t)HW * C / 4;
+    hipLaunchKernelGGL(bn_apply_bwd_kernel, dim3(ew_blocks(n4)), dim3(256), 0, s, dy, x, stat, stat2, leak, dx, n4, C, gn4);
+    CGS_CHECK_LAUNCH("instnorm_lrelu_bwd_data");
     return CGS_OK;
 }

@@ -197,3 +197,16 @@ int cgs_refine_select(const float* theta, const float* logit, const int32_t* for
     CGS_CHECK_LAUNCH("refine_select");
     return CGS_OK;
 }
+
+
+// out = a + b  (residual connection and the sum of its two gradient branches)
+__global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ o, size_t n) {
+    GRID_STRIDE(i, n) o[i] = a[i] + b[i];
+}
+
+int cgs_add(const float* a, const float* b, float* out, size_t n, void* stream) {
+    if (n == 0) return CGS_OK;
+    hipLaunchKernelGGL(add_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, a, b, out, n);
+    CGS_CHECK_LAUNCH("add");
+    return CGS_OK;
+}

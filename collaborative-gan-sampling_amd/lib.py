@@ -32,6 +32,10 @@ SIGNATURES = {
     "cgs_bn_ws_bytes": (_z, [_i, _i]),
     "cgs_bn_train_lrelu_fwd": (_i, [_p, _p, _p, _f, _f, _p, _p, _p, _i, _i, _p, _z, _p]),
     "cgs_bn_train_lrelu_bwd_data": (_i, [_p] * 6 + [_f, _p, _i, _i, _p, _z, _p]),
+    "cgs_instnorm_ws_bytes": (_z, [_i, _i, _i]),
+    "cgs_instnorm_lrelu_fwd": (_i, [_p, _p, _p, _f, _f, _p, _p, _p, _i, _i, _i, _p, _z, _p]),
+    "cgs_instnorm_lrelu_bwd_data": (_i, [_p] * 6 + [_f, _p, _i, _i, _i, _p, _z, _p]),
+    "cgs_add": (_i, [_p, _p, _p, _z, _p]),
     "cgs_bn_fold": (_i, [_p] * 4 + [_f, _p, _p, _i, _p]),
     "cgs_affine_relu_fwd": (_i, [_p] * 4 + [_i, _i, _p]),
     "cgs_affine_relu_bwd": (_i, [_p] * 4 + [_i, _i, _p]),

@@ -123,6 +123,18 @@ int cgs_bn_train_lrelu_bwd_data(const float* dy, const float* x, const float* ga
                                 const float* mean, const float* invstd, float leak, float* dx, int M, int C,
                                 void* ws, size_t ws_bytes, void* stream);
 
+/* Instance norm (+ lrelu; leak = 0 gives relu, 1 plain): statistics over the HW pixels of every (sample, channel);
+ * x is [B,HW,C].  CycleGAN-style generators / PatchGAN discriminators (BASELINE config 5; the reference ships no
+ * code for them).  mean / invstd are [B,C].  ws: cgs_instnorm_ws_bytes(B, HW, C). */
+size_t cgs_instnorm_ws_bytes(int B, int HW, int C);
+int cgs_instnorm_lrelu_fwd(const float* x, const float* scale, const float* offset, float eps, float leak, float* y,
+                           float* mean, float* invstd, int B, int HW, int C, void* ws, size_t ws_bytes, void* stream);
+int cgs_instnorm_lrelu_bwd_data(const float* dy, const float* x, const float* scale, const float* offset,
+                                const float* mean, const float* invstd, float leak, float* dx, int B, int HW, int C,
+                                void* ws, size_t ws_bytes, void* stream);
+/* out = a + b (residual connections). */
+int cgs_add(const float* a, const float* b, float* out, size_t n, void* stream);
+
 /* Inference-mode bn folded to a per-channel affine (nsgan/GAN.py:87,94): a = gamma/sqrt(mv+eps), b = beta - a*mm. */
 int cgs_bn_fold(const float* gamma, const float* beta, const float* moving_mean, const float* moving_var,
                 float eps, float* a, float* b, int C, void* stream);
