@@ -63,12 +63,56 @@ def cpu_baseline(arch, refine_steps, rate, budget_batch=64):
                       f"{dt:.1f} s wall, all host threads"}
 
 
+def bench_synthetic2d(args, dev, rank, world):
+    """BASELINE config 1: Imbal-8Gaussians MLP-GAN (D: 2 -> 64 x 5 -> 1), batch 512, K = 10, ladam rate 0.1
+    (synthetic/main.py:32-62) -- the whole refiner_cpu loop as one launch per batch (cgs_amd.synthetic)."""
+    from cgs_amd.synthetic import MLPDiscriminator
+    from oracle import sampling_ref as S                      # only for the seeded weights + the cpu_baseline leg
+    B, Ksteps = args.batch or 512, args.refine_steps or 10
+    Ws, bs = S.mlp_init(64, 6, seed=2019, scale=2.0)
+    D = MLPDiscriminator.from_lists([w.numpy() for w in Ws], [b.numpy() for b in bs], dev)
+    n = args.steps + args.warmup
+    x = torch.from_numpy((3.0 * np.random.RandomState(2019 + rank).randn(n, B, 2)).astype(np.float32)).to(dev)
+    real = torch.from_numpy(S.toy_next_batch("Imbal-8Gaussians", 10.0, 0.9, B, np.random.RandomState(7)).astype(np.float32)).to(dev)
+
+    def step(i):
+        base = D.sigmoid_and_saliency(real, want_saliency=False)[0].mean().item()     # np.mean(real_sigmoid), refiner_cpu.py:23,28
+        return D.refine(x[i], base, Ksteps, args.rate, "ladam")[0]
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i in range(args.warmup, n):
+        step(i)
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    if rank == 0:
+        out = {"metric": f"refined samples/sec @ {Ksteps} refinement steps", "value": round(world * B * args.steps / dt, 1), "unit": "samples/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": f"synthetic2d Imbal-8Gaussians MLP-GAN D 2-64x5-1, batch {B}, K={Ksteps}, ladam rate {args.rate}: "
+                                      "real-batch baseline + fused K-step refine (2 launches + 1 host read per batch)"},
+               "roofline": None}
+        if not args.no_cpu_baseline:
+            fake = x[0].cpu().numpy(); rb = real.cpu().numpy().astype(np.float64)
+            d_fn = lambda v: S.mlp_sigmoid_and_saliency(Ws, bs, v)
+            S.refine_2d(fake, rb, d_fn, Ksteps, args.rate, "ladam")
+            t = time.time(); reps = 20
+            for _ in range(reps):
+                S.refine_2d(fake, rb, d_fn, Ksteps, args.rate, "ladam")
+            c = (time.time() - t) / reps
+            out["cpu_baseline"] = {"value": round(B / c, 1), "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+                                   "sample": f"oracle.refine_2d (refiner_cpu.manipulate_sample restated; torch-CPU D), batch {B}, K={Ksteps}, {reps} reps"}
+        print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--arch", default="dcgan64", choices=["mnist", "dcgan32", "dcgan64"])
+    ap.add_argument("--arch", default="dcgan64", choices=["mnist", "dcgan32", "dcgan64", "synthetic2d"],
+                    help="synthetic2d = BASELINE config 1 (2-D MLP GAN, batch 512, K=10, ladam) on the fused device refiner")
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: 1024 dcgan64, 256 dcgan32, 64 mnist)")
     ap.add_argument("--refine-steps", type=int, default=0, help="K (default: 20; 50 for mnist)")
     ap.add_argument("--rate", type=float, default=0.1)
@@ -92,6 +136,9 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
+
+    if args.arch == "synthetic2d":
+        return bench_synthetic2d(args, dev, rank, world)
 
     from cgs_amd import kernels as K
     from cgs_amd import nets

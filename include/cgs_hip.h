@@ -174,6 +174,21 @@ int cgs_refine_select(const float* theta, const float* logit, const int32_t* for
 int cgs_refine_select_rows(const float* src, const float* logit, const int32_t* forced, int step_index, float* dst,
                            const float* best_logit, int B, int F, void* stream);
 
+/* ---- the 2-D path (BASELINE config 1: synthetic/ MLP GAN) ----------------------------------------------------------
+ * ReLU MLP discriminator on 2-D points, 2 -> nhidden x (nlayers-1) -> 1 (synthetic/GAN.py:28-37); w[l] is layer l's
+ * [din,dout] kernel (tf.layers.dense), b[l] its bias; w / b are HOST arrays of nlayers DEVICE pointers; nhidden <= 64.
+ *   sigmoid[B]    = sigmoid(D(x))                                              synthetic/GAN.py:108
+ *   saliency[B,2] = inv_batch * d sum_b softplus(-logit_b) / dx  (inv_batch = 1/B keeps the reduce_mean factor of :109-111)
+ * saliency may be NULL. */
+int cgs_mlp2d_sigmoid_saliency(const float* const* w, const float* const* b, int nlayers, int nhidden, const float* x,
+                               float* sigmoid, float* saliency, int B, float inv_batch, void* stream);
+/* The whole host loop of sampling/refiner_cpu.py:26-66 in one launch (one wave per sample): K steps of
+ * sgd (method 0) / momentum (1) / ladam (2) (sampling/policy.py:26-61) on x[B,2] with loss = real_sigmoid_mean - sigmoid,
+ * best-loss tracking (best_x[B,2], best_step[B]) and, if traj != NULL, the trajectory traj[B,K+1,2]. */
+int cgs_refine2d(const float* const* w, const float* const* b, int nlayers, int nhidden, const float* x,
+                 float real_sigmoid_mean, float inv_batch, int steps, float rate, int method,
+                 float* best_x, float* best_step, float* traj, int B, void* stream);
+
 /* ---- discriminator shaping step (the caller after the refinement path: nsgan/GAN.py:270-272, 126-146) ----------
  * Weight gradients of D's layers, the BCE seed with 0/1 targets, and the Adam update.  NOT part of the frozen-weight
  * refinement loop; provided so the method's only training step (shape D on refined samples) runs on the same ABI. */
