@@ -18,7 +18,7 @@ import torch
 
 from . import kernels as K
 from . import lib as L
-from .nets import ARCHS, _same_out
+from .nets import ARCHS, _same_out, g_input_shape, layer_ks
 
 
 # ----------------------------------------------------------------------------- stages
@@ -60,8 +60,11 @@ class _Conv(_Stage):
         return K.conv2d_fwd(x, self.w, self.b, self.s, self.s, self.epi, out=self.out)
 
     def bwd(self, dy):
-        if self.epi == L.EPI_LRELU and not self.pre_folded:
-            dy = K.lrelu_bwd(dy, self.out, out=dy)
+        if not self.pre_folded:
+            if self.epi == L.EPI_LRELU:
+                dy = K.lrelu_bwd(dy, self.out, out=dy)
+            elif self.epi == L.EPI_TANH:
+                dy = K.tanh_bwd(dy, self.out, out=dy)
         e, a, aux = self.bwd_epi
         return K.conv2d_bwd_data(dy, self.w, self.in_hw, self.s, self.s, out=self.dx, epilogue=e, ep_a=a, ep_aux=aux)
 
@@ -123,6 +126,47 @@ class _BnTrainLrelu(_Stage):
         return K.bn_train_lrelu_bwd_data(dy, self.x, self.gamma, self.beta, self.mean, self.invstd, self.leak, out=dy)
 
 
+class _InstNormAct(_Stage):
+    """Instance norm [+ relu / lrelu]: per-(sample, channel) statistics over the pixels (CycleGAN G, PatchGAN D)."""
+
+    def __init__(self, B, shape, scale, offset, leak, dev):
+        self.scale, self.offset, self.leak = scale, offset, leak
+        self.out = torch.empty((B,) + tuple(shape), dtype=torch.float32, device=dev)
+        self.mean = torch.empty((B, shape[-1]), dtype=torch.float32, device=dev)
+        self.invstd = torch.empty((B, shape[-1]), dtype=torch.float32, device=dev)
+        self.x = None
+
+    def fwd(self, x):
+        self.x = x
+        K.instnorm_lrelu_fwd(x, self.scale, self.offset, self.leak, out=self.out, stats=(self.mean, self.invstd))
+        return self.out
+
+    def bwd(self, dy):
+        return K.instnorm_lrelu_bwd_data(dy, self.x, self.scale, self.offset, self.mean, self.invstd, self.leak, out=dy)
+
+
+class _Residual(_Stage):
+    """x + F(x): forward adds the skip, backward adds the two gradient branches."""
+
+    def __init__(self, B, shape, inner, dev):
+        self.inner = inner
+        self.out = torch.empty((B,) + tuple(shape), dtype=torch.float32, device=dev)
+        self.dskip = torch.empty((B,) + tuple(shape), dtype=torch.float32, device=dev)
+
+    def fwd(self, x):
+        y = x
+        for st in self.inner:
+            y = st.fwd(y)
+        return K.add(x, y, out=self.out)
+
+    def bwd(self, dy):
+        self.dskip.copy_(dy)                     # the inner stages transform their incoming gradient in place
+        g = dy
+        for st in reversed(self.inner):
+            g = st.bwd(g)
+        return K.add(self.dskip, g, out=self.dskip)
+
+
 class _AffineRelu(_Stage):
     """Inference-mode bn + relu that could not be folded into a producer epilogue (G head)."""
 
@@ -174,17 +218,19 @@ def compile_layers(layers, in_shape, P, scope, B, k, stride, bn_training, dev):
         t = Lr[0]
         if t == "deconv":
             w, b = P[f"{scope}/{Lr[1]}/w"], P[f"{scope}/{Lr[1]}/biases"]
+            _, stride_l = layer_ks(Lr, k, stride)
             epi, a, c, used = L.EPI_NONE, None, None, 1
             if kind(i + 1) == "bn" and kind(i + 2) == "relu" and not bn_training:
                 a, c = fold(layers[i + 1][1]); epi, used = L.EPI_AFFINE_RELU, 3
             elif kind(i + 1) == "tanh":
                 epi, used = L.EPI_TANH, 2
-            stages.append(_Deconv(B, shape, Lr[2], w, b, stride, epi, a, c, dev))
+            stages.append(_Deconv(B, shape, Lr[2], w, b, stride_l, epi, a, c, dev))
             shape = tuple(Lr[2]); i += used
         elif t == "conv":
             w, b = P[f"{scope}/{Lr[1]}/w"], P[f"{scope}/{Lr[1]}/biases"]
-            epi, used = (L.EPI_LRELU, 2) if kind(i + 1) == "lrelu" else (L.EPI_NONE, 1)
-            st = _Conv(B, shape, w, b, stride, epi, dev)
+            _, stride_l = layer_ks(Lr, k, stride)
+            epi, used = (L.EPI_LRELU, 2) if kind(i + 1) == "lrelu" else (L.EPI_TANH, 2) if kind(i + 1) == "tanh" else (L.EPI_NONE, 1)
+            st = _Conv(B, shape, w, b, stride_l, epi, dev)
             stages.append(st)
             shape = tuple(st.out.shape[1:]); i += used
         elif t == "linear":
@@ -203,6 +249,14 @@ def compile_layers(layers, in_shape, P, scope, B, k, stride, bn_training, dev):
                     raise NotImplementedError("inference-mode bn is only supported when followed by relu")
                 a, c = fold(Lr[1])
                 stages.append(_AffineRelu(B, shape, a, c, dev)); i += 2
+        elif t == "instnorm":
+            sc = f"{scope}/{Lr[1]}"
+            leak, used = (K.LEAK, 2) if kind(i + 1) == "lrelu" else (0.0, 2) if kind(i + 1) == "relu" else (1.0, 1)
+            stages.append(_InstNormAct(B, shape, P[sc + "/scale"], P[sc + "/offset"], leak, dev)); i += used
+        elif t == "res":
+            inner, ishape = compile_layers(Lr[1], shape, P, scope, B, k, stride, bn_training, dev)
+            assert tuple(ishape) == tuple(shape)
+            stages.append(_Residual(B, shape, inner, dev)); i += 1
         elif t in ("relu", "lrelu", "tanh"):
             stages.append(_Unary(B, shape, t, dev)); i += 1
         elif t == "reshape":
@@ -227,6 +281,8 @@ def link_backward_fusion(stages):
             above.bwd_epi = (L.EPI_TANH_BWD, None, below.out)
         elif isinstance(below, _Conv) and below.epi == L.EPI_LRELU:
             above.bwd_epi = (L.EPI_LRELU_BWD, None, below.out)
+        elif isinstance(below, _Conv) and below.epi == L.EPI_TANH:
+            above.bwd_epi = (L.EPI_TANH_BWD, None, below.out)
         else:
             continue
         below.pre_folded = True
@@ -262,7 +318,7 @@ class RefineEngine:
         A, B = self.A, int(batch_size)
         self.B, self.P = B, params
         with torch.cuda.device(self.dev):
-            self.g_head = Tape(A["g_head"], (A["z_dim"],), params, "generator", B, A["k"], A["stride"], False, self.dev)
+            self.g_head = Tape(A["g_head"], g_input_shape(A), params, "generator", B, A["k"], A["stride"], False, self.dev)
             self.g_tail = Tape(A["g_tail"], A["feature"], params, "generator", B, A["k"], A["stride"], False, self.dev)
             self.d = Tape(A["d"], A["img"], params, "discriminator", B, A["k"], A["stride"], True, self.dev)
             link_backward_fusion(self.g_tail.stages + self.d.stages)     # across the G-tail / D seam too

@@ -239,6 +239,51 @@ def bn_train_lrelu_bwd_data(dy, x, gamma, beta, mean, invstd, leak=LEAK, out=Non
     return dx
 
 
+_in_ws = {}
+
+
+def _in_workspace(B, HW, C, device):
+    key = (B, HW, C, device.index, torch.cuda.current_stream(device).cuda_stream)
+    ws = _in_ws.get(key)
+    if ws is None:
+        ws = torch.empty(int(L.load().cgs_instnorm_ws_bytes(B, HW, C)) // 4 + 4, dtype=torch.float32, device=device)
+        _in_ws[key] = ws
+    return ws
+
+
+def instnorm_lrelu_fwd(x, scale, offset, leak=1.0, eps=BN_EPS, out=None, stats=None):
+    """Instance norm over the H*W pixels of every (sample, channel) (+ lrelu; leak 0 = relu, 1 = none).
+    x: [B,H,W,C].  Returns (y, mean[B,C], invstd[B,C])."""
+    _chk(x, "x")
+    B, C = x.shape[0], x.shape[-1]
+    HW = x.numel() // (B * C)
+    y = out if out is not None else torch.empty_like(x)
+    mean, invstd = stats if stats is not None else (torch.empty((B, C), dtype=torch.float32, device=x.device),
+                                                     torch.empty((B, C), dtype=torch.float32, device=x.device))
+    ws = _in_workspace(B, HW, C, x.device)
+    L.call("cgs_instnorm_lrelu_fwd", _ptr(x), _ptr(scale), _ptr(offset), eps, leak, _ptr(y), _ptr(mean), _ptr(invstd), B, HW, C,
+           _ptr(ws), ws.numel() * 4, _stream())
+    return y, mean, invstd
+
+
+def instnorm_lrelu_bwd_data(dy, x, scale, offset, mean, invstd, leak=1.0, out=None):
+    _chk(dy, "dy"); _chk(x, "x")
+    B, C = x.shape[0], x.shape[-1]
+    HW = x.numel() // (B * C)
+    dx = out if out is not None else torch.empty_like(x)
+    ws = _in_workspace(B, HW, C, x.device)
+    L.call("cgs_instnorm_lrelu_bwd_data", _ptr(dy), _ptr(x), _ptr(scale), _ptr(offset), _ptr(mean), _ptr(invstd), leak, _ptr(dx),
+           B, HW, C, _ptr(ws), ws.numel() * 4, _stream())
+    return dx
+
+
+def add(a, b, out=None):
+    _chk(a, "a"); _chk(b, "b")
+    o = out if out is not None else torch.empty_like(a)
+    L.call("cgs_add", _ptr(a), _ptr(b), _ptr(o), a.numel(), _stream())
+    return o
+
+
 def bn_fold(gamma, beta, moving_mean, moving_var, eps=BN_EPS):
     """Inference-mode bn as a per-channel affine (a, b).  nsgan/GAN.py:87,94."""
     C = gamma.numel()

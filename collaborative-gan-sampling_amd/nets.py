@@ -7,8 +7,10 @@ README links a missing image/ package), so they are defined here from the nsgan/
 reference credits (nsgan/ops.py:1-3), refined at G.h1.
 
 A layer list is a sequence of tuples:
-    ("linear", scope, out) ("reshape", (h,w,c)) ("flatten",) ("conv", scope, cout) ("deconv", scope, (ho,wo,cout))
-    ("bn", scope) ("relu",) ("lrelu",) ("tanh",)
+    ("linear", scope, out) ("reshape", (h,w,c)) ("flatten",) ("conv", scope, cout[, k, stride])
+    ("deconv", scope, (ho,wo,cout)[, k, stride]) ("bn", scope) ("instnorm", scope) ("relu",) ("lrelu",) ("tanh",)
+    ("res", [inner layers])  -- a residual block  x + F(x)
+(conv / deconv take the arch-wide kernel size and stride unless they carry their own.)
 Parameter names are the TF variable names (``generator/g_dc3/w`` ...; nsgan/ops.py:38-43,49-61,75-79)
 so a converted checkpoint drops in unchanged.
 """
@@ -52,6 +54,35 @@ ARCHS = {
 }
 
 
+def cyclegan(img=256, n_res=9, ngf=64, ndf=64):
+    """BASELINE config 5: a CycleGAN ResNet generator (c7s1-64, d128, d256, R256 x n, u128, u64, c7s1-3) refined at the
+    output of its residual trunk, and the 70x70 PatchGAN discriminator (C64-C128-C256-C512-1), both with instance norm.
+    The reference ships NO code for this config: the layers are defined here with the
+    operator defaults of nsgan/ops.py ('SAME' zero padding instead of the paper's reflection padding); the
+    generator's input is an image, so ``z_dim`` is replaced by ``g_in`` = the image shape."""
+    q = img // 4
+    res = [("res", [("conv", f"g_r{i}_c1", 4 * ngf, 3, 1), ("instnorm", f"g_r{i}_in1"), ("relu",),
+                    ("conv", f"g_r{i}_c2", 4 * ngf, 3, 1), ("instnorm", f"g_r{i}_in2")]) for i in range(n_res)]
+    return dict(
+        z_dim=None, g_in=(img, img, 3), img=(img, img, 3), k=3, stride=2,
+        g_head=[("conv", "g_c1", ngf, 7, 1), ("instnorm", "g_in1"), ("relu",),
+                ("conv", "g_d1", 2 * ngf, 3, 2), ("instnorm", "g_in2"), ("relu",),
+                ("conv", "g_d2", 4 * ngf, 3, 2), ("instnorm", "g_in3"), ("relu",)] + res,
+        g_tail=[("deconv", "g_u1", (img // 2, img // 2, 2 * ngf), 3, 2), ("instnorm", "g_in4"), ("relu",),
+                ("deconv", "g_u2", (img, img, ngf), 3, 2), ("instnorm", "g_in5"), ("relu",),
+                ("conv", "g_c2", 3, 7, 1), ("tanh",)],
+        d=[("conv", "d_c1", ndf, 4, 2), ("lrelu",),
+           ("conv", "d_c2", 2 * ndf, 4, 2), ("instnorm", "d_in2"), ("lrelu",),
+           ("conv", "d_c3", 4 * ndf, 4, 2), ("instnorm", "d_in3"), ("lrelu",),
+           ("conv", "d_c4", 8 * ndf, 4, 1), ("instnorm", "d_in4"), ("lrelu",),
+           ("conv", "d_c5", 1, 4, 1)],
+        feature=(q, q, 4 * ngf))
+
+
+ARCHS["cyclegan256"] = cyclegan(256, 9)
+ARCHS["cyclegan_tiny"] = cyclegan(32, 2, ngf=16, ndf=16)       # same topology, test-sized
+
+
 def _same_out(size, stride):
     return int(math.ceil(float(size) / float(stride)))
 
@@ -70,17 +101,30 @@ def walk_shapes(layers, shape, k, stride, scope):
         elif kind == "flatten":
             shape = (int(np.prod(shape)),)
         elif kind == "conv":
-            yield f"{scope}/{L[1]}/w", (k, k, shape[-1], L[2])
+            kk, ss = layer_ks(L, k, stride)
+            yield f"{scope}/{L[1]}/w", (kk, kk, shape[-1], L[2])
             yield f"{scope}/{L[1]}/biases", (L[2],)
-            shape = (_same_out(shape[0], stride), _same_out(shape[1], stride), L[2])
+            shape = (_same_out(shape[0], ss), _same_out(shape[1], ss), L[2])
         elif kind == "deconv":
-            yield f"{scope}/{L[1]}/w", (k, k, L[2][2], shape[-1])
+            kk, ss = layer_ks(L, k, stride)
+            yield f"{scope}/{L[1]}/w", (kk, kk, L[2][2], shape[-1])
             yield f"{scope}/{L[1]}/biases", (L[2][2],)
             shape = tuple(L[2])
         elif kind == "bn":
             for v in ("beta", "gamma", "moving_mean", "moving_variance"):
                 yield f"{scope}/{L[1]}/{v}", (shape[-1],)
+        elif kind == "instnorm":
+            yield f"{scope}/{L[1]}/scale", (shape[-1],)
+            yield f"{scope}/{L[1]}/offset", (shape[-1],)
+        elif kind == "res":
+            inner = yield from walk_shapes(L[1], shape, k, stride, scope)
+            assert tuple(inner) == tuple(shape), "a residual block must preserve its input shape"
     return shape
+
+
+def layer_ks(L, k, stride):
+    """(kernel size, stride) of a conv / deconv layer tuple: its own if it carries them, else the arch-wide ones."""
+    return (L[3], L[4]) if len(L) >= 5 else (k, stride)
 
 
 def param_shapes(arch):
@@ -95,10 +139,15 @@ def param_shapes(arch):
                 out[n] = s
             except StopIteration as e:
                 return e.value
-    feat = run(A["g_head"], (A["z_dim"],), "generator")
+    feat = run(A["g_head"], g_input_shape(A), "generator")
     img = run(A["g_tail"], feat, "generator")
     run(A["d"], img, "discriminator")
     return out
+
+
+def g_input_shape(A):
+    """Shape (no batch dim) of what the generator head consumes: a z vector, or an image for image-to-image nets."""
+    return tuple(A["g_in"]) if A.get("g_in") else (A["z_dim"],)
 
 
 def init_params(arch, device, seed=2019):
@@ -113,7 +162,7 @@ def init_params(arch, device, seed=2019):
             torch.nn.init.trunc_normal_(t, 0.0, 0.02, -0.04, 0.04, generator=g)
         elif leaf in ("w", "Matrix"):
             t = torch.randn(shp, generator=g) * 0.02
-        elif leaf in ("gamma", "moving_variance"):
+        elif leaf in ("gamma", "moving_variance", "scale"):
             t = torch.ones(shp)
         else:
             t = torch.zeros(shp)
@@ -135,12 +184,16 @@ def macs_per_sample(arch):
         m = 0
         for L in layers:
             if L[0] == "conv":
-                o = (_same_out(shape[0], A["stride"]), _same_out(shape[1], A["stride"]), L[2])
-                m += o[0] * o[1] * o[2] * A["k"] ** 2 * shape[2]
+                kk, ss = layer_ks(L, A["k"], A["stride"])
+                o = (_same_out(shape[0], ss), _same_out(shape[1], ss), L[2])
+                m += o[0] * o[1] * o[2] * kk ** 2 * shape[2]
                 shape = o
             elif L[0] == "deconv":
-                m += shape[0] * shape[1] * shape[2] * A["k"] ** 2 * L[2][2]
+                kk, ss = layer_ks(L, A["k"], A["stride"])
+                m += shape[0] * shape[1] * shape[2] * kk ** 2 * L[2][2]
                 shape = tuple(L[2])
+            elif L[0] == "res":
+                m += walk(L[1], shape)
             elif L[0] == "linear":
                 m += int(np.prod(shape)) * L[2]
                 shape = (L[2],)

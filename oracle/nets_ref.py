@@ -55,6 +55,36 @@ ARCHS = {
 }
 
 
+def _cyclegan(img, n_res, ngf=64, ndf=64):
+    """CycleGAN ResNet G / PatchGAN D with instance norm (BASELINE config 5).  NOT in the reference tree and without
+    reference code of any kind: parity for it is oracle-vs-kernel only (unpinned)."""
+    q = img // 4
+    res = [("res", [("conv", f"g_r{i}_c1", 4 * ngf, 3, 1), ("instnorm", f"g_r{i}_in1"), ("relu",),
+                    ("conv", f"g_r{i}_c2", 4 * ngf, 3, 1), ("instnorm", f"g_r{i}_in2")]) for i in range(n_res)]
+    return dict(
+        z_dim=None, g_in=(img, img, 3), img=(img, img, 3), k=3,
+        g_head=[("conv", "g_c1", ngf, 7, 1), ("instnorm", "g_in1"), ("relu",),
+                ("conv", "g_d1", 2 * ngf, 3, 2), ("instnorm", "g_in2"), ("relu",),
+                ("conv", "g_d2", 4 * ngf, 3, 2), ("instnorm", "g_in3"), ("relu",)] + res,
+        g_tail=[("deconv", "g_u1", (img // 2, img // 2, 2 * ngf), 3, 2), ("instnorm", "g_in4"), ("relu",),
+                ("deconv", "g_u2", (img, img, ngf), 3, 2), ("instnorm", "g_in5"), ("relu",),
+                ("conv", "g_c2", 3, 7, 1), ("tanh",)],
+        d=[("conv", "d_c1", ndf, 4, 2), ("lrelu",),
+           ("conv", "d_c2", 2 * ndf, 4, 2), ("instnorm", "d_in2"), ("lrelu",),
+           ("conv", "d_c3", 4 * ndf, 4, 2), ("instnorm", "d_in3"), ("lrelu",),
+           ("conv", "d_c4", 8 * ndf, 4, 1), ("instnorm", "d_in4"), ("lrelu",),
+           ("conv", "d_c5", 1, 4, 1)],
+        feature=(q, q, 4 * ngf))
+
+
+ARCHS["cyclegan256"] = _cyclegan(256, 9)
+ARCHS["cyclegan_tiny"] = _cyclegan(32, 2, ngf=16, ndf=16)
+
+
+def _ks(L, k):
+    return (L[3], L[4]) if len(L) >= 5 else (k, 2)
+
+
 def _walk_shapes(layers, shape, k, scope, out):
     """Collect parameter shapes by walking a layer list from an input shape (no batch dim)."""
     for L in layers:
@@ -67,11 +97,17 @@ def _walk_shapes(layers, shape, k, scope, out):
         elif kind == "flatten":
             shape = (int(np.prod(shape)),)
         elif kind == "conv":
-            out[f"{scope}/{L[1]}/w"] = (k, k, shape[-1], L[2]); out[f"{scope}/{L[1]}/biases"] = (L[2],)
-            shape = (R.conv_out_size_same(shape[0], 2), R.conv_out_size_same(shape[1], 2), L[2])
+            kk, ss = _ks(L, k)
+            out[f"{scope}/{L[1]}/w"] = (kk, kk, shape[-1], L[2]); out[f"{scope}/{L[1]}/biases"] = (L[2],)
+            shape = (R.conv_out_size_same(shape[0], ss), R.conv_out_size_same(shape[1], ss), L[2])
         elif kind == "deconv":
-            out[f"{scope}/{L[1]}/w"] = (k, k, L[2][2], shape[-1]); out[f"{scope}/{L[1]}/biases"] = (L[2][2],)
+            kk, ss = _ks(L, k)
+            out[f"{scope}/{L[1]}/w"] = (kk, kk, L[2][2], shape[-1]); out[f"{scope}/{L[1]}/biases"] = (L[2][2],)
             shape = tuple(L[2])
+        elif kind == "instnorm":
+            out[f"{scope}/{L[1]}/scale"] = (shape[-1],); out[f"{scope}/{L[1]}/offset"] = (shape[-1],)
+        elif kind == "res":
+            assert tuple(_walk_shapes(L[1], shape, k, scope, out)) == tuple(shape)
         elif kind == "bn":
             for v in ("beta", "gamma", "moving_mean", "moving_variance"):
                 out[f"{scope}/{L[1]}/{v}"] = (shape[-1],)
@@ -81,7 +117,7 @@ def _walk_shapes(layers, shape, k, scope, out):
 def param_shapes(arch):
     A = ARCHS[arch]
     out = {}
-    feat = _walk_shapes(A["g_head"], (A["z_dim"],), A["k"], "generator", out)
+    feat = _walk_shapes(A["g_head"], tuple(A["g_in"]) if A.get("g_in") else (A["z_dim"],), A["k"], "generator", out)
     assert tuple(feat) == tuple(A["feature"])
     img = _walk_shapes(A["g_tail"], feat, A["k"], "generator", out)
     assert tuple(img) == tuple(A["img"])
@@ -105,8 +141,10 @@ def init_params(arch, seed=2019, perturb=True):
             t = torch.randn(shp, generator=g) * 0.02
         elif leaf in ("biases", "bias", "beta"):
             t = torch.randn(shp, generator=g) * 0.02 if perturb else torch.zeros(shp)
-        elif leaf == "gamma":
+        elif leaf in ("gamma", "scale"):
             t = 1.0 + 0.1 * torch.randn(shp, generator=g) if perturb else torch.ones(shp)
+        elif leaf == "offset":
+            t = torch.randn(shp, generator=g) * 0.02 if perturb else torch.zeros(shp)
         elif leaf == "moving_mean":
             t = 0.05 * torch.randn(shp, generator=g) if perturb else torch.zeros(shp)
         elif leaf == "moving_variance":
@@ -127,10 +165,17 @@ def run_layers(layers, x, P, scope, bn_training, k_stride=2):
         elif kind == "flatten":
             x = x.reshape(x.shape[0], -1)          # NHWC -> (h,w,c)-major rows, nsgan/GAN.py:66
         elif kind == "conv":
-            x = R.conv2d(x, P[f"{scope}/{L[1]}/w"], P[f"{scope}/{L[1]}/biases"], k_stride, k_stride)
+            ss = L[4] if len(L) >= 5 else k_stride
+            x = R.conv2d(x, P[f"{scope}/{L[1]}/w"], P[f"{scope}/{L[1]}/biases"], ss, ss)
         elif kind == "deconv":
+            ss = L[4] if len(L) >= 5 else k_stride
             x = R.deconv2d(x, P[f"{scope}/{L[1]}/w"], P[f"{scope}/{L[1]}/biases"],
-                           (x.shape[0],) + tuple(L[2]), k_stride, k_stride)
+                           (x.shape[0],) + tuple(L[2]), ss, ss)
+        elif kind == "instnorm":
+            s_ = f"{scope}/{L[1]}"
+            x = R.instance_norm(x, P[s_ + "/scale"], P[s_ + "/offset"])
+        elif kind == "res":
+            x = x + run_layers(L[1], x, P, scope, bn_training, k_stride)
         elif kind == "bn":
             s = f"{scope}/{L[1]}"
             if bn_training:
@@ -171,10 +216,14 @@ def macs_per_sample(arch):
         m = 0
         for L in layers:
             if L[0] == "conv":
-                o = (R.conv_out_size_same(shape[0], 2), R.conv_out_size_same(shape[1], 2), L[2])
-                m += o[0] * o[1] * o[2] * A["k"] ** 2 * shape[2]; shape = o
+                kk, ss = _ks(L, A["k"])
+                o = (R.conv_out_size_same(shape[0], ss), R.conv_out_size_same(shape[1], ss), L[2])
+                m += o[0] * o[1] * o[2] * kk ** 2 * shape[2]; shape = o
             elif L[0] == "deconv":
-                m += shape[0] * shape[1] * shape[2] * A["k"] ** 2 * L[2][2]; shape = tuple(L[2])
+                kk, ss = _ks(L, A["k"])
+                m += shape[0] * shape[1] * shape[2] * kk ** 2 * L[2][2]; shape = tuple(L[2])
+            elif L[0] == "res":
+                m += walk(L[1], shape)
             elif L[0] == "linear":
                 m += int(np.prod(shape)) * L[2]; shape = (L[2],)
             elif L[0] == "flatten":

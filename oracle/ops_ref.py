@@ -69,6 +69,14 @@ def bn_infer(x, gamma, beta, moving_mean, moving_var):
     return gamma * (x - moving_mean) / torch.sqrt(moving_var + BN_EPS) + beta
 
 
+def instance_norm(x, scale, offset):
+    """Instance norm: statistics over the pixels of every (sample, channel); biased variance, eps 1e-5.
+    (No reference call site: used only by the build-defined CycleGAN / PatchGAN nets of BASELINE config 5.)"""
+    mean = x.mean(dim=(1, 2), keepdim=True)
+    var = ((x - mean) ** 2).mean(dim=(1, 2), keepdim=True)
+    return scale * (x - mean) / torch.sqrt(var + BN_EPS) + offset
+
+
 def lrelu(x, leak=LRELU_LEAK):
     """tf.maximum(x, leak*x)  (nsgan/ops.py:69-70)."""
     return torch.maximum(x, leak * x)
