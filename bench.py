@@ -111,7 +111,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--arch", default="dcgan64", choices=["mnist", "dcgan32", "dcgan64", "synthetic2d"],
+    ap.add_argument("--arch", default="dcgan64", choices=["mnist", "dcgan32", "dcgan64", "synthetic2d", "cyclegan256"],
                     help="synthetic2d = BASELINE config 1 (2-D MLP GAN, batch 512, K=10, ladam) on the fused device refiner")
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: 1024 dcgan64, 256 dcgan32, 64 mnist)")
     ap.add_argument("--refine-steps", type=int, default=0, help="K (default: 20; 50 for mnist)")
@@ -144,7 +144,7 @@ def main():
     from cgs_amd import nets
     from cgs_amd.engine import RefineEngine
 
-    B = args.batch or {"dcgan64": 1024, "dcgan32": 256, "mnist": 64}[args.arch]
+    B = args.batch or {"dcgan64": 1024, "dcgan32": 256, "mnist": 64, "cyclegan256": 8}[args.arch]
     Ksteps = args.refine_steps or (50 if args.arch == "mnist" else 20)
     A = nets.ARCHS[args.arch]
     P = nets.init_params(args.arch, dev, seed=2019)                     # same frozen weights on every rank
@@ -153,7 +153,7 @@ def main():
     eng = engines[0]
     n_batches = args.steps + args.warmup
     rs = np.random.RandomState(2019 + rank)                            # rank-offset seed: disjoint z shards
-    z = torch.from_numpy(rs.uniform(-1, 1, (n_batches, B, A["z_dim"])).astype(np.float32)).to(dev)
+    z = torch.from_numpy(rs.uniform(-1, 1, (n_batches, B) + nets.g_input_shape(A)).astype(np.float32)).to(dev)   # z, or source images
     pools = [torch.empty((world * B,) + tuple(A["img"]), dtype=torch.float32, device=dev) if use_dist else None
              for _ in engines]                                           # one node-wide pool buffer per batch in flight
 
@@ -210,7 +210,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.arch} collaborative refinement (propose + K-step refine + render), "
-                                   f"batch {B}/GPU, K={Ksteps}, momentum rate {args.rate}, refine@G.h1 "
+                                   f"batch {B}/GPU, K={Ksteps}, momentum rate {args.rate}, refine at feature "
                                    f"{list(A['feature'])}, random-init weights, z~U(-1,1) seed 2019+rank",
                        "global_batch": world * B, "refine_steps": Ksteps, "parallelism": f"z-shards x{world} + RCCL all-gather of the pool" if world > 1 else "single GPU",
                        "hipgraph": bool(args.graph), "batches_in_flight": len(engines)},
