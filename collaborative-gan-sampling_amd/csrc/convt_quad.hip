@@ -297,6 +297,7 @@ int cgs_convt_quad_launch(const CgsLayer& L, int B, const float* in, const float
     quad_range(L.kh, pt, p.dmin_y, hy);
     quad_range(L.kw, pl, p.dmin_x, hx);
     p.ny = hy - p.dmin_y + 1; p.nx = hx - p.dmin_x + 1;
+    if ((long)B * L.Hs * L.Ws * L.Cs * 4 > 0x7fffffffL) return cgs_set_error(CGS_EINVAL, "convt_quad: input exceeds 2 GiB (split the batch)");
     const size_t K = (size_t)p.ny * p.nx * L.Cs;
     const size_t need = K * 16 * sizeof(float);
     if (!ws || ws_bytes < need) return cgs_set_error(CGS_EWORKSPACE, "convt_quad: workspace %zu < %zu bytes", ws_bytes, need);
