@@ -58,6 +58,9 @@ static int run_dir(const CgsLayer& L, bool dirT, int B, const float* in, const f
         if (epilogue < CGS_EPI_RELU_BWD_AFFINE)
             return cgs_convt_smalln_launch(L, B, in, w, bias, out, epilogue, s);     // VALU form (any Cs % 4 == 0)
     }
+    if (!dirT && cgs_conv_smalln_f_ok(L, B, epilogue) && ws && ws_bytes >= cgs_conv_smalln_f_ws_floats(L) * sizeof(float) &&
+        !(((uintptr_t)in & 15) || ((uintptr_t)ws & 15)))
+        return cgs_conv_smalln_f_launch(L, B, in, w, bias, out, epilogue, (float*)ws, ws_bytes, prepacked, s);
     if (!dirT && cgs_conv_patch_ok(L, epilogue) && ws && ws_bytes >= cgs_conv_patch_ws_floats(L) * sizeof(float) &&
         !(((uintptr_t)ws & 15) || ((uintptr_t)out & 15) || ((uintptr_t)bias & 15) || ((uintptr_t)ep_a & 15) ||
           ((uintptr_t)ep_b & 15) || ((uintptr_t)ep_aux & 15)))

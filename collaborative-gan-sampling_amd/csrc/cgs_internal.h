@@ -106,6 +106,10 @@ __device__ __forceinline__ float epilogue_apply(float v, int mode, float a, floa
 }
 #endif
 
+int cgs_conv_smalln_f_ok(const CgsLayer& L, int B, int epilogue);
+size_t cgs_conv_smalln_f_ws_floats(const CgsLayer& L);
+int cgs_conv_smalln_f_launch(const CgsLayer& L, int B, const float* in, const float* w, const float* bias, float* out,
+                             int epilogue, float* ws, size_t ws_bytes, int prepacked, hipStream_t s);
 int cgs_conv_patch_ok(const CgsLayer& L, int epilogue);
 size_t cgs_conv_patch_ws_floats(const CgsLayer& L);
 int cgs_conv_patch_launch(const CgsLayer& L, int B, const float* in, const float* w, const float* bias, float* out, int epilogue,

@@ -90,6 +90,11 @@ def call(name, *args):
         raise CgsError(f"{name} failed ({rc}): {lib.cgs_last_error().decode()}")
 
 
+def last_kernel():
+    """Name of the kernel the last conv / deconv / linear dispatch launched (as rocprofv3 prints it)."""
+    return load().cgs_last_kernel().decode()
+
+
 def conv_ws_bytes(op, kh, kw, sh, sw, cin, cout):
     return int(load().cgs_conv_ws_bytes(op, kh, kw, sh, sw, cin, cout))
 

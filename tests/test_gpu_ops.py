@@ -40,6 +40,10 @@ CONV_CASES = [  # B,H,W,Cin,Cout,k,s
     (256, 16, 16, 32, 64, 5, 2),     # pixel-major, 8x8 grid, whole tiles per pixel
     (128, 6, 6, 32, 64, 4, 2),       # pixel-major with 4x4 kernels
     (3, 64, 64, 3, 64, 5, 2),        # dcgan64 d_h0: bwd-data = LDS-patch quad kernel (32x32 quads)
+    (8, 128, 128, 64, 3, 7, 1),      # c7s1-3 RGB head: stride-1 small-N VALU kernel (>= 512 tiles)
+    (2, 256, 256, 16, 1, 3, 1),      # same kernel, N=1, 3x3, one channel chunk
+    (32, 64, 64, 32, 4, 5, 1),       # same kernel, N=4
+    (2, 32, 32, 64, 3, 7, 1),        # too few tiles for it: N-padded MFMA path
     (2, 64, 32, 1, 32, 4, 2),        # 1 channel, 4x4 kernel, 32x16 quads -> global-load quad kernel (Ws % 32 != 0)
     (2, 16, 64, 2, 16, 5, 2),        # 2 channels, 8x32 quads: LDS-patch kernel with a single 16-channel chunk
 ]
@@ -55,6 +59,16 @@ def test_conv2d_fwd(B, H, W, Cin, Cout, k, s, epi):
         want = R.lrelu(want)
     got = K.conv2d_fwd(x.to(dev()), w.to(dev()), b.to(dev()), s, s, lib.EPI_LRELU if epi == "lrelu" else lib.EPI_NONE)
     assert got.shape == want.shape
+    close(got, want, 2e-5)
+
+
+def test_conv2d_smalln_head_tanh():
+    """c7s1-3 + tanh of the CycleGAN generator tail goes to conv_smalln_f_kernel with the tanh fused."""
+    from cgs_amd import kernels as K, lib
+    x, w, b = rnd((8, 128, 128, 64), 1), rnd((7, 7, 64, 3), 2, 0.05), rnd((3,), 3, 0.1)
+    want = torch.tanh(R.conv2d(x, w, b, 1, 1))
+    got = K.conv2d_fwd(x.to(dev()), w.to(dev()), b.to(dev()), 1, 1, lib.EPI_TANH)
+    assert lib.last_kernel().startswith("conv_smalln_f_kernel")
     close(got, want, 2e-5)
 
 
