@@ -338,11 +338,14 @@ int cgs_convt_quad_launch(const CgsLayer& L, int B, const float* in, const float
         }
     }
     constexpr int MT = 4;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static bool attr_done[64] = {};       // per device: the attribute belongs to the device's code object
+    int dev_ = 0;
+    (void)hipGetDevice(&dev_);
+    dev_ &= 63;
+    if (!attr_done[dev_]) {
         hipError_t e = hipFuncSetAttribute((const void*)convt_quad_mfma_kernel<MT>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         if (e != hipSuccess) return cgs_set_error(CGS_ELAUNCH, "convt_quad smem attr: %s", hipGetErrorString(e));
-        attr_done = true;
+        attr_done[dev_] = true;
     }
     const long total = (long)B * L.Hs * L.Ws;
     if (total == 0) return CGS_OK;

@@ -541,12 +541,15 @@ template <int BM, int BN, int NW, bool VEC, int TBK>
 static int launch_cfg(const IgemmParams& p, hipStream_t s) {
     constexpr size_t kloop_f = (size_t)2 * BM * (TBK + 4) + 2 * TBK * BN, stage_f = (size_t)NW * (BM / 2) * (BN / (NW / 2) + 4);
     constexpr size_t smem = (kloop_f > stage_f ? kloop_f : stage_f) * sizeof(float) + BM * sizeof(int);
-    static bool attr_done = false;
-    if (!attr_done) {
+    static bool attr_done[64] = {};       // per device: the attribute belongs to the device's code object
+    int dev_ = 0;
+    (void)hipGetDevice(&dev_);
+    dev_ &= 63;
+    if (!attr_done[dev_]) {
         hipError_t e = hipFuncSetAttribute((const void*)igemm_kernel<BM, BN, NW, VEC, TBK>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return cgs_set_error(CGS_ELAUNCH, "igemm smem attr: %s", hipGetErrorString(e));
-        attr_done = true;
+        attr_done[dev_] = true;
     }
     long maxM = 0;
     for (int i = 0; i < p.nclasses; ++i) {
