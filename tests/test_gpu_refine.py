@@ -187,6 +187,33 @@ def test_full_size_properties(arch, B, K):
     assert (osp == 1).all() and torch.allclose(ofp, f0 - 0.1 * grad, rtol=0, atol=1e-6)
 
 
+@pytest.mark.parametrize("arch,B,K", [("dcgan64", 1024, 2), ("dcgan32", 256, 4)])
+def test_two_batches_in_flight_match_sequential(arch, B, K):
+    """bench.py's default mode at BASELINE's full batch: two engines on two HIP streams refine concurrently (shared frozen
+    weights, per-stream packed-weight caches and workspaces).  Each must reproduce, bit for bit, what one engine computes
+    alone -- any cross-stream hazard (shared scratch, weight re-packing under a running kernel) would show up here."""
+    from cgs_amd.engine import RefineEngine
+    from cgs_amd.nets import to_device, ARCHS
+    d = dev()
+    P = to_device(N.init_params(arch, 2019, True), d)
+    rs = np.random.RandomState(5)
+    z = [torch.from_numpy(rs.uniform(-1, 1, (B, ARCHS[arch]["z_dim"])).astype(np.float32)).to(d) for _ in range(2)]
+    solo = RefineEngine(arch, P, B, d)
+    want = [[t.clone() for t in solo.refine_from_z(zi, K, 0.1)[:4]] for zi in z]
+    engines = [RefineEngine(arch, P, B, d) for _ in range(2)]
+    streams = [torch.cuda.Stream(d) for _ in range(2)]
+    torch.cuda.synchronize(d)
+    for rep in range(2):                      # second round: caches warm, both streams busy from the first launch
+        got = []
+        for e, st, zi in zip(engines, streams, z):
+            with torch.cuda.stream(st):
+                got.append(e.refine_from_z(zi, K, 0.1)[:4])
+        torch.cuda.synchronize(d)
+        for g, w in zip(got, want):
+            for a, b in zip(g, w):
+                assert torch.equal(a, b)
+
+
 def test_collaborative_fill_loop_on_device():
     """refine -> D-score -> MH accept -> fill (nsgan/GAN.py:398-426) driven by the device engine."""
     from cgs_amd.engine import RefineEngine
