@@ -227,6 +227,110 @@ int cgs_bn_train_lrelu_bwd_data(const float* dy, const float* x, const float* ga
 }
 
 
+
+// ------------------------------------------------------------------------------------------------
+// Synchronised batch statistics (one logical batch split over several GPUs; SURVEY.md 8e caveat).
+// The local reduction stops at per-channel SUMS in double; the caller all-reduces the 2*C doubles over the ranks
+// (RCCL) and the second half finishes the statistics from the global sums and the global row count.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_sums_kernel(const float* __restrict__ part, int G, int C, double* __restrict__ sums) {
+    __shared__ double red[2][16][17];
+    const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    double a = 0.0, b = 0.0;
+    if (c < C)
+        for (int g = sl; g < G; g += 16) { a += (double)part[((size_t)g * 2 + 0) * C + c]; b += (double)part[((size_t)g * 2 + 1) * C + c]; }
+    red[0][sl][cl] = a; red[1][sl][cl] = b;
+    __syncthreads();
+    if (sl != 0 || c >= C) return;
+    a = 0.0; b = 0.0;
+    for (int i = 0; i < 16; ++i) { a += red[0][i][cl]; b += red[1][i][cl]; }
+    sums[c] = a; sums[C + c] = b;
+}
+
+__global__ void bn_stats_from_sums_kernel(const double* __restrict__ sums, double Mtot, int C, const float* __restrict__ gamma,
+                                          const float* __restrict__ beta, float eps, float* __restrict__ stat,
+                                          float* __restrict__ mean_out, float* __restrict__ invstd_out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double mean = sums[c] / Mtot;
+    double var = sums[C + c] / Mtot - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float scale = gamma[c] * invstd;
+    stat[c] = (float)mean; stat[C + c] = invstd; stat[2 * C + c] = scale; stat[3 * C + c] = beta[c] - (float)mean * scale;
+    mean_out[c] = (float)mean; invstd_out[c] = invstd;
+}
+
+__global__ void bn_stat2_from_sums_kernel(const double* __restrict__ sums, double Mtot, int C, float* __restrict__ stat2) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    stat2[c] = (float)(sums[c] / Mtot); stat2[C + c] = (float)(sums[C + c] / Mtot);
+}
+
+static int bn_sync_check(const char* who, int M, int C, size_t ws_bytes, const void* sums) {
+    if (M <= 0 || C <= 0 || (C & 3)) return cgs_set_error(CGS_EINVAL, "%s: M=%d C=%d (C must be a multiple of 4)", who, M, C);
+    if (ws_bytes < cgs_bn_ws_bytes(M, C)) return cgs_set_error(CGS_EWORKSPACE, "%s: workspace %zu < %zu", who, ws_bytes, cgs_bn_ws_bytes(M, C));
+    if (!sums || ((uintptr_t)sums & 7)) return cgs_set_error(CGS_EINVAL, "%s: sums must be an 8-byte aligned [2][C] double buffer", who);
+    return CGS_OK;
+}
+
+int cgs_bn_sync_fwd_sums(const float* x, double* sums, int M, int C, void* ws, size_t ws_bytes, void* stream) {
+    if (int rc = bn_sync_check("bn sync fwd sums", M, C, ws_bytes, sums)) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const BnGeom g = bn_geom(M, C);
+    float* part = (float*)ws;
+    hipLaunchKernelGGL(bn_partial_kernel<0>, dim3(g.G), dim3(256), 0, s, x, nullptr, nullptr, 1.f, part, M, C, g.rows_per_block);
+    hipLaunchKernelGGL(bn_sums_kernel, dim3(cgs_ceil_div(C, 16)), dim3(256), 0, s, part, g.G, C, sums);
+    CGS_CHECK_LAUNCH("bn_sync_fwd_sums");
+    return CGS_OK;
+}
+
+int cgs_bn_sync_fwd_apply(const float* x, const float* gamma, const float* beta, float eps, float leak, const double* sums,
+                          long long M_total, float* y, float* mean, float* invstd, int M, int C, void* ws, size_t ws_bytes,
+                          void* stream) {
+    if (int rc = bn_sync_check("bn sync fwd apply", M, C, ws_bytes, sums)) return rc;
+    if (M_total < M) return cgs_set_error(CGS_EINVAL, "bn sync fwd apply: M_total %lld < local M %d", M_total, M);
+    hipStream_t s = (hipStream_t)stream;
+    float* stat = (float*)ws + (size_t)BN_MAX_BLOCKS * 2 * C;
+    hipLaunchKernelGGL(bn_stats_from_sums_kernel, dim3(cgs_ceil_div(C, 128)), dim3(128), 0, s, sums, (double)M_total, C, gamma, beta, eps, stat, mean, invstd);
+    const size_t n4 = (size_t)M * C / 4;
+    hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3(ew_blocks(n4)), dim3(256), 0, s, x, stat, leak, y, n4, C, n4);
+    CGS_CHECK_LAUNCH("bn_sync_fwd_apply");
+    return CGS_OK;
+}
+
+int cgs_bn_sync_bwd_sums(const float* dy, const float* x, const float* gamma, const float* beta, const float* mean,
+                         const float* invstd, float leak, double* sums, int M, int C, void* ws, size_t ws_bytes, void* stream) {
+    if (int rc = bn_sync_check("bn sync bwd sums", M, C, ws_bytes, sums)) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const BnGeom g = bn_geom(M, C);
+    float* part = (float*)ws;
+    float* stat = part + (size_t)BN_MAX_BLOCKS * 2 * C;
+    hipLaunchKernelGGL(bn_restat_kernel, dim3(cgs_ceil_div(C, 128)), dim3(128), 0, s, mean, invstd, gamma, beta, stat, C);
+    hipLaunchKernelGGL(bn_partial_kernel<1>, dim3(g.G), dim3(256), 0, s, x, dy, stat, leak, part, M, C, g.rows_per_block);
+    hipLaunchKernelGGL(bn_sums_kernel, dim3(cgs_ceil_div(C, 16)), dim3(256), 0, s, part, g.G, C, sums);
+    CGS_CHECK_LAUNCH("bn_sync_bwd_sums");
+    return CGS_OK;
+}
+
+int cgs_bn_sync_bwd_apply(const float* dy, const float* x, const float* gamma, const float* beta, const float* mean,
+                          const float* invstd, float leak, const double* sums, long long M_total, float* dx, int M, int C,
+                          void* ws, size_t ws_bytes, void* stream) {
+    if (int rc = bn_sync_check("bn sync bwd apply", M, C, ws_bytes, sums)) return rc;
+    if (M_total < M) return cgs_set_error(CGS_EINVAL, "bn sync bwd apply: M_total %lld < local M %d", M_total, M);
+    hipStream_t s = (hipStream_t)stream;
+    float* stat = (float*)ws + (size_t)BN_MAX_BLOCKS * 2 * C;
+    float* stat2 = stat + 4 * (size_t)C;
+    hipLaunchKernelGGL(bn_restat_kernel, dim3(cgs_ceil_div(C, 128)), dim3(128), 0, s, mean, invstd, gamma, beta, stat, C);
+    hipLaunchKernelGGL(bn_stat2_from_sums_kernel, dim3(cgs_ceil_div(C, 128)), dim3(128), 0, s, sums, (double)M_total, C, stat2);
+    const size_t n4 = (size_t)M * C / 4;
+    hipLaunchKernelGGL(bn_apply_bwd_kernel, dim3(ew_blocks(n4)), dim3(256), 0, s, dy, x, stat, stat2, leak, dx, n4, C, n4);
+    CGS_CHECK_LAUNCH("bn_sync_bwd_apply");
+    return CGS_OK;
+}
+
+
 // bias gradient db[c] (+)= sum_m dy[m][c]: the same two-stage deterministic column reduction
 __global__ void colsum_finalize_kernel(const float* __restrict__ part, int G, int C, float* __restrict__ db, int accumulate) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;

@@ -8,8 +8,10 @@ into the node-wide pool that the host-side accept/reject samplers consume: one a
 (``torch.distributed`` backend "nccl" = RCCL over xGMI on the GPU box; "gloo" in the CPU tests).
 
 Caveat: D normalises with BATCH statistics, so a logical batch of W*B samples split W ways is
-W independent B-batches, not one W*B batch.  That is the semantics here (and of the reference run at
-batch B); a sync-BN mode would all-reduce 2*C floats per bn layer per pass and is not implemented.
+W independent B-batches, not one W*B batch.  That is the default semantics here (and of the reference run at
+batch B).  ``RefineEngine(..., sync_bn=True)`` makes the W shards ONE logical batch instead: every bn pass of D
+all-reduces its 2*C per-channel sums (double) over the group between the two halves of the pass
+(cgs_bn_sync_*; tests/test_gpu_sync_bn.py checks two ranks against the unsplit batch).
 """
 import numpy as np
 import torch

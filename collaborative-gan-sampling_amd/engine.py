@@ -117,13 +117,61 @@ class _BnTrainLrelu(_Stage):
         self.invstd = torch.empty(shape[-1], dtype=torch.float32, device=dev)
         self.x = None
 
+    sync = None          # a BnSync: the batch is one shard of a logical batch spread over the ranks of a process group
+
     def fwd(self, x):
         self.x = x
-        K.bn_train_lrelu_fwd(x, self.gamma, self.beta, self.leak, out=self.out, stats=(self.mean, self.invstd))
+        if self.sync is None:
+            K.bn_train_lrelu_fwd(x, self.gamma, self.beta, self.leak, out=self.out, stats=(self.mean, self.invstd))
+            return self.out
+        M = x.numel() // x.shape[-1]
+        sums = self.sync.sums(x.shape[-1], x.device)
+        K.bn_sync_fwd_sums(x, sums)
+        self.sync.all_reduce(sums)
+        K.bn_sync_fwd_apply(x, self.gamma, self.beta, sums, self.sync.world * M, self.leak, out=self.out,
+                            stats=(self.mean, self.invstd))
         return self.out
 
     def bwd(self, dy):
-        return K.bn_train_lrelu_bwd_data(dy, self.x, self.gamma, self.beta, self.mean, self.invstd, self.leak, out=dy)
+        if self.sync is None:
+            return K.bn_train_lrelu_bwd_data(dy, self.x, self.gamma, self.beta, self.mean, self.invstd, self.leak, out=dy)
+        M = self.x.numel() // self.x.shape[-1]
+        sums = self.sync.sums(self.x.shape[-1], dy.device)
+        K.bn_sync_bwd_sums(dy, self.x, self.gamma, self.beta, self.mean, self.invstd, sums, self.leak)
+        self.sync.all_reduce(sums)
+        return K.bn_sync_bwd_apply(dy, self.x, self.gamma, self.beta, self.mean, self.invstd, sums, self.sync.world * M,
+                                   self.leak, out=dy)
+
+
+class BnSync:
+    """All-reduce of the per-channel batch-norm sums over a process group (one logical batch of W*B samples
+    split W ways reproduces the reference's whole-batch statistics, nsgan/GAN.py:175).  2*C doubles per bn layer and pass.
+    "nccl" (RCCL) reduces the device buffer in place; any other backend (gloo in the tests) goes through the host."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()):
+            raise L.CgsError("sync_bn needs an initialised torch.distributed process group")
+        self.dist, self.group = dist, group
+        self.world = dist.get_world_size(group)
+        self.on_device = dist.get_backend(group) == "nccl"
+        self._sums = {}
+
+    def sums(self, C, dev):
+        key = (C, dev)
+        if key not in self._sums:
+            self._sums[key] = torch.empty((2, C), dtype=torch.float64, device=dev)
+        return self._sums[key]
+
+    def all_reduce(self, sums):
+        if self.world == 1:
+            return
+        if self.on_device:
+            self.dist.all_reduce(sums, group=self.group)
+        else:
+            h = sums.cpu()
+            self.dist.all_reduce(h, group=self.group)
+            sums.copy_(h)
 
 
 class _InstNormAct(_Stage):
@@ -309,7 +357,7 @@ class Tape:
 class RefineEngine:
     """K-step collaborative refinement of a batch of G activation maps on one GPU."""
 
-    def __init__(self, arch, params, batch_size, device=None, use_graph=False):
+    def __init__(self, arch, params, batch_size, device=None, use_graph=False, sync_bn=None):
         self.A = ARCHS[arch] if isinstance(arch, str) else arch
         self.dev = torch.device(device if device is not None else "cuda:0")
         if self.dev.type != "cuda":
@@ -332,6 +380,21 @@ class RefineEngine:
             self.images = torch.empty((B,) + tuple(A["img"]), **f32)
         self.use_graph = use_graph
         self._graphs = {}
+        # sync_bn = True (default process group) or a process group: this engine's batch is one shard of a logical batch of
+        # world_size * batch_size samples; D's batch statistics are all-reduced so the result equals the unsplit batch's
+        self.sync_bn = None
+        if sync_bn is not None and sync_bn is not False:
+            if use_graph:
+                raise L.CgsError("sync_bn runs eagerly: the all-reduce between the two halves of a bn pass is not captured")
+            self.sync_bn = BnSync(None if sync_bn is True else sync_bn)
+
+            def walk(stages):
+                for st in stages:
+                    if isinstance(st, _BnTrainLrelu):
+                        st.sync = self.sync_bn
+                    if isinstance(st, _Residual):
+                        walk(st.inner)
+            walk(self.d.stages); walk(self.g_tail.stages)
 
     # -- pieces (sampling/collaborator.py:26-39) ------------------------------------------------
     def input_to_feature(self, z):

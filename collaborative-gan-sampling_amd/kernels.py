@@ -239,6 +239,51 @@ def bn_train_lrelu_bwd_data(dy, x, gamma, beta, mean, invstd, leak=LEAK, out=Non
     return dx
 
 
+# synchronised batch statistics: the reductions stop at per-channel sums (double) that the caller all-reduces over the ranks
+def bn_sync_fwd_sums(x, sums):
+    """sums[2, C] (float64, device) <- (sum x, sum x^2) over the local rows."""
+    _chk(x, "x")
+    C = x.shape[-1]
+    M = x.numel() // C
+    ws = _bn_workspace(M, C, x.device)
+    L.call("cgs_bn_sync_fwd_sums", _ptr(x), sums.data_ptr(), M, C, _ptr(ws), ws.numel() * 4, _stream())
+    return sums
+
+
+def bn_sync_fwd_apply(x, gamma, beta, sums, m_total, leak=LEAK, eps=BN_EPS, out=None, stats=None):
+    _chk(x, "x")
+    C = x.shape[-1]
+    M = x.numel() // C
+    y = out if out is not None else torch.empty_like(x)
+    mean, invstd = stats if stats is not None else (torch.empty(C, dtype=torch.float32, device=x.device),
+                                                    torch.empty(C, dtype=torch.float32, device=x.device))
+    ws = _bn_workspace(M, C, x.device)
+    L.call("cgs_bn_sync_fwd_apply", _ptr(x), _ptr(gamma), _ptr(beta), eps, leak, sums.data_ptr(), int(m_total), _ptr(y),
+           _ptr(mean), _ptr(invstd), M, C, _ptr(ws), ws.numel() * 4, _stream())
+    return y, mean, invstd
+
+
+def bn_sync_bwd_sums(dy, x, gamma, beta, mean, invstd, sums, leak=LEAK):
+    _chk(dy, "dy"); _chk(x, "x")
+    C = x.shape[-1]
+    M = x.numel() // C
+    ws = _bn_workspace(M, C, x.device)
+    L.call("cgs_bn_sync_bwd_sums", _ptr(dy), _ptr(x), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(invstd), leak,
+           sums.data_ptr(), M, C, _ptr(ws), ws.numel() * 4, _stream())
+    return sums
+
+
+def bn_sync_bwd_apply(dy, x, gamma, beta, mean, invstd, sums, m_total, leak=LEAK, out=None):
+    _chk(dy, "dy"); _chk(x, "x")
+    C = x.shape[-1]
+    M = x.numel() // C
+    dx = out if out is not None else torch.empty_like(x)
+    ws = _bn_workspace(M, C, x.device)
+    L.call("cgs_bn_sync_bwd_apply", _ptr(dy), _ptr(x), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(invstd), leak,
+           sums.data_ptr(), int(m_total), _ptr(dx), M, C, _ptr(ws), ws.numel() * 4, _stream())
+    return dx
+
+
 _in_ws = {}
 
 

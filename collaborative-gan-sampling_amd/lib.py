@@ -15,6 +15,7 @@ EPI_RELU_BWD_AFFINE, EPI_LRELU_BWD, EPI_TANH_BWD = 4, 5, 6
 CONV_FWD, CONV_BWD_DATA, DECONV_FWD, DECONV_BWD_DATA = 0, 1, 2, 3
 
 _p, _i, _f, _z = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+_ll = C.c_longlong
 
 # name -> (restype, argtypes); mirrors include/cgs_hip.h one to one
 SIGNATURES = {
@@ -32,6 +33,10 @@ SIGNATURES = {
     "cgs_bn_ws_bytes": (_z, [_i, _i]),
     "cgs_bn_train_lrelu_fwd": (_i, [_p, _p, _p, _f, _f, _p, _p, _p, _i, _i, _p, _z, _p]),
     "cgs_bn_train_lrelu_bwd_data": (_i, [_p] * 6 + [_f, _p, _i, _i, _p, _z, _p]),
+    "cgs_bn_sync_fwd_sums": (_i, [_p, _p, _i, _i, _p, _z, _p]),
+    "cgs_bn_sync_fwd_apply": (_i, [_p, _p, _p, _f, _f, _p, _ll, _p, _p, _p, _i, _i, _p, _z, _p]),
+    "cgs_bn_sync_bwd_sums": (_i, [_p] * 6 + [_f, _p, _i, _i, _p, _z, _p]),
+    "cgs_bn_sync_bwd_apply": (_i, [_p] * 6 + [_f, _p, _ll, _p, _i, _i, _p, _z, _p]),
     "cgs_instnorm_ws_bytes": (_z, [_i, _i, _i]),
     "cgs_instnorm_lrelu_fwd": (_i, [_p, _p, _p, _f, _f, _p, _p, _p, _i, _i, _i, _p, _z, _p]),
     "cgs_instnorm_lrelu_bwd_data": (_i, [_p] * 6 + [_f, _p, _i, _i, _i, _p, _z, _p]),

@@ -123,6 +123,25 @@ int cgs_bn_train_lrelu_bwd_data(const float* dy, const float* x, const float* ga
                                 const float* mean, const float* invstd, float leak, float* dx, int M, int C,
                                 void* ws, size_t ws_bytes, void* stream);
 
+/* Synchronised batch statistics: ONE logical batch whose rows are split over several GPUs (the reference computes D's
+ * batch norm over the whole batch, nsgan/GAN.py:175 -> nsgan/ops.py:19-26).  Each pass is cut at the per-channel sums:
+ *   cgs_bn_sync_fwd_sums : sums[0..C) = sum_m x, sums[C..2C) = sum_m x^2 over the LOCAL rows, in double
+ *   -- caller: all-reduce(SUM) of the 2*C doubles over the ranks (RCCL) --
+ *   cgs_bn_sync_fwd_apply: statistics from the global sums and M_total = total rows; y, mean, invstd as cgs_bn_train_lrelu_fwd
+ *   cgs_bn_sync_bwd_sums : sums = {sum dy', sum dy'*xhat} over the local rows (mean / invstd = the saved global statistics)
+ *   -- all-reduce --
+ *   cgs_bn_sync_bwd_apply: dx as cgs_bn_train_lrelu_bwd_data with the global means.
+ * With one rank (M_total = M) the results equal the unsplit entry points'.  ws: cgs_bn_ws_bytes(M, C). */
+int cgs_bn_sync_fwd_sums(const float* x, double* sums, int M, int C, void* ws, size_t ws_bytes, void* stream);
+int cgs_bn_sync_fwd_apply(const float* x, const float* gamma, const float* beta, float eps, float leak, const double* sums,
+                          long long M_total, float* y, float* mean, float* invstd, int M, int C,
+                          void* ws, size_t ws_bytes, void* stream);
+int cgs_bn_sync_bwd_sums(const float* dy, const float* x, const float* gamma, const float* beta, const float* mean,
+                         const float* invstd, float leak, double* sums, int M, int C, void* ws, size_t ws_bytes, void* stream);
+int cgs_bn_sync_bwd_apply(const float* dy, const float* x, const float* gamma, const float* beta, const float* mean,
+                          const float* invstd, float leak, const double* sums, long long M_total, float* dx, int M, int C,
+                          void* ws, size_t ws_bytes, void* stream);
+
 /* Instance norm (+ lrelu; leak = 0 gives relu, 1 plain): statistics over the HW pixels of every (sample, channel);
  * x is [B,HW,C].  CycleGAN-style generators / PatchGAN discriminators (BASELINE config 5; the reference ships no
  * code for them).  mean / invstd are [B,C].  ws: cgs_instnorm_ws_bytes(B, HW, C). */
