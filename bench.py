@@ -135,6 +135,9 @@ def main():
     ap.add_argument("--streams", type=int, default=2,
                     help="z-batches in flight per GPU, one engine + HIP stream each: the tail / small kernels of one "
                          "batch overlap the big kernels of the other (measured: 1 -> 5040, 2 -> 5500, 3 -> 5460 samples/s)")
+    ap.add_argument("--sync-bn", action="store_true",
+                    help="treat the N ranks' batches as ONE logical batch of N*B samples: all-reduce D's batch-norm sums "
+                         "(needs the torch.distributed launch; eager only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--by-layer", action="store_true", help="key the per-kernel timing records by layer shape too (diagnostic)")
     args = ap.parse_args()
@@ -163,7 +166,10 @@ def main():
     Ksteps = args.refine_steps or (50 if args.arch == "mnist" else 20)
     A = nets.ARCHS[args.arch]
     P = nets.init_params(args.arch, dev, seed=2019)                     # same frozen weights on every rank
-    engines = [RefineEngine(args.arch, P, B, dev, use_graph=args.graph) for _ in range(max(1, args.streams))]
+    if args.sync_bn and not use_dist:
+        raise SystemExit("--sync-bn needs the torch.distributed launch (python -m torch.distributed.run ... bench.py)")
+    engines = [RefineEngine(args.arch, P, B, dev, use_graph=args.graph, sync_bn=True if args.sync_bn else None)
+               for _ in range(max(1, args.streams))]
     streams = [torch.cuda.Stream(dev) for _ in engines] if len(engines) > 1 else [torch.cuda.current_stream(dev)]
     eng = engines[0]
     n_batches = args.steps + args.warmup
@@ -228,7 +234,7 @@ def main():
                                    f"batch {B}/GPU, K={Ksteps}, momentum rate {args.rate}, refine at feature "
                                    f"{list(A['feature'])}, random-init weights, z~U(-1,1) seed 2019+rank",
                        "global_batch": world * B, "refine_steps": Ksteps, "parallelism": f"z-shards x{world} + RCCL all-gather of the pool" if world > 1 else "single GPU",
-                       "hipgraph": bool(args.graph), "batches_in_flight": len(engines)},
+                       "hipgraph": bool(args.graph), "batches_in_flight": len(engines), "sync_bn": bool(args.sync_bn)},
             "algorithmic_tflops": round(value * flops_per_sample / 1e12, 2),
         }
         if prof:
