@@ -167,14 +167,20 @@ __global__ __launch_bounds__(64 * NW, 2) void igemm_kernel(IgemmParams p) {
 
     // block id -> (m-tile, n-tile); class = blockIdx.y (heaviest class first).  Measured and rejected: computing all
     // parity classes of a tile back to back in one block (FETCH_SIZE only -10 %: the patch does not survive in the
-    // 4 MiB L2 across a class pass; 2-4 % slower).  An XCD-aware id remap (contiguous
-    // tile runs per XCD, classes interleaved) was measured: within +-0.5 % for the remap alone, 25-50 % SLOWER with
-    // the classes interleaved -- this kernel is MFMA-bound and its fetch latency is already hidden.
+    // 4 MiB L2 across a class pass; 2-4 % slower); running the s*s classes of an m-tile as consecutive workgroups of one
+    // XCD (FETCH_SIZE of the 32x32 transposed layers 670 -> 270 MB, but +30 % on the small-grid layers whose four weight
+    // sets then compete for the L2, and 13 % SLOWER end to end: the kernel is MFMA-bound, its fetch latency is hidden).
+    // Workgroups go to the 8 XCDs round-robin by id, each XCD with its own L2.  With id = mb * nblk_n + nb the n-tiles of
+    // one m-tile (same A rows) land on DIFFERENT XCDs and every XCD streams the whole input: measured 26x the input bytes
+    // from HBM for the 8x8 256->512 layer.  Decode per XCD instead: XCD x = id % 8 owns the m-tiles = x (mod 8) and runs
+    // their n-tiles back to back; in the LPT order (m-tile = pixel rank * groups + image group) that also gives an XCD
+    // the same image groups for every pixel, so the tap overlap between neighbouring pixels hits in its L2 too.
     const int nblk_n = p.Np / BN;
     const unsigned wi = blockIdx.x;
+    const unsigned xcd = wi & 7u, q = wi >> 3;
+    const int nb = (int)(q % (unsigned)nblk_n);
     const int cls_i = blockIdx.y;
-    const int nb = (int)(wi % (unsigned)nblk_n);
-    int mb = (int)(wi / (unsigned)nblk_n);
+    int mb = (int)(q / (unsigned)nblk_n) * 8 + (int)xcd;
     const IgemmClass& c = p.cls[cls_i];
     const int RC = c.R * c.C;
     const int M = p.B * RC;
@@ -557,7 +563,7 @@ static int launch_cfg(const IgemmParams& p, hipStream_t s) {
         if (m > maxM) maxM = m;
     }
     if (maxM == 0) return CGS_OK;
-    const long gx = (maxM + BM - 1) / BM * (p.Np / BN);
+    const long gx = ((maxM + BM - 1) / BM + 7) / 8 * 8 * (p.Np / BN);      // m-tiles padded to the 8 XCDs (see the id decode)
     if (gx > 0x7fffffffL) return cgs_set_error(CGS_EINVAL, "igemm: grid too large");
     hipLaunchKernelGGL((igemm_kernel<BM, BN, NW, VEC, TBK>), dim3((unsigned)gx, p.nclasses, p.splitk > 1 ? p.splitk : 1), dim3(64 * NW), smem, s, p);
     CGS_CHECK_LAUNCH("igemm");

@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""rocprofv3 PMC passes -> profiles/traffic.json (what bench.py reports as roofline.traffic).
+
+    python tools/make_traffic_json.py <FETCH_SIZE counter_collection.csv> <WRITE_SIZE counter_collection.csv> <tag>
+
+Per kernel name: launches, average FETCH_SIZE / WRITE_SIZE (KB, as rocprofv3 prints them) and the HBM-side bytes per launch
+= 2 * FETCH_SIZE + WRITE_SIZE (KB -> bytes; FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md, HBM section:
+the loads are 16 B per lane).  Also writes trimmed copies of the two CSVs (conv-family kernels only) under profiles/."""
+import collections
+import csv
+import json
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEEP = ("igemm_kernel", "convt_quad", "conv_patch", "conv_smalln", "convt_smalln")
+
+
+def short(name):
+    name = re.sub(r"^void ", "", name)
+    return re.sub(r"\(.*\)$", "", name)
+
+
+def load(path, counter):
+    acc, rows = collections.defaultdict(list), []
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != counter:
+            continue
+        acc[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+        if any(k in r["Kernel_Name"] for k in KEEP):
+            rows.append(r)
+    return acc, rows
+
+
+def main():
+    fpath, wpath, tag = sys.argv[1], sys.argv[2], sys.argv[3]
+    F, frows = load(fpath, "FETCH_SIZE")
+    W, wrows = load(wpath, "WRITE_SIZE")
+    out = {}
+    for k in F:
+        if not any(s in k for s in KEEP) and "pack" not in k:
+            continue
+        f, w = sum(F[k]) / len(F[k]), sum(W.get(k, [0.0])) / max(1, len(W.get(k, [])))
+        out[k] = {"launches": len(F[k]), "FETCH_SIZE_KB_avg": round(f, 1), "WRITE_SIZE_KB_avg": round(w, 1),
+                  "hbm_bytes_per_launch_corrected": int(round((2 * f + w) * 1024))}
+    json.dump(out, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
+    for rows, name in ((frows, "fetch_size"), (wrows, "write_size")):
+        with open(os.path.join(ROOT, "profiles", f"{tag}_pmc_{name}.csv"), "w", newline="") as fh:
+            wr = csv.DictWriter(fh, fieldnames=list(rows[0].keys()))
+            wr.writeheader(); wr.writerows(rows)
+    for k, v in out.items():
+        print(f"{k:50s} x{v['launches']:4d}  {v['hbm_bytes_per_launch_corrected'] / 1e6:9.1f} MB / launch")
+
+
+if __name__ == "__main__":
+    main()
