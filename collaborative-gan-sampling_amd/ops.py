@@ -94,51 +94,69 @@ def constant_initializer(value):
 
 
 # ----------------------------------------------------------------------------- autograd glue
-def _no_wgrad(ctx_needs, what):
-    if any(ctx_needs):
-        raise L.CgsError(f"{what}: weight gradients are not part of the refinement path "
-                         "(frozen weights, sampling/collaborator.py:31); detach the parameters")
+# Input gradients are the refinement path (frozen weights, sampling/collaborator.py:31).  Parameter gradients are
+# produced only for parameters that require grad (the D shaping step / training callers, nsgan/GAN.py:141-146): the layer
+# input is kept for them only then, so the refinement path saves nothing extra.
+def _keep(x, *params):
+    return x if any(p.requires_grad for p in params) else None
 
 
 class _Conv2d(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, sh, sw):
-        ctx.save_for_backward(w)
+        x = x.contiguous()
+        ctx.save_for_backward(w, _keep(x, w))
         ctx.hw, ctx.s = (x.shape[1], x.shape[2]), (sh, sw)
-        return K.conv2d_fwd(x.contiguous(), w, b, sh, sw)
+        return K.conv2d_fwd(x, w, b, sh, sw)
 
     @staticmethod
     def backward(ctx, dy):
-        _no_wgrad(ctx.needs_input_grad[1:3], "conv2d")
-        (w,) = ctx.saved_tensors
-        return K.conv2d_bwd_data(dy.contiguous(), w, ctx.hw, *ctx.s), None, None, None, None
+        w, x = ctx.saved_tensors
+        dy = dy.contiguous()
+        nx, nw, nb = ctx.needs_input_grad[:3]
+        dw = K.conv2d_bwd_weight(x, dy, w.shape[0], w.shape[1], *ctx.s) if nw else None
+        db = K.bias_grad(dy) if nb else None
+        dx = K.conv2d_bwd_data(dy, w, ctx.hw, *ctx.s) if nx else None
+        return dx, dw, db, None, None
 
 
 class _Deconv2d(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, ho, wo, sh, sw):
-        ctx.save_for_backward(w)
+        x = x.contiguous()
+        ctx.save_for_backward(w, _keep(x, w))
         ctx.hw, ctx.s = (x.shape[1], x.shape[2]), (sh, sw)
-        return K.deconv2d_fwd(x.contiguous(), w, b, (ho, wo), sh, sw)
+        return K.deconv2d_fwd(x, w, b, (ho, wo), sh, sw)
 
     @staticmethod
     def backward(ctx, dy):
-        _no_wgrad(ctx.needs_input_grad[1:3], "deconv2d")
-        (w,) = ctx.saved_tensors
-        return K.deconv2d_bwd_data(dy.contiguous(), w, ctx.hw, *ctx.s), None, None, None, None, None, None
+        w, x = ctx.saved_tensors
+        dy = dy.contiguous()
+        nx, nw, nb = ctx.needs_input_grad[:3]
+        # w is the HWIO filter of the conv this op is the adjoint of (big = output side): its gradient is that conv's
+        # filter gradient with the roles swapped -- the conv's input is dy, its output gradient is x
+        dw = K.conv2d_bwd_weight(dy, x, w.shape[0], w.shape[1], *ctx.s) if nw else None
+        db = K.bias_grad(dy) if nb else None
+        dx = K.deconv2d_bwd_data(dy, w, ctx.hw, *ctx.s) if nx else None
+        return dx, dw, db, None, None, None, None
 
 
 class _Linear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b):
-        ctx.save_for_backward(w)
-        return K.linear_fwd(x.contiguous(), w, b)
+        x = x.contiguous()
+        ctx.save_for_backward(w, _keep(x, w))
+        return K.linear_fwd(x, w, b)
 
     @staticmethod
     def backward(ctx, dy):
-        _no_wgrad(ctx.needs_input_grad[1:3], "linear")
-        (w,) = ctx.saved_tensors
-        return K.linear_bwd_data(dy.contiguous(), w), None, None
+        w, x = ctx.saved_tensors
+        dy = dy.contiguous()
+        nx, nw, nb = ctx.needs_input_grad[:3]
+        dw = K.linear_bwd_weight(x, dy) if nw else None
+        db = K.bias_grad(dy) if nb else None
+        dx = K.linear_bwd_data(dy, w) if nx else None
+        return dx, dw, db
 
 
 class _BnTrain(torch.autograd.Function):
@@ -153,9 +171,13 @@ class _BnTrain(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy, _dm, _di):
-        _no_wgrad(ctx.needs_input_grad[1:3], "bn")
         x, gamma, beta, mean, invstd = ctx.saved_tensors
-        return K.bn_train_lrelu_bwd_data(dy.contiguous(), x, gamma, beta, mean, invstd, ctx.leak), None, None, None
+        dx = K.bn_train_lrelu_bwd_data(dy.contiguous(), x, gamma, beta, mean, invstd, ctx.leak)
+        dgamma = dbeta = None
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(beta)
+            K.bn_train_param_grads(x, dgamma, dbeta)          # from the sums the backward-data call just left in its workspace
+        return dx, dgamma, dbeta, None
 
 
 class _Affine(torch.autograd.Function):
