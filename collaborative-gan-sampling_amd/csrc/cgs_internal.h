@@ -69,6 +69,7 @@ struct IgemmParams {
     int pix_major;       // GEMM rows ordered (pixel, image) instead of (image, pixel): enables zero-tap skipping
     int splitk;          // > 1: blockIdx.z splits the K tiles; raw partial tiles go to slab, reduced by a second kernel
     float* slab;         // [class][split][M_c][Np]
+    int xcd_map;         // block id -> (XCD, local index) decode: an m-tile's n-tiles run on one XCD (see igemm_kernel)
     int lpt;             // pixel-major only: m-tiles visit the pixels in perm[] order (most valid taps first)
     int nclasses;
     IgemmClass cls[CGS_MAX_CLASSES];

@@ -177,10 +177,16 @@ __global__ __launch_bounds__(64 * NW, 2) void igemm_kernel(IgemmParams p) {
     // the same image groups for every pixel, so the tap overlap between neighbouring pixels hits in its L2 too.
     const int nblk_n = p.Np / BN;
     const unsigned wi = blockIdx.x;
-    const unsigned xcd = wi & 7u, q = wi >> 3;
-    const int nb = (int)(q % (unsigned)nblk_n);
     const int cls_i = blockIdx.y;
-    int mb = (int)(q / (unsigned)nblk_n) * 8 + (int)xcd;
+    int nb, mb;
+    if (p.xcd_map) {
+        const unsigned xcd = wi & 7u, q = wi >> 3;
+        nb = (int)(q % (unsigned)nblk_n);
+        mb = (int)(q / (unsigned)nblk_n) * 8 + (int)xcd;
+    } else {          // few m-tiles (fc layers, small batches): spread the n-tiles over the XCDs instead of idling most of them
+        nb = (int)(wi % (unsigned)nblk_n);
+        mb = (int)(wi / (unsigned)nblk_n);
+    }
     const IgemmClass& c = p.cls[cls_i];
     const int RC = c.R * c.C;
     const int M = p.B * RC;
@@ -491,10 +497,23 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(IgemmParams p) {
     const int nq = p.Np / 4;
     const long total = (long)M * nq;
     const float* slab = p.slab + c.slab_off;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int m = (int)(i / nq), n = (int)(i - (long)m * nq) * 4;
+    // four adjacent lanes share one output quad: lane g adds the slabs g, g+4, ... in order and the four partial sums are
+    // combined as (s0 + s1) + (s2 + s3) -- a fixed tree, so the result does not depend on the launch geometry
+    const int g = threadIdx.x & 3;
+    const long stride = (long)gridDim.x * (blockDim.x >> 2);
+    const long total_pad = (total + stride - 1) / stride * stride;          // every lane takes part in the shuffles
+    for (long i = (long)blockIdx.x * (blockDim.x >> 2) + (threadIdx.x >> 2); i < total_pad; i += stride) {
+        const bool live = i < total;
+        const int m = live ? (int)(i / nq) : 0, n = live ? (int)(i - (long)m * nq) * 4 : 0;
         f32x4 a = {0.f, 0.f, 0.f, 0.f};
-        for (int sidx = 0; sidx < p.splitk; ++sidx) a += *(const f32x4*)(slab + ((size_t)sidx * M + m) * p.Np + n);
+        if (live)
+            for (int sidx = g; sidx < p.splitk; sidx += 4) a += *(const f32x4*)(slab + ((size_t)sidx * M + m) * p.Np + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            a[e] += __shfl_xor(a[e], 1);
+            a[e] += __shfl_xor(a[e], 2);
+        }
+        if (!live || g != 0) continue;
         int b, r, cc, rem;
         if (p.pix_major) { rem = m / p.B; b = m - rem * p.B; } else { b = m / RC; rem = m - b * RC; }
         r = rem / c.C; cc = rem - r * c.C;
@@ -563,14 +582,17 @@ static int launch_cfg(const IgemmParams& p, hipStream_t s) {
         if (m > maxM) maxM = m;
     }
     if (maxM == 0) return CGS_OK;
-    const long gx = ((maxM + BM - 1) / BM + 7) / 8 * 8 * (p.Np / BN);      // m-tiles padded to the 8 XCDs (see the id decode)
+    const long mtiles = (maxM + BM - 1) / BM;
+    IgemmParams q = p;
+    q.xcd_map = (mtiles % 8 == 0 || mtiles >= 64) ? 1 : 0;        // per-XCD decode only where it keeps the 8 XCDs evenly loaded
+    const long gx = (q.xcd_map ? (mtiles + 7) / 8 * 8 : mtiles) * (p.Np / BN);
     if (gx > 0x7fffffffL) return cgs_set_error(CGS_EINVAL, "igemm: grid too large");
-    hipLaunchKernelGGL((igemm_kernel<BM, BN, NW, VEC, TBK>), dim3((unsigned)gx, p.nclasses, p.splitk > 1 ? p.splitk : 1), dim3(64 * NW), smem, s, p);
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, NW, VEC, TBK>), dim3((unsigned)gx, p.nclasses, p.splitk > 1 ? p.splitk : 1), dim3(64 * NW), smem, s, q);
     CGS_CHECK_LAUNCH("igemm");
     if (p.splitk > 1) {
         long tot = 0;
         for (int i = 0; i < p.nclasses; ++i) { long t = (long)p.B * p.cls[i].R * p.cls[i].C * (p.Np / 4); if (t > tot) tot = t; }
-        unsigned rb = (unsigned)((tot + 255) / 256 > 2048 ? 2048 : (tot + 255) / 256);
+        unsigned rb = (unsigned)((tot + 63) / 64 > 4096 ? 4096 : (tot + 63) / 64);       // 64 output quads per 256-thread block
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rb, p.nclasses), dim3(256), 0, s, p);
         CGS_CHECK_LAUNCH("splitk_reduce");
     }
