@@ -69,12 +69,20 @@ struct IgemmParams {
     int pix_major;       // GEMM rows ordered (pixel, image) instead of (image, pixel): enables zero-tap skipping
     int splitk;          // > 1: blockIdx.z splits the K tiles; raw partial tiles go to slab, reduced by a second kernel
     float* slab;         // [class][split][M_c][Np]
+    int tap_parity;      // VEC K order visits the taps even offsets first, then odd, per axis (stride-2 F direction)
     int xcd_map;         // block id -> (XCD, local index) decode: an m-tile's n-tiles run on one XCD (see igemm_kernel)
     int lpt;             // pixel-major only: m-tiles visit the pixels in perm[] order (most valid taps first)
     int nclasses;
     IgemmClass cls[CGS_MAX_CLASSES];
     unsigned char perm[CGS_MAX_CLASSES][64];   // per class: base pixels sorted by descending valid-tap count
 };
+
+// i-th tap visited along one axis of an n-tap kernel: natural order, or evens then odds
+__host__ __device__ inline int cgs_tap_order(int i, int n, int parity_first) {
+    if (!parity_first) return i;
+    const int ne = (n + 1) >> 1;
+    return i < ne ? 2 * i : 2 * (i - ne) + 1;
+}
 
 // geometry builders (igemm.hip)
 void cgs_geom_F(const CgsLayer& L, IgemmParams& p);

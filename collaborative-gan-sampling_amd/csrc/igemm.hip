@@ -39,6 +39,10 @@ void cgs_geom_F(const CgsLayer& L, IgemmParams& p) {
     p.Hin = L.Hb; p.Win = L.Wb; p.Cred = L.Cb;
     p.Hout = L.Hs; p.Wout = L.Ws; p.N = L.Cs; p.Np = cgs_round_up(L.Cs, 64);
     p.S = L.sh; p.So = 1; p.dstep = 1; p.kstep = 1; p.nclasses = 1;
+    // parity-first tap order (see igemm_kernel) where tiles are runs of neighbouring pixels; the small grids that run
+    // pixel-major (one pixel of 128 images per tile, <= 64 base pixels) gain nothing from it and measured 1-4 % slower.
+    // Decided from the layer geometry alone, so a packed-weight workspace stays valid for every batch size.
+    p.tap_parity = (L.sh == 2 && L.sw == 2 && L.Hs * L.Ws > 64) ? 1 : 0;
     IgemmClass& c = p.cls[0];
     c.R = L.Hs; c.C = L.Ws; c.py = 0; c.px = 0; c.nty = L.kh; c.ntx = L.kw;
     c.dy0 = -cgs_same_pad_before(L.Hb, L.kh, L.sh); c.dx0 = -cgs_same_pad_before(L.Wb, L.kw, L.sw);
@@ -49,6 +53,7 @@ void cgs_geom_T(const CgsLayer& L, IgemmParams& p) {
     p.Hin = L.Hs; p.Win = L.Ws; p.Cred = L.Cs;
     p.Hout = L.Hb; p.Wout = L.Wb; p.N = L.Cb; p.Np = cgs_round_up(L.Cb, 64);
     p.S = 1; p.So = L.sh; p.dstep = -1; p.kstep = L.sh; p.nclasses = L.sh * L.sw;
+    p.tap_parity = 0;      // consecutive taps of a parity class already read neighbouring input pixels
     const int pt = cgs_same_pad_before(L.Hb, L.kh, L.sh), pl = cgs_same_pad_before(L.Wb, L.kw, L.sw);
     int off = 0;
     for (int py = 0; py < L.sh; ++py)
@@ -89,15 +94,17 @@ __global__ void pack_weights_kernel(IgemmParams p, const float* __restrict__ w, 
         const int k = (int)((i >> 2) / p.Np) * 4 + e;
         float v = 0.f;
         if (k < c.K && n < p.N) {
-            int t, ci;
+            int t, ci, ta, tb;
             if ((p.Cred % BK) == 0) {      // K order (32-channel chunk, tap, channel in chunk): see igemm_kernel
                 const int ntaps = c.nty * c.ntx;
                 const int kt = k / BK, chunk = kt / ntaps;
                 t = kt - chunk * ntaps; ci = chunk * BK + (k - kt * BK);
+                ta = t / c.ntx; tb = t - ta * c.ntx;
+                ta = cgs_tap_order(ta, c.nty, p.tap_parity); tb = cgs_tap_order(tb, c.ntx, p.tap_parity);
             } else {
                 t = k / p.Cred; ci = k - t * p.Cred;
+                ta = t / c.ntx; tb = t - ta * c.ntx;
             }
-            const int ta = t / c.ntx, tb = t - ta * c.ntx;
             const int tap = (c.ky0 + ta * p.kstep) * kw + (c.kx0 + tb * p.kstep);
             const size_t src = dirT ? ((size_t)tap * Cb + n) * Cs + ci      // reduce over Cs, n indexes Cb
                                     : ((size_t)tap * Cb + ci) * Cs + n;     // reduce over Cb, n indexes Cs
@@ -148,7 +155,9 @@ __device__ __forceinline__ void epilogue_rows(const IgemmParams& p, const float*
 }
 
 // NW waves per block, arranged 2 (M) x NW/2 (N); wave tile (BM/2) x (BN/(NW/2)).
-template <int BM, int BN, int NW, bool VEC, int TBK>
+// PAR: parity-first tap order (a compile-time variant: the extra scalar decode slowed the natural-order layers by ~0.8 %
+// when it was a run-time flag).
+template <int BM, int BN, int NW, bool VEC, int TBK, bool PAR>
 __global__ __launch_bounds__(64 * NW, 2) void igemm_kernel(IgemmParams p) {
     constexpr int BK = TBK;                       // K tile (shadows the packing granule; TBK divides it)
     constexpr int LDA = BK + 4;                   // padded A row (floats): keeps the b128 fragment reads conflict-free
@@ -271,13 +280,18 @@ __global__ __launch_bounds__(64 * NW, 2) void igemm_kernel(IgemmParams p) {
     // The 25 (9/6/6/4) taps of a tile re-read one input patch; with the taps inner only a 32-channel slice of the
     // patch is live at a time, so the working set of an XCD's resident blocks fits its 4 MiB L2 and the tap
     // re-reads hit there instead of going out to the Infinity Cache / HBM.
+    // Stride-2 forward direction: the taps are visited even offsets first, then odd, per axis (cgs_tap_order).  Taps of one
+    // (row, column) parity read the SAME input pixels shifted by whole output pixels, taps of different parity read
+    // disjoint pixels, so a block's live set is one parity quarter of its patch (23 KB instead of 78 KB per 32 channels)
+    // and the quarter is used up before the next one is touched.
     const int ntaps = c.nty * c.ntx;
     // first K tile >= kt whose tap is inside the image for this tile (nk if none)
     auto next_chunk = [&](int kt) -> int {
         if (!skip_ok) return kt;
         while (kt < nk) {
             const int t = kt % ntaps;
-            const int ta = t / c.ntx, tb = t - ta * c.ntx;
+            const int ia = t / c.ntx, ib = t - ia * c.ntx;
+            const int ta = cgs_tap_order(ia, c.nty, PAR), tb = cgs_tap_order(ib, c.ntx, PAR);
             const int iy = u_iy + ta * p.dstep, ix = u_ix + tb * p.dstep;
             if ((unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win) break;
             ++kt;
@@ -295,7 +309,8 @@ __global__ __launch_bounds__(64 * NW, 2) void igemm_kernel(IgemmParams p) {
         if constexpr (VEC) {                                                                                    \
             const int chunk_ = (kt_) / ntaps, t = (kt_) - chunk_ * ntaps;                                       \
             const int ci = chunk_ * BK + aq * 4;                                                                \
-            const int ta = t / c.ntx, tb = t - ta * c.ntx;                                                      \
+            const int ia_ = t / c.ntx, ib_ = t - ia_ * c.ntx;                                                   \
+            const int ta = cgs_tap_order(ia_, c.nty, PAR), tb = cgs_tap_order(ib_, c.ntx, PAR);                 \
             const int dy = ta * p.dstep, dx = tb * p.dstep;                                                     \
             _Pragma("unroll") for (int i = 0; i < AI; ++i) {                                                    \
                 const int iy = a_iy[i] + dy, ix = a_ix[i] + dx;                                                 \
@@ -562,7 +577,7 @@ size_t cgs_igemm_splitk_bytes(const IgemmParams& p) {
     return n * sizeof(float);
 }
 
-template <int BM, int BN, int NW, bool VEC, int TBK>
+template <int BM, int BN, int NW, bool VEC, int TBK, bool PAR = false>
 static int launch_cfg(const IgemmParams& p, hipStream_t s) {
     constexpr size_t kloop_f = (size_t)2 * BM * (TBK + 4) + 2 * TBK * BN, stage_f = (size_t)NW * (BM / 2) * (BN / (NW / 2) + 4);
     constexpr size_t smem = (kloop_f > stage_f ? kloop_f : stage_f) * sizeof(float) + BM * sizeof(int);
@@ -571,7 +586,7 @@ static int launch_cfg(const IgemmParams& p, hipStream_t s) {
     (void)hipGetDevice(&dev_);
     dev_ &= 63;
     if (!attr_done[dev_]) {
-        hipError_t e = hipFuncSetAttribute((const void*)igemm_kernel<BM, BN, NW, VEC, TBK>,
+        hipError_t e = hipFuncSetAttribute((const void*)igemm_kernel<BM, BN, NW, VEC, TBK, PAR>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return cgs_set_error(CGS_ELAUNCH, "igemm smem attr: %s", hipGetErrorString(e));
         attr_done[dev_] = true;
@@ -587,7 +602,7 @@ static int launch_cfg(const IgemmParams& p, hipStream_t s) {
     q.xcd_map = (mtiles % 8 == 0 || mtiles >= 64) ? 1 : 0;        // per-XCD decode only where it keeps the 8 XCDs evenly loaded
     const long gx = (q.xcd_map ? (mtiles + 7) / 8 * 8 : mtiles) * (p.Np / BN);
     if (gx > 0x7fffffffL) return cgs_set_error(CGS_EINVAL, "igemm: grid too large");
-    hipLaunchKernelGGL((igemm_kernel<BM, BN, NW, VEC, TBK>), dim3((unsigned)gx, p.nclasses, p.splitk > 1 ? p.splitk : 1), dim3(64 * NW), smem, s, q);
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, NW, VEC, TBK, PAR>), dim3((unsigned)gx, p.nclasses, p.splitk > 1 ? p.splitk : 1), dim3(64 * NW), smem, s, q);
     CGS_CHECK_LAUNCH("igemm");
     if (p.splitk > 1) {
         long tot = 0;
@@ -598,7 +613,7 @@ static int launch_cfg(const IgemmParams& p, hipStream_t s) {
     }
     // the name rocprofv3 prints for this instantiation
     static char name[64];
-    snprintf(name, sizeof(name), "igemm_kernel<%d, %d, %d, %s, %d>", BM, BN, NW, VEC ? "true" : "false", TBK);
+    snprintf(name, sizeof(name), "igemm_kernel<%d, %d, %d, %s, %d, %s>", BM, BN, NW, VEC ? "true" : "false", TBK, PAR ? "true" : "false");
     cgs_note_kernel(name);
     return CGS_OK;
 }
@@ -655,6 +670,7 @@ int cgs_igemm_launch(const IgemmParams& p_in, void* slab, size_t slab_bytes, hip
     }
     // K tile: 32 when every tile lies inside one tap (VEC); 16 for the generic-K gather (small K: less padding waste)
     // (8-wave 128x128 blocks, 4 waves per SIMD: +1.3 % with one batch in flight, +-0 with two -- not kept)
+    if (vec && p.tap_parity) return wide ? launch_cfg<128, 128, 4, true, 32, true>(p, s) : launch_cfg<128, 64, 4, true, 32, true>(p, s);
     if (vec) return wide ? launch_cfg<128, 128, 4, true, 32>(p, s) : launch_cfg<128, 64, 4, true, 32>(p, s);
     return wide ? launch_cfg<128, 128, 4, false, 16>(p, s) : launch_cfg<128, 64, 4, false, 16>(p, s);
 }
