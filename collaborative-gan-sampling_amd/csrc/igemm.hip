@@ -178,7 +178,8 @@ __global__ __launch_bounds__(64 * NW, 2) void igemm_kernel(IgemmParams p) {
     // parity classes of a tile back to back in one block (FETCH_SIZE only -10 %: the patch does not survive in the
     // 4 MiB L2 across a class pass; 2-4 % slower); running the s*s classes of an m-tile as consecutive workgroups of one
     // XCD (FETCH_SIZE of the 32x32 transposed layers 670 -> 270 MB, but +30 % on the small-grid layers whose four weight
-    // sets then compete for the L2, and 13 % SLOWER end to end: the kernel is MFMA-bound, its fetch latency is hidden).
+    // sets then compete for the L2, and 13 % SLOWER end to end: the kernel is MFMA-bound, its fetch latency is hidden);
+    // sweeping runs of 16-64 m-tiles class after class per XCD (670 -> 515 MB on those layers, +-1 % in time: not kept).
     // Workgroups go to the 8 XCDs round-robin by id, each XCD with its own L2.  With id = mb * nblk_n + nb the n-tiles of
     // one m-tile (same A rows) land on DIFFERENT XCDs and every XCD streams the whole input: measured 26x the input bytes
     // from HBM for the 8x8 256->512 layer.  Decode per XCD instead: XCD x = id % 8 owns the m-tiles = x (mod 8) and runs
