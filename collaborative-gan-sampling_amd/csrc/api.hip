@@ -53,7 +53,7 @@ static int run_dir(const CgsLayer& L, bool dirT, int B, const float* in, const f
         return cgs_set_error(CGS_EINVAL, "%s: backward epilogue %d needs aux%s", who, epilogue, epilogue == CGS_EPI_RELU_BWD_AFFINE ? " and a" : "");
     if (dirT && (L.sh > 2 || L.sw > 2)) return cgs_set_error(CGS_EINVAL, "%s: transposed direction supports stride <= 2", who);
     if (dirT && smalln_ok(L, epilogue)) {
-        if ((L.Cs % 16) == 0 && ws)
+        if ((L.Cs % 16) == 0 && ws && cgs_convt_quad_fits(L))
             return cgs_convt_quad_launch(L, B, in, w, bias, out, epilogue, ep_a, ep_aux, (float*)ws, ws_bytes, prepacked, s);
         if (epilogue < CGS_EPI_RELU_BWD_AFFINE)
             return cgs_convt_smalln_launch(L, B, in, w, bias, out, epilogue, s);     // VALU form (any Cs % 4 == 0)

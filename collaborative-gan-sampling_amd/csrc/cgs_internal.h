@@ -115,6 +115,7 @@ __device__ __forceinline__ float epilogue_apply(float v, int mode, float a, floa
 }
 #endif
 
+bool cgs_convt_quad_fits(const CgsLayer& L);
 int cgs_conv_smalln_f_ok(const CgsLayer& L, int B, int epilogue);
 size_t cgs_conv_smalln_f_ws_floats(const CgsLayer& L);
 int cgs_conv_smalln_f_launch(const CgsLayer& L, int B, const float* in, const float* w, const float* bias, float* out,

@@ -286,6 +286,15 @@ size_t cgs_convt_quad_ws_floats_bound(int kh, int kw, int Cs) {
     return (size_t)((kh + 1) / 2 + 1) * ((kw + 1) / 2 + 1) * Cs * 16;
 }
 
+// the quad form keeps the whole packed weight image [ny*nx*Cs][16] in LDS: large kernels x many channels do not fit
+bool cgs_convt_quad_fits(const CgsLayer& L) {
+    const int pt = cgs_same_pad_before(L.Hb, L.kh, 2), pl = cgs_same_pad_before(L.Wb, L.kw, 2);
+    int dy0, hy, dx0, hx;
+    quad_range(L.kh, pt, dy0, hy);
+    quad_range(L.kw, pl, dx0, hx);
+    return (size_t)(hy - dy0 + 1) * (hx - dx0 + 1) * L.Cs * 16 * sizeof(float) <= 150 * 1024;
+}
+
 int cgs_convt_quad_launch(const CgsLayer& L, int B, const float* in, const float* w, const float* bias, float* out,
                           int epilogue, const float* ep_a, const float* ep_aux, float* ws, size_t ws_bytes, int prepacked,
                           hipStream_t s) {
