@@ -86,3 +86,78 @@ def test_deconv_random_shapes(B, H, W, Cin, Cout, k, s):
     dy = rnd(tuple(y.shape), 4)
     (y * dy).sum().backward()
     close(K.deconv2d_bwd_data(dy.to(d), w.to(d), (H, W), s, s), x.grad, ktol(k, Cout))
+
+
+def lin_cases(seed, n):
+    rs = np.random.RandomState(seed)
+    return [(int(rs.choice([1, 3, 64, 200])), int(rs.choice([1, 7, 32, 100, 1024, 6272])), int(rs.choice([1, 3, 10, 64, 1000])))
+            for _ in range(n)]
+
+
+@pytest.mark.parametrize("B,fin,fout", lin_cases(5 + SEED, max(10, N_CASES // 2)))
+def test_linear_random_shapes(B, fin, fout):
+    from cgs_amd import kernels as K
+    d = dev()
+    x = rnd((B, fin), 1).requires_grad_(True)
+    w, b = rnd((fin, fout), 2, 0.1), rnd((fout,), 3, 0.2)
+    y = R.linear(x, w, b)
+    close(K.linear_fwd(x.detach().to(d), w.to(d), b.to(d)), y, ktol(1, fin))
+    dy = rnd((B, fout), 4)
+    (y * dy).sum().backward()
+    close(K.linear_bwd_data(dy.to(d), w.to(d)), x.grad, ktol(1, fout))
+
+
+def bn_cases(seed, n):
+    rs = np.random.RandomState(seed)
+    return [(int(rs.choice([1, 2, 17, 64, 1000, 5000])), int(rs.choice([4, 8, 64, 100, 128, 1024])), float(rs.choice([0.2, 1.0, 0.0])))
+            for _ in range(n)]
+
+
+@pytest.mark.parametrize("M,C,leak", bn_cases(9 + SEED, max(10, N_CASES // 2)))
+def test_bn_random_shapes(M, C, leak):
+    from cgs_amd import kernels as K
+    d = dev()
+    x = (rnd((M, C), 1) * 1.3 + 0.4).requires_grad_(True)
+    gamma, beta = rnd((C,), 2).abs() + 0.5, rnd((C,), 3, 0.3)
+    z = R.bn_train(x, gamma, beta)
+    want = torch.where(z > 0, z, leak * z)
+    y, mean, invstd = K.bn_train_lrelu_fwd(x.detach().to(d), gamma.to(d), beta.to(d), leak)
+    if M == 1:                              # a single row: variance 0, output = beta through the activation
+        close(y, want, 1e-4)
+        return
+    close(y, want, 1e-5 if M > 2 else 1e-3)
+    dy = rnd((M, C), 4)
+    (want * dy).sum().backward()
+    got = K.bn_train_lrelu_bwd_data(dy.to(d), x.detach().to(d), gamma.to(d), beta.to(d), mean, invstd, leak)
+    # rows whose pre-activation sits within rounding of the lrelu kink may take the other slope: compare away from it
+    safe = (z.detach().abs() > 1e-4).all(dim=1) if leak != 1.0 else torch.ones(M, dtype=torch.bool)
+    if safe.all():
+        close(got, x.grad, 2e-4 if M > 2 else 2e-2)
+
+
+def wgrad_cases(seed, n):
+    rs = np.random.RandomState(seed)
+    out = []
+    while len(out) < n:
+        B, k, s = int(rs.choice([1, 3, 33])), int(rs.choice([1, 3, 4, 5])), int(rs.choice([1, 2]))
+        H, W = int(rs.randint(1, 15)), int(rs.randint(1, 15))
+        cin, cout = int(rs.choice(CH)), int(rs.choice(CH))
+        if B * H * W * cin * cout * k * k > 3e9:
+            continue
+        out.append((B, H, W, cin, cout, k, s))
+    return out
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,s", wgrad_cases(31 + SEED, max(10, N_CASES // 2)))
+def test_conv_weight_gradient_random_shapes(B, H, W, Cin, Cout, k, s):
+    from cgs_amd import kernels as K
+    d = dev()
+    x = rnd((B, H, W, Cin), 1)
+    w = rnd((k, k, Cin, Cout), 2, 0.1).requires_grad_(True)
+    b = torch.zeros(Cout, requires_grad=True)
+    y = R.conv2d(x, w, b, s, s)
+    dy = rnd(tuple(y.shape), 4)
+    (y * dy).sum().backward()
+    got = K.conv2d_bwd_weight(x.to(d), dy.to(d), k, k, s, s)
+    close(got, w.grad, 2e-5 * max(1.0, (B * y.shape[1] * y.shape[2] / 1000.0) ** 0.5))
+    close(K.bias_grad(dy.to(d)), b.grad, 1e-5 * max(1.0, (B * y.shape[1] * y.shape[2] / 1000.0) ** 0.5))
