@@ -64,7 +64,7 @@ def cpu_baseline(arch, refine_steps, rate, budget_batch=64):
     for n in sorted({c for c in (8, 16, 32, 64, ncpu) if c <= ncpu}):
         torch.set_num_threads(n)
         run(8, 1)
-        t = run(8, 1)
+        t = run(32, 1) / 4.0               # (per 8 samples; a 32-sample run is long enough to rank the thread counts reliably)
         if best_t is None or t < best_t:
             best_n, best_t = n, t
     torch.set_num_threads(best_n)
