@@ -298,3 +298,4 @@ if __name__ == "__main__":
     collab_case("mnist", 8, 5, "deterministic", 0.5, seed=9, constraints=(0.05, 1.5))
     collab_case("dcgan32", 4, 5, "deterministic", 0.1, seed=21)      # 5x5 kernels: asymmetric SAME
     collab_case("dcgan32", 4, 5, "probabilistic", 0.1, seed=22)
+    collab_case("dcgan64", 2, 2, "deterministic", 0.1, seed=31)     # the headline architecture (BASELINE configs 3/4)
