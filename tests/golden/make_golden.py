@@ -192,7 +192,7 @@ def collab_case(arch, B, K, mode, rate, seed, constraints=None):
     P = N.init_params(arch, seed=2019, perturb=True)
     A = N.ARCHS[arch]
     rs = np.random.RandomState(seed)
-    z = rs.uniform(-1, 1, (B, A["z_dim"])).astype(np.float32)
+    z = rs.uniform(-1, 1, (B,) + (tuple(A["g_in"]) if A.get("g_in") else (A["z_dim"],))).astype(np.float32)   # z, or the source image
     real = rs.uniform(-1, 1, (B,) + tuple(A["img"])).astype(np.float32)
     with torch.no_grad():
         feat0 = N.input_to_feature(arch, P, torch.from_numpy(z))
@@ -299,3 +299,4 @@ if __name__ == "__main__":
     collab_case("dcgan32", 4, 5, "deterministic", 0.1, seed=21)      # 5x5 kernels: asymmetric SAME
     collab_case("dcgan32", 4, 5, "probabilistic", 0.1, seed=22)
     collab_case("dcgan64", 2, 2, "deterministic", 0.1, seed=31)     # the headline architecture (BASELINE configs 3/4)
+    collab_case("cyclegan_tiny", 3, 3, "deterministic", 0.1, seed=41)   # PatchGAN logit map: collaborator.py:34-37
