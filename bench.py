@@ -142,6 +142,7 @@ def main():
     ap.add_argument("--by-layer", action="store_true", help="key the per-kernel timing records by layer shape too (diagnostic)")
     args = ap.parse_args()
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC for RCCL; must be set before HIP initialises
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
     if world != args.gpus:
@@ -152,7 +153,6 @@ def main():
     use_dist = "RANK" in os.environ and "MASTER_ADDR" in os.environ      # launched by torch.distributed.run (any world size)
     if use_dist:
         import torch.distributed as dist
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
 
     if args.arch == "synthetic2d":
