@@ -135,6 +135,9 @@ def main():
     ap.add_argument("--streams", type=int, default=2,
                     help="z-batches in flight per GPU, one engine + HIP stream each: the tail / small kernels of one "
                          "batch overlap the big kernels of the other (measured: 1 -> 5040, 2 -> 5500, 3 -> 5460 samples/s)")
+    ap.add_argument("--fuse", type=int, default=0,
+                    help="logical batches fused into one engine batch (conv launches G times larger, batch-norm statistics kept "
+                         "per logical batch).  Default: as many as make ~1024 samples per launch (dcgan64 1, dcgan32 4, mnist 16)")
     ap.add_argument("--sync-bn", action="store_true",
                     help="treat the N ranks' batches as ONE logical batch of N*B samples: all-reduce D's batch-norm sums "
                          "(needs the torch.distributed launch; eager only)")
@@ -168,14 +171,15 @@ def main():
     P = nets.init_params(args.arch, dev, seed=2019)                     # same frozen weights on every rank
     if args.sync_bn and not use_dist:
         raise SystemExit("--sync-bn needs the torch.distributed launch (python -m torch.distributed.run ... bench.py)")
-    engines = [RefineEngine(args.arch, P, B, dev, use_graph=args.graph, sync_bn=True if args.sync_bn else None)
+    G = args.fuse if args.fuse > 0 else {"dcgan32": 4, "mnist": 16}.get(args.arch, 1) if not args.sync_bn else 1
+    engines = [RefineEngine(args.arch, P, B * G, dev, use_graph=args.graph, sync_bn=True if args.sync_bn else None, bn_groups=G)
                for _ in range(max(1, args.streams))]
     streams = [torch.cuda.Stream(dev) for _ in engines] if len(engines) > 1 else [torch.cuda.current_stream(dev)]
     eng = engines[0]
-    n_batches = args.steps + args.warmup
+    n_batches = args.steps + args.warmup                                # a step = one engine call = G logical batches
     rs = np.random.RandomState(2019 + rank)                            # rank-offset seed: disjoint z shards
-    z = torch.from_numpy(rs.uniform(-1, 1, (n_batches, B) + nets.g_input_shape(A)).astype(np.float32)).to(dev)   # z, or source images
-    pools = [torch.empty((world * B,) + tuple(A["img"]), dtype=torch.float32, device=dev) if use_dist else None
+    z = torch.from_numpy(rs.uniform(-1, 1, (n_batches, B * G) + nets.g_input_shape(A)).astype(np.float32)).to(dev)   # z, or source images
+    pools = [torch.empty((world * B * G,) + tuple(A["img"]), dtype=torch.float32, device=dev) if use_dist else None
              for _ in engines]                                           # one node-wide pool buffer per batch in flight
 
     def step(i):
@@ -224,17 +228,18 @@ def main():
         dt = float(t.item())
 
     if rank == 0:
-        value = world * B * args.steps / dt
+        value = world * B * G * args.steps / dt
         flops_per_sample = nets.refine_flops_per_sample(args.arch, Ksteps)
         out = {
             "metric": f"refined samples/sec @ {Ksteps} refinement steps", "value": round(value, 2), "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.arch} collaborative refinement (propose + K-step refine + render), "
-                                   f"batch {B}/GPU, K={Ksteps}, momentum rate {args.rate}, refine at feature "
+                                   f"batch {B}/GPU{f' (x{G} logical batches per launch, batch-norm statistics per logical batch)' if G > 1 else ''}, "
+                                   f"K={Ksteps}, momentum rate {args.rate}, refine at feature "
                                    f"{list(A['feature'])}, random-init weights, z~U(-1,1) seed 2019+rank",
-                       "global_batch": world * B, "refine_steps": Ksteps, "parallelism": f"z-shards x{world} + RCCL all-gather of the pool" if world > 1 else "single GPU",
-                       "hipgraph": bool(args.graph), "batches_in_flight": len(engines), "sync_bn": bool(args.sync_bn)},
+                       "global_batch": world * B * G, "refine_steps": Ksteps, "parallelism": f"z-shards x{world} + RCCL all-gather of the pool" if world > 1 else "single GPU",
+                       "hipgraph": bool(args.graph), "batches_in_flight": len(engines) * G, "fused_per_launch": G, "sync_bn": bool(args.sync_bn)},
             "algorithmic_tflops": round(value * flops_per_sample / 1e12, 2),
         }
         if prof:

@@ -118,9 +118,23 @@ class _BnTrainLrelu(_Stage):
         self.x = None
 
     sync = None          # a BnSync: the batch is one shard of a logical batch spread over the ranks of a process group
+    groups = 1           # > 1: the engine batch is ``groups`` logical batches back to back, each with its OWN statistics
+
+    def set_groups(self, groups):
+        """Statistics per group of rows: the instance-norm kernels with one 'sample' = one logical batch."""
+        self.groups = int(groups)
+        C = self.out.shape[-1]
+        self.mean = torch.empty((self.groups, C), dtype=torch.float32, device=self.out.device)
+        self.invstd = torch.empty((self.groups, C), dtype=torch.float32, device=self.out.device)
+
+    def _g(self, t):
+        return t.view(self.groups, -1, t.shape[-1])
 
     def fwd(self, x):
         self.x = x
+        if self.groups > 1:
+            K.instnorm_lrelu_fwd(self._g(x), self.gamma, self.beta, self.leak, out=self._g(self.out), stats=(self.mean, self.invstd))
+            return self.out
         if self.sync is None:
             K.bn_train_lrelu_fwd(x, self.gamma, self.beta, self.leak, out=self.out, stats=(self.mean, self.invstd))
             return self.out
@@ -133,6 +147,10 @@ class _BnTrainLrelu(_Stage):
         return self.out
 
     def bwd(self, dy):
+        if self.groups > 1:
+            K.instnorm_lrelu_bwd_data(self._g(dy), self._g(self.x), self.gamma, self.beta, self.mean, self.invstd, self.leak,
+                                      out=self._g(dy))
+            return dy
         if self.sync is None:
             return K.bn_train_lrelu_bwd_data(dy, self.x, self.gamma, self.beta, self.mean, self.invstd, self.leak, out=dy)
         M = self.x.numel() // self.x.shape[-1]
@@ -357,7 +375,7 @@ class Tape:
 class RefineEngine:
     """K-step collaborative refinement of a batch of G activation maps on one GPU."""
 
-    def __init__(self, arch, params, batch_size, device=None, use_graph=False, sync_bn=None):
+    def __init__(self, arch, params, batch_size, device=None, use_graph=False, sync_bn=None, bn_groups=1):
         self.A = ARCHS[arch] if isinstance(arch, str) else arch
         self.dev = torch.device(device if device is not None else "cuda:0")
         if self.dev.type != "cuda":
@@ -382,6 +400,23 @@ class RefineEngine:
         self._graphs = {}
         # sync_bn = True (default process group) or a process group: this engine's batch is one shard of a logical batch of
         # world_size * batch_size samples; D's batch statistics are all-reduced so the result equals the unsplit batch's
+        # bn_groups = G: ``batch_size`` holds G logical batches of batch_size / G samples back to back.  Convolutions do not
+        # care; D's batch norm keeps one set of statistics per logical batch, so the result is that of G separate calls while
+        # every launch is G times larger (small batches then fill the GPU from one stream).
+        self.bn_groups = int(bn_groups)
+        if self.bn_groups > 1:
+            if B % self.bn_groups:
+                raise L.CgsError(f"bn_groups={bn_groups} does not divide the engine batch {B}")
+            if sync_bn:
+                raise L.CgsError("bn_groups and sync_bn are mutually exclusive")
+
+            def walk_g(stages):
+                for st in stages:
+                    if isinstance(st, _BnTrainLrelu):
+                        st.set_groups(self.bn_groups)
+                    if isinstance(st, _Residual):
+                        walk_g(st.inner)
+            walk_g(self.d.stages); walk_g(self.g_tail.stages)
         self.sync_bn = None
         if sync_bn is not None and sync_bn is not False:
             if use_graph:

@@ -214,6 +214,29 @@ def test_two_batches_in_flight_match_sequential(arch, B, K):
                 assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("arch,B,G,K", [("mnist", 8, 3, 3), ("dcgan32", 16, 2, 2)])
+def test_fused_logical_batches_keep_their_own_statistics(arch, B, G, K):
+    """RefineEngine(bn_groups=G): G logical batches in one engine batch, D's batch norm per logical batch -> the same
+    result as G separate calls (the convolutions only see a larger batch)."""
+    from cgs_amd.engine import RefineEngine
+    from cgs_amd.nets import to_device, ARCHS
+    d = dev()
+    P = to_device(N.init_params(arch, 2019, True), d)
+    z = torch.from_numpy(np.random.RandomState(9).uniform(-1, 1, (G * B, ARCHS[arch]["z_dim"])).astype(np.float32)).to(d)
+    solo = RefineEngine(arch, P, B, d)
+    want = [[t.clone() for t in solo.refine_from_z(z[i * B:(i + 1) * B], K, 0.1)] for i in range(G)]
+    fused = RefineEngine(arch, P, G * B, d, bn_groups=G)
+    img, dl, ol, st, of = fused.refine_from_z(z, K, 0.1)
+    cat = lambda j: torch.cat([w[j] for w in want])
+    assert torch.allclose(dl, cat(1), rtol=1e-4, atol=1e-5)
+    assert torch.allclose(ol, cat(2), rtol=2e-3, atol=2e-4)
+    assert (st == cat(3)).float().mean().item() >= 0.9
+    assert torch.allclose(of, cat(4), rtol=0, atol=2e-3 * cat(4).abs().max().item())
+    assert torch.allclose(img, cat(0), rtol=0, atol=5e-3)
+    plain = RefineEngine(arch, P, G * B, d)                          # one batch of G*B: different statistics, different logits
+    assert (plain.refine_from_z(z, K, 0.1)[1] - cat(1)).abs().max().item() > 10 * (dl - cat(1)).abs().max().item()
+
+
 def test_collaborative_fill_loop_on_device():
     """refine -> D-score -> MH accept -> fill (nsgan/GAN.py:398-426) driven by the device engine."""
     from cgs_amd.engine import RefineEngine
