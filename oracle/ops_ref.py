@@ -33,7 +33,8 @@ def conv2d(x, w, b, d_h=2, d_w=2):
     pt, pb = same_pads(x.shape[1], kh, d_h)
     pl, pr = same_pads(x.shape[2], kw, d_w)
     xn = F.pad(x.permute(0, 3, 1, 2), (pl, pr, pt, pb))
-    y = F.conv2d(xn, w.permute(3, 2, 0, 1), b, stride=(d_h, d_w))
+    y = F.conv2d(xn, w.permute(3, 2, 0, 1).contiguous(), b, stride=(d_h, d_w))      # (contiguous: torch-CPU's native conv
+    # backward refuses a permuted filter gradient for one output channel)
     return y.permute(0, 2, 3, 1).contiguous()
 
 
