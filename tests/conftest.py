@@ -12,6 +12,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("filterwarnings", "ignore:TF32 acceleration on top of oneDNN:UserWarning")
 
 
 @pytest.fixture(scope="session")
