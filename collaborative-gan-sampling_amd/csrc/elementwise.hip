@@ -126,9 +126,28 @@ __global__ void bce_rowmean_kernel(const float* __restrict__ l, float* __restric
     lm[b] = s / (float)P;
 }
 
+// PatchGAN logit maps (P = hundreds of logits per sample): one wave per sample, lanes stride over the row, fixed shuffle tree
+__global__ __launch_bounds__(256) void bce_rowmean_wave_kernel(const float* __restrict__ l, float* __restrict__ dl, float* __restrict__ lm,
+                                                               int B, int P) {
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (b >= B) return;
+    float s = 0.f;
+    for (int i = lane; i < P; i += 64) {
+        const float v = l[(size_t)b * P + i];
+        s += v;
+        dl[(size_t)b * P + i] = v >= 0.f ? -expf(-v) / (1.f + expf(-v)) : -1.f / (1.f + expf(v));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) lm[b] = s / (float)P;
+}
+
 int cgs_bce_ones_grad_rowmean(const float* logits, float* dlogits, float* logit_mean, int B, int P, void* stream) {
     if (B <= 0 || P <= 0) return cgs_set_error(CGS_EINVAL, "bce_ones_grad_rowmean: B=%d P=%d", B, P);
-    hipLaunchKernelGGL(bce_rowmean_kernel, dim3(cgs_ceil_div(B, 128)), dim3(128), 0, (hipStream_t)stream, logits, dlogits, logit_mean, B, P);
+    if (P >= 64)
+        hipLaunchKernelGGL(bce_rowmean_wave_kernel, dim3(cgs_ceil_div(B, 4)), dim3(256), 0, (hipStream_t)stream, logits, dlogits, logit_mean, B, P);
+    else
+        hipLaunchKernelGGL(bce_rowmean_kernel, dim3(cgs_ceil_div(B, 128)), dim3(128), 0, (hipStream_t)stream, logits, dlogits, logit_mean, B, P);
     CGS_CHECK_LAUNCH("bce_ones_grad_rowmean");
     return CGS_OK;
 }

@@ -232,6 +232,11 @@ def test_elementwise_and_fold():
     logits = rnd((9, 4), 7, 5.0)
     dl, lm = K.bce_ones_grad_rowmean(logits.to(d))
     close(dl, torch.sigmoid(logits) - 1, 1e-5); close(lm, logits.mean(1), 1e-6)
+    for shape in ((8, 32, 32, 1), (3, 1000), (5, 64), (2, 77)):      # PatchGAN maps: the wave-per-sample form (P >= 64)
+        lg = rnd(shape, 8, 3.0)
+        dl, lm = K.bce_ones_grad_rowmean(lg.to(d))
+        close(dl, torch.sigmoid(lg) - 1, 1e-5)
+        close(lm, lg.reshape(shape[0], -1).mean(1), 1e-5)
 
 
 def test_refine_update_and_select_match_policy():
