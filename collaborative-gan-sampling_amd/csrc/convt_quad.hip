@@ -13,6 +13,8 @@
 // A fragments are read straight from global memory (each lane one float4 = 4 consecutive ci of its
 // row; the K order inside a 16-channel chunk is permuted identically for A and B so no shuffle is
 // needed); the packed weights (37 KB for 9 x 64 x 16) sit in LDS for the whole block.
+#include <stdio.h>
+
 #include "cgs_internal.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -143,32 +145,35 @@ __global__ __launch_bounds__(256) void convt_quad_mfma_kernel(QuadParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// LDS-patch variant (Ws % 32 == 0, Hs % 8 == 0): a block owns an 8 x 32 tile of quads of one image.  Per
-// 16-channel chunk the (8+ny-1) x (32+nx-1) input patch is staged ONCE in LDS (double buffered, the next chunk's
+// LDS-patch variant: a block owns a TH x TW tile of quads of one image (8 x 32, or 16 x 16 for narrow / ragged grids: tiles may
+// hang over the right / bottom edge, their loads read zeros and their stores are clipped).  Per
+// 16-channel chunk the (TH+ny-1) x (TW+nx-1) input patch is staged ONCE in LDS (double buffered, the next chunk's
 // global loads in flight under the MFMAs) and every neighbour's A fragment is a conflict-free ds_read_b128 from it:
 // each input element leaves L2 ~1.3x instead of 9x.  The 4 image rows x 64 pixels x N channels a wave produces
 // are transposed through LDS and stored (and the aux tensor loaded) as 16-byte accesses of whole 768-byte rows.
 // ------------------------------------------------------------------------------------------------
-template <int NPAD>   // NPAD = N (<= 4)
+template <int NPAD, int TW>   // NPAD = N (<= 4); TW = tile width in quads (32 or 16), tile height 256 / TW
 __global__ __launch_bounds__(256, 2) void convt_quad_lds_kernel(QuadParams p) {
+    constexpr int TH = 256 / TW;
+    constexpr int QR = TH / 4;                              // quad rows per wave (2 or 4)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, i = lane & 15;
     const int K = p.ny * p.nx * p.Cs;
-    const int PH = 8 + p.ny - 1, PW = 32 + p.nx - 1;       // patch rows / cols (pixels)
+    const int PH = TH + p.ny - 1, PW = TW + p.nx - 1;      // patch rows / cols (pixels)
     const int patch_f4 = PH * PW * 4;                      // float4 per 16-channel patch
     float* Bs = smem;                                      // [K/4][16][4]
     float* Ps = smem + (size_t)K * 16;                     // [2][PH][PW][16]
     for (int q = tid; q < K * 4; q += 256) ((f32x4*)Bs)[q] = ((const f32x4*)p.wq)[q];
 
-    const int tiles_x = p.Ws >> 5, tiles_y = p.Hs >> 3;
+    const int tiles_x = (p.Ws + TW - 1) / TW, tiles_y = (p.Hs + TH - 1) / TH;
     const int tpi = tiles_x * tiles_y;
     const int b = blockIdx.x / tpi, trem = blockIdx.x - b * tpi;
-    const int r0 = (trem / tiles_x) * 8, c0 = (trem - (trem / tiles_x) * tiles_x) * 32;
+    const int r0 = (trem / tiles_x) * TH, c0 = (trem - (trem / tiles_x) * tiles_x) * TW;
 
     const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void*)p.in, 0, (int)((unsigned)p.B * (unsigned)p.Hs * (unsigned)p.Ws * (unsigned)p.Cs * 4u), 0x00020000);
-    constexpr int PL = 6;                                  // float4 staged per thread: ceil(10*34*4 / 256)
+    constexpr int PL = 6;                                  // float4 staged per thread: ceil(10*34*4 / 256), ceil(18*18*4 / 256)
     f32x4 st[PL];
     const int nchunk = p.Cs >> 4;
 #define LOAD_PATCH(ch_)                                                                                   \
@@ -208,7 +213,7 @@ __global__ __launch_bounds__(256, 2) void convt_quad_lds_kernel(QuadParams p) {
                 f32x4 fa[4];
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    const int pr = 2 * wave + (t >> 1) + a, pc = 16 * (t & 1) + i + bq;
+                    const int pr = (TW == 32 ? 2 * wave + (t >> 1) : 4 * wave + t) + a, pc = (TW == 32 ? 16 * (t & 1) : 0) + i + bq;
                     fa[t] = *(const f32x4*)(P + ((size_t)(pr * PW + pc) * 4 + g) * 4);
                 }
 #pragma unroll
@@ -227,8 +232,8 @@ __global__ __launch_bounds__(256, 2) void convt_quad_lds_kernel(QuadParams p) {
 
     // ---- epilogue: transpose the wave's 4 image rows x (64 px x N) through LDS, then 16-byte row accesses ----
     constexpr int N = NPAD;
-    const int rowf = 64 * N;                               // floats per output image row of the tile
-    float* E = Ps + (size_t)wave * 4 * rowf;               // [4 image rows][64*N]   (patch buffers are dead: barrier above)
+    const int rowf = 2 * TW * N;                           // floats per output image row of the tile
+    float* E = Ps + (size_t)wave * 2 * QR * rowf;          // [2*QR image rows][2*TW*N]   (patch buffers are dead: barrier above)
     const int cls = i / N, n = i - cls * N;
     if (cls < 4) {
         const int py = cls >> 1, px = cls & 1;
@@ -237,19 +242,19 @@ __global__ __launch_bounds__(256, 2) void convt_quad_lds_kernel(QuadParams p) {
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int c = 16 * (t & 1) + g * 4 + r;    // quad column inside the tile
-                E[(2 * (t >> 1) + py) * rowf + (2 * c + px) * N + n] = acc[t][r] + bias;
+                const int c = (TW == 32 ? 16 * (t & 1) : 0) + g * 4 + r;    // quad column inside the tile
+                E[(2 * (TW == 32 ? (t >> 1) : t) + py) * rowf + (2 * c + px) * N + n] = acc[t][r] + bias;
             }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const int f4_per_row = rowf / 4;                       // 48 for N = 3
-    const float ea = 1.f;
-    (void)ea;
-    for (int q = lane; q < 4 * f4_per_row; q += 64) {
+    const int f4_per_row = rowf / 4;                       // 48 for N = 3, TW = 32
+    const int live_f = 2 * (p.Ws - c0 < TW ? p.Ws - c0 : TW) * N;      // floats of a tile row that lie inside the image
+    for (int q = lane; q < 2 * QR * f4_per_row; q += 64) {
         const int yr = q / f4_per_row, xq = q - yr * f4_per_row;
-        const int y = 2 * (r0 + 2 * wave) + yr;
+        const int y = 2 * (r0 + QR * wave) + yr;
+        if (y >= 2 * p.Hs || xq * 4 >= live_f) continue;
         const size_t o = ((size_t)(b * 2 * p.Hs + y) * (2 * p.Ws) + 2 * c0) * N + xq * 4;
         f32x4 v = *(const f32x4*)(E + yr * rowf + xq * 4);
         if (p.epilogue == CGS_EPI_TANH) {
@@ -318,31 +323,39 @@ int cgs_convt_quad_launch(const CgsLayer& L, int B, const float* in, const float
     }
     const long total_q = (long)B * L.Hs * L.Ws;
     if (total_q == 0) return CGS_OK;
-    // LDS-patch variant: 8 x 32 quad tiles; needs 16-byte aligned output rows (64*N floats per tile row)
-    if ((L.Ws % 32) == 0 && (L.Hs % 8) == 0 && p.ny <= 3 && p.nx <= 3 && ((64 * L.Cb) % 4) == 0 &&
-        ((2 * L.Ws * L.Cb) % 4) == 0) {
-        const int PH = 8 + p.ny - 1, PW = 32 + p.nx - 1;
+    // LDS-patch variant: 8 x 32 quad tiles, or 16 x 16 (clipped at the edges) for grids that are not whole 8 x 32 tiles;
+    // needs 16-byte aligned output rows
+    if (p.ny <= 3 && p.nx <= 3 && ((2 * L.Ws * L.Cb) % 4) == 0 && ((32 * L.Cb) % 4) == 0) {
+        const bool wide = (L.Ws % 32) == 0 && (L.Hs % 8) == 0;
+        const int TWr = wide ? 32 : 16, THr = 256 / TWr;
+        const int PH = THr + p.ny - 1, PW = TWr + p.nx - 1;
         const size_t smem = need + (size_t)2 * PH * PW * 16 * sizeof(float);
-        const long blocks = (long)B * (L.Hs / 8) * (L.Ws / 32);
-#define QUAD_LDS_CASE(NN)                                                                                          \
-    case NN: {                                                                                                     \
+        const long blocks = (long)B * cgs_ceil_div(L.Hs, THr) * cgs_ceil_div(L.Ws, TWr);
+#define QUAD_LDS_LAUNCH(NN, TT)                                                                                    \
+    {                                                                                                              \
         static bool done_ = false;                                                                                 \
         if (!done_) {                                                                                              \
-            hipError_t e = hipFuncSetAttribute((const void*)convt_quad_lds_kernel<NN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            hipError_t e = hipFuncSetAttribute((const void*)convt_quad_lds_kernel<NN, TT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
             if (e != hipSuccess) return cgs_set_error(CGS_ELAUNCH, "convt_quad_lds smem attr: %s", hipGetErrorString(e)); \
             done_ = true;                                                                                          \
         }                                                                                                          \
-        hipLaunchKernelGGL(convt_quad_lds_kernel<NN>, dim3((unsigned)blocks), dim3(256), smem, s, p);              \
-        break;                                                                                                     \
+        hipLaunchKernelGGL((convt_quad_lds_kernel<NN, TT>), dim3((unsigned)blocks), dim3(256), smem, s, p);        \
     }
-        if (smem <= 160 * 1024 && (size_t)4 * 4 * 64 * L.Cb <= (size_t)2 * PH * PW * 16) {
+#define QUAD_LDS_CASE(NN)                                                                                          \
+    case NN:                                                                                                       \
+        if (wide) QUAD_LDS_LAUNCH(NN, 32) else QUAD_LDS_LAUNCH(NN, 16)                                             \
+        break;
+        if (smem <= 160 * 1024 && (size_t)4 * 256 * L.Cb <= (size_t)2 * PH * PW * 16) {
             switch (L.Cb) {
                 QUAD_LDS_CASE(1) QUAD_LDS_CASE(2) QUAD_LDS_CASE(3) QUAD_LDS_CASE(4)
                 default: return cgs_set_error(CGS_EINVAL, "convt_quad: N=%d", L.Cb);
             }
 #undef QUAD_LDS_CASE
+#undef QUAD_LDS_LAUNCH
             CGS_CHECK_LAUNCH("convt_quad_lds");
-            cgs_note_kernel(L.Cb == 3 ? "convt_quad_lds_kernel<3>" : L.Cb == 1 ? "convt_quad_lds_kernel<1>" : L.Cb == 2 ? "convt_quad_lds_kernel<2>" : "convt_quad_lds_kernel<4>");
+            static thread_local char name[48];
+            snprintf(name, sizeof(name), "convt_quad_lds_kernel<%d, %d>", L.Cb, TWr);       // as rocprofv3 prints it
+            cgs_note_kernel(name);
             return CGS_OK;
         }
     }

@@ -99,6 +99,8 @@ DECONV_CASES = [  # B,H,W,Cin,Ho,Wo,Cout,k,s
     (128, 7, 7, 32, 14, 14, 64, 4, 2),    # pixel-major 7x7 grid, 4x4 kernels
     (3, 32, 32, 64, 64, 64, 3, 5, 2),     # dcgan64 g_h4: LDS-patch quad kernel
     (2, 8, 32, 32, 16, 64, 4, 4, 2),      # N = 4, 4x4 kernel, LDS-patch
+    (3, 20, 12, 32, 40, 24, 3, 5, 2),     # LDS-patch, 16x16 tiles hanging over both edges
+    (2, 40, 40, 16, 80, 80, 2, 5, 2),     # LDS-patch, 16x16 tiles, 2.5 tiles per side
 ]
 
 
