@@ -68,9 +68,9 @@ def cpu_baseline(arch, refine_steps, rate, budget_batch=64):
         if best_t is None or t < best_t:
             best_n, best_t = n, t
     torch.set_num_threads(best_n)
-    # size the sample for ~15 s of CPU work (a K-step refinement costs about (2K+2)/3 one-step runs)
-    est_rate = 8.0 / best_t * 3.0 / (2 * refine_steps + 2)
-    budget_batch = int(min(1024, max(budget_batch, 64 * round(15.0 * est_rate / 64))))
+    # size the sample for ~15 s of CPU work from a 32-sample pilot at the full K
+    pilot = run(32, refine_steps)
+    budget_batch = int(min(512, max(budget_batch, 32 * round(15.0 / pilot))))
     dt = run(budget_batch, refine_steps)
     return {"value": round(budget_batch / dt, 3), "unit": "samples/s", "cores": best_n, "kind": "port",
             "sample": f"oracle.collaborative_refine (torch-CPU fp32), {arch}, batch {budget_batch}, K={refine_steps}, "
