@@ -89,9 +89,15 @@ def bench_synthetic2d(args, dev, rank, world):
     x = torch.from_numpy((3.0 * np.random.RandomState(2019 + rank).randn(n, B, 2)).astype(np.float32)).to(dev)
     real = torch.from_numpy(S.toy_next_batch("Imbal-8Gaussians", 10.0, 0.9, B, np.random.RandomState(7)).astype(np.float32)).to(dev)
 
+    # one wave per sample: a 512-sample batch occupies 6 % of the GPU's wave slots and is latency-bound (K+1 dependent MLP
+    # evaluations), so independent batches are kept in flight on several streams (nothing synchronises with the host)
+    n_streams = args.streams if args.streams > 0 else 8
+    streams = [torch.cuda.Stream(dev) for _ in range(n_streams)]
+
     def step(i):
-        base = D.sigmoid_and_saliency(real, want_saliency=False)[0].mean().item()     # np.mean(real_sigmoid), refiner_cpu.py:23,28
-        return D.refine(x[i], base, Ksteps, args.rate, "ladam")[0]
+        with torch.cuda.stream(streams[i % n_streams]):
+            base = D.sigmoid_and_saliency(real, want_saliency=False)[0].mean()        # np.mean(real_sigmoid), refiner_cpu.py:23,28 (stays on the device)
+            return D.refine(x[i], base, Ksteps, args.rate, "ladam")[0]
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize(dev)
@@ -105,7 +111,7 @@ def bench_synthetic2d(args, dev, rank, world):
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": f"synthetic2d Imbal-8Gaussians MLP-GAN D 2-64x5-1, batch {B}, K={Ksteps}, ladam rate {args.rate}: "
-                                      "real-batch baseline + fused K-step refine (2 launches + 1 host read per batch)"},
+                                      f"real-batch baseline + fused K-step refine (3 launches per batch, no host synchronisation), {n_streams} batches in flight"},
                "roofline": None}
         if not args.no_cpu_baseline:
             fake = x[0].cpu().numpy(); rb = real.cpu().numpy().astype(np.float64)
@@ -124,7 +130,7 @@ def bench_synthetic2d(args, dev, rank, world):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=0, help="timed steps (default 4; 256 for synthetic2d, whose step is 0.05 ms)")
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--arch", default="dcgan64", choices=["mnist", "dcgan32", "dcgan64", "synthetic2d", "cyclegan256"],
                     help="synthetic2d = BASELINE config 1 (2-D MLP GAN, batch 512, K=10, ladam) on the fused device refiner")
@@ -132,8 +138,8 @@ def main():
     ap.add_argument("--refine-steps", type=int, default=0, help="K (default: 20; 50 for mnist)")
     ap.add_argument("--rate", type=float, default=0.1)
     ap.add_argument("--graph", action="store_true", help="replay the K-step program as a hipGraph")
-    ap.add_argument("--streams", type=int, default=2,
-                    help="z-batches in flight per GPU, one engine + HIP stream each: the tail / small kernels of one "
+    ap.add_argument("--streams", type=int, default=0,
+                    help="(default 2; 8 for synthetic2d) z-batches in flight per GPU, one engine + HIP stream each: the tail / small kernels of one "
                          "batch overlap the big kernels of the other (measured: 1 -> 5040, 2 -> 5500, 3 -> 5460 samples/s)")
     ap.add_argument("--fuse", type=int, default=0,
                     help="logical batches fused into one engine batch (conv launches G times larger, batch-norm statistics kept "
@@ -144,6 +150,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--by-layer", action="store_true", help="key the per-kernel timing records by layer shape too (diagnostic)")
     args = ap.parse_args()
+    if args.steps <= 0:
+        args.steps = 256 if args.arch == "synthetic2d" else 4
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC for RCCL; must be set before HIP initialises
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
@@ -173,7 +181,7 @@ def main():
         raise SystemExit("--sync-bn needs the torch.distributed launch (python -m torch.distributed.run ... bench.py)")
     G = args.fuse if args.fuse > 0 else {"dcgan32": 4, "mnist": 16}.get(args.arch, 1) if not args.sync_bn else 1
     engines = [RefineEngine(args.arch, P, B * G, dev, use_graph=args.graph, sync_bn=True if args.sync_bn else None, bn_groups=G)
-               for _ in range(max(1, args.streams))]
+               for _ in range(args.streams if args.streams > 0 else 2)]
     streams = [torch.cuda.Stream(dev) for _ in engines] if len(engines) > 1 else [torch.cuda.current_stream(dev)]
     eng = engines[0]
     n_batches = args.steps + args.warmup                                # a step = one engine call = G logical batches

@@ -110,13 +110,15 @@ __global__ __launch_bounds__(1024) void mlp_saliency_kernel(MlpParams p, const f
 }
 
 // the whole refiner_cpu loop for one sample per wave.  method: 0 sgd, 1 momentum, 2 ladam (policy.py:26-61, numpy branch)
-__global__ __launch_bounds__(1024) void refine2d_kernel(MlpParams p, const float* __restrict__ x_in, float real_mean,
+__global__ __launch_bounds__(1024) void refine2d_kernel(MlpParams p, const float* __restrict__ x_in, float real_mean_host,
+                                                        const float* __restrict__ real_mean_dev,
                                                         float inv_batch, int steps, float rate, int method,
                                                         float* __restrict__ best_x, float* __restrict__ best_step,
                                                         float* __restrict__ traj /* [B][steps+1][2] or null */, int B) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const MlpLds L = mlp_lds(smem, p.nlayers);
     mlp_load(p, L);
+    const float real_mean = real_mean_dev ? real_mean_dev[0] : real_mean_host;      // device scalar: no host round trip per batch
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     for (int s = blockIdx.x * nw + wave; s < B; s += gridDim.x * nw) {
         float x0 = x_in[2 * s], x1 = x_in[2 * s + 1];
@@ -186,9 +188,9 @@ int cgs_mlp2d_sigmoid_saliency(const float* const* w, const float* const* b, int
     return CGS_OK;
 }
 
-int cgs_refine2d(const float* const* w, const float* const* b, int nlayers, int nhidden, const float* x, float real_sigmoid_mean,
-                 float inv_batch, int steps, float rate, int method, float* best_x, float* best_step, float* traj, int B,
-                 void* stream) {
+static int refine2d_launch(const float* const* w, const float* const* b, int nlayers, int nhidden, const float* x, float mean_host,
+                           const float* mean_dev, float inv_batch, int steps, float rate, int method, float* best_x, float* best_step,
+                           float* traj, int B, void* stream) {
     MlpParams p;
     int rc = mlp_fill(p, w, b, nlayers, nhidden, "refine2d");
     if (rc) return rc;
@@ -196,10 +198,23 @@ int cgs_refine2d(const float* const* w, const float* const* b, int nlayers, int 
     const size_t smem = mlp_smem(nlayers);
     (void)hipFuncSetAttribute((const void*)refine2d_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     int blocks = (B + 15) / 16; if (blocks > 256) blocks = 256;
-    hipLaunchKernelGGL(refine2d_kernel, dim3(blocks), dim3(1024), smem, (hipStream_t)stream, p, x, real_sigmoid_mean, inv_batch, steps, rate,
+    hipLaunchKernelGGL(refine2d_kernel, dim3(blocks), dim3(1024), smem, (hipStream_t)stream, p, x, mean_host, mean_dev, inv_batch, steps, rate,
                        method, best_x, best_step, traj, B);
     CGS_CHECK_LAUNCH("refine2d");
     return CGS_OK;
+}
+
+int cgs_refine2d(const float* const* w, const float* const* b, int nlayers, int nhidden, const float* x, float real_sigmoid_mean,
+                 float inv_batch, int steps, float rate, int method, float* best_x, float* best_step, float* traj, int B,
+                 void* stream) {
+    return refine2d_launch(w, b, nlayers, nhidden, x, real_sigmoid_mean, nullptr, inv_batch, steps, rate, method, best_x, best_step, traj, B, stream);
+}
+
+int cgs_refine2d_devbase(const float* const* w, const float* const* b, int nlayers, int nhidden, const float* x,
+                         const float* real_sigmoid_mean_dev, float inv_batch, int steps, float rate, int method, float* best_x,
+                         float* best_step, float* traj, int B, void* stream) {
+    if (!real_sigmoid_mean_dev) return cgs_set_error(CGS_EINVAL, "refine2d_devbase: null baseline pointer");
+    return refine2d_launch(w, b, nlayers, nhidden, x, 0.f, real_sigmoid_mean_dev, inv_batch, steps, rate, method, best_x, best_step, traj, B, stream);
 }
 
 }  // extern "C"

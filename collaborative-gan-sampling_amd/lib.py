@@ -56,6 +56,7 @@ SIGNATURES = {
     "cgs_refine_select_rows": (_i, [_p, _p, _p, _i, _p, _p, _i, _i, _p]),
     "cgs_mlp2d_sigmoid_saliency": (_i, [_p, _p, _i, _i, _p, _p, _p, _i, _f, _p]),
     "cgs_refine2d": (_i, [_p, _p, _i, _i, _p, _f, _f, _i, _f, _i, _p, _p, _p, _i, _p]),
+    "cgs_refine2d_devbase": (_i, [_p, _p, _i, _i, _p, _p, _f, _i, _f, _i, _p, _p, _p, _i, _p]),
     "cgs_conv_wgrad_ws_bytes": (_z, [_i] * 9),
     "cgs_conv2d_nhwc_bwd_weight": (_i, [_p] * 3 + [_i] * 9 + [_i, _p, _z, _p]),
     "cgs_linear_bwd_weight": (_i, [_p] * 3 + [_i] * 3 + [_i, _p, _z, _p]),

@@ -68,9 +68,13 @@ class MLPDiscriminator:
         best = torch.empty((B, 2), dtype=torch.float32, device=self.dev)
         step = torch.empty(B, dtype=torch.float32, device=self.dev)
         traj = torch.empty((B, steps + 1, 2), dtype=torch.float32, device=self.dev) if want_traj else None
-        L.call("cgs_refine2d", self._wp, self._bp, self.nlayers, self.nhidden, xd.data_ptr(), float(real_sigmoid_mean), 1.0 / B,
-               int(steps), float(rate), _METHODS[method], best.data_ptr(), step.data_ptr(), None if traj is None else traj.data_ptr(),
-               B, torch.cuda.current_stream(self.dev).cuda_stream)
+        tail = (1.0 / B, int(steps), float(rate), _METHODS[method], best.data_ptr(), step.data_ptr(),
+                None if traj is None else traj.data_ptr(), B, torch.cuda.current_stream(self.dev).cuda_stream)
+        if isinstance(real_sigmoid_mean, torch.Tensor):            # a device scalar: no host round trip, batches queue back to back
+            base = real_sigmoid_mean.to(self.dev, torch.float32).reshape(1)
+            L.call("cgs_refine2d_devbase", self._wp, self._bp, self.nlayers, self.nhidden, xd.data_ptr(), base.data_ptr(), *tail)
+        else:
+            L.call("cgs_refine2d", self._wp, self._bp, self.nlayers, self.nhidden, xd.data_ptr(), float(real_sigmoid_mean), *tail)
         return best, step, traj
 
 

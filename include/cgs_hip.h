@@ -208,6 +208,12 @@ int cgs_refine2d(const float* const* w, const float* const* b, int nlayers, int 
                  float real_sigmoid_mean, float inv_batch, int steps, float rate, int method,
                  float* best_x, float* best_step, float* traj, int B, void* stream);
 
+/* The same with the baseline read from DEVICE memory (one float): the real batch's mean sigmoid never visits the host, so
+ * consecutive batches queue without a synchronisation. */
+int cgs_refine2d_devbase(const float* const* w, const float* const* b, int nlayers, int nhidden, const float* x,
+                         const float* real_sigmoid_mean_dev, float inv_batch, int steps, float rate, int method,
+                         float* best_x, float* best_step, float* traj, int B, void* stream);
+
 /* ---- discriminator shaping step (the caller after the refinement path: nsgan/GAN.py:270-272, 126-146) ----------
  * Weight gradients of D's layers, the BCE seed with 0/1 targets, and the Adam update.  NOT part of the frozen-weight
  * refinement loop; provided so the method's only training step (shape D on refined samples) runs on the same ABI. */

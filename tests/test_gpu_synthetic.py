@@ -90,3 +90,20 @@ def test_fused_refiner_methods_vs_oracle_large_batch(method):
     assert agree.mean() > 0.98                                       # best-step flips only on numerical ties
     traj_close(best.cpu().numpy()[agree], want[agree])
     np.testing.assert_allclose(traj.cpu().numpy()[:, 0, :], fake, rtol=0, atol=0)
+
+
+def test_device_baseline_equals_host_baseline():
+    """cgs_refine2d_devbase: the real batch's mean sigmoid passed as a device scalar gives the bits of the host-float call."""
+    import numpy as np
+    import torch
+    from cgs_amd.synthetic import MLPDiscriminator
+    from oracle import sampling_ref as S
+    d = torch.device("cuda:0")
+    Ws, bs = S.mlp_init(64, 6, seed=2019, scale=2.0)
+    D = MLPDiscriminator.from_lists([w.numpy() for w in Ws], [b.numpy() for b in bs], d)
+    x = torch.from_numpy((3.0 * np.random.RandomState(3).randn(512, 2)).astype(np.float32)).to(d)
+    real = torch.from_numpy(np.random.RandomState(4).randn(512, 2).astype(np.float32)).to(d)
+    base = D.sigmoid_and_saliency(real, want_saliency=False)[0].mean()
+    a = D.refine(x, base, 10, 0.1, "ladam")
+    b = D.refine(x, float(base.item()), 10, 0.1, "ladam")
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
