@@ -61,10 +61,13 @@ static int run_dir(const CgsLayer& L, bool dirT, int B, const float* in, const f
     if (!dirT && cgs_conv_smalln_f_ok(L, B, epilogue) && ws && ws_bytes >= cgs_conv_smalln_f_ws_floats(L) * sizeof(float) &&
         !(((uintptr_t)in & 15) || ((uintptr_t)ws & 15)))
         return cgs_conv_smalln_f_launch(L, B, in, w, bias, out, epilogue, (float*)ws, ws_bytes, prepacked, s);
-    if (!dirT && cgs_conv_patch_ok(L, epilogue) && ws && ws_bytes >= cgs_conv_patch_ws_floats(L) * sizeof(float) &&
-        !(((uintptr_t)ws & 15) || ((uintptr_t)out & 15) || ((uintptr_t)bias & 15) || ((uintptr_t)ep_a & 15) ||
-          ((uintptr_t)ep_b & 15) || ((uintptr_t)ep_aux & 15)))
-        return cgs_conv_patch_launch(L, B, in, w, bias, out, epilogue, ep_a, ep_b, ep_aux, (float*)ws, ws_bytes, prepacked, s);
+    {
+        const bool patch_f = !dirT && cgs_conv_patch_ok(L, epilogue), patch_t = dirT && cgs_conv_patch_T_ok(L);
+        if ((patch_f || patch_t) && ws && ws_bytes >= cgs_conv_patch_ws_floats(L, dirT) * sizeof(float) &&
+            !(((uintptr_t)ws & 15) || ((uintptr_t)out & 15) || ((uintptr_t)bias & 15) || ((uintptr_t)ep_a & 15) ||
+              ((uintptr_t)ep_b & 15) || ((uintptr_t)ep_aux & 15)))
+            return cgs_conv_patch_launch(L, dirT, B, in, w, bias, out, epilogue, ep_a, ep_b, ep_aux, (float*)ws, ws_bytes, prepacked, s);
+    }
     IgemmParams p;
     p.in = in; p.bias = bias; p.ep_a = ep_a; p.ep_b = ep_b; p.ep_aux = ep_aux; p.out = out; p.B = B; p.epilogue = epilogue;
     if (dirT) cgs_geom_T(L, p); else cgs_geom_F(L, p);

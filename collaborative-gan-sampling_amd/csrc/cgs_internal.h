@@ -121,7 +121,8 @@ size_t cgs_conv_smalln_f_ws_floats(const CgsLayer& L);
 int cgs_conv_smalln_f_launch(const CgsLayer& L, int B, const float* in, const float* w, const float* bias, float* out,
                              int epilogue, float* ws, size_t ws_bytes, int prepacked, hipStream_t s);
 int cgs_conv_patch_ok(const CgsLayer& L, int epilogue);
-size_t cgs_conv_patch_ws_floats(const CgsLayer& L);
-int cgs_conv_patch_launch(const CgsLayer& L, int B, const float* in, const float* w, const float* bias, float* out, int epilogue,
-                          const float* ep_a, const float* ep_b, const float* ep_aux, float* ws, size_t ws_bytes, int prepacked,
-                          hipStream_t s);
+int cgs_conv_patch_T_ok(const CgsLayer& L);          // backward-data of a stride-1 conv with <= 4 output channels
+size_t cgs_conv_patch_ws_floats(const CgsLayer& L, bool dirT);
+int cgs_conv_patch_launch(const CgsLayer& L, bool dirT, int B, const float* in, const float* w, const float* bias, float* out,
+                          int epilogue, const float* ep_a, const float* ep_b, const float* ep_aux, float* ws, size_t ws_bytes,
+                          int prepacked, hipStream_t s);

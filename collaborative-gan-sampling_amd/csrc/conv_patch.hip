@@ -23,6 +23,7 @@ struct PatchParams {
     float* out;           // [B,Hout,Wout,N]
     int B, Hin, Win, Cred, Hout, Wout, N, Np;
     int kh, kw, pt, pl, K, Kp;
+    int S;                // stride (1 or 2)
     int PH, PW, pitch;    // patch rows, pixels per row, floats per LDS patch row
     int epilogue;
 };
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(256, 2) void conv_patch_kernel(PatchParams p) {
     const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void*)p.in, 0, (int)((unsigned)p.B * (unsigned)p.Hin * (unsigned)p.Win * (unsigned)p.Cred * 4u), 0x00020000);
     const int rowf = p.PW * p.Cred;                      // valid floats per patch row
-    const int iy0 = 2 * oy0 - p.pt, ix0 = 2 * ox0 - p.pl;
+    const int iy0 = p.S * oy0 - p.pt, ix0 = p.S * ox0 - p.pl;
     {   // a patch row is one contiguous run of the NHWC image row: range-check the flattened column; all of a
         // thread's loads are issued before the first LDS store so they are in flight together
         const int rowlen = p.Win * p.Cred, col0 = ix0 * p.Cred;
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(256, 2) void conv_patch_kernel(PatchParams p) {
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm) {
         const int m = wm * 64 + tm * 32 + j;
-        rowbase[tm] = (2 * (m / TC)) * p.pitch + (2 * (m % TC)) * p.Cred;
+        rowbase[tm] = (p.S * (m / TC)) * p.pitch + (p.S * (m % TC)) * p.Cred;
     }
     f32x16 acc[2];
 #pragma unroll
@@ -171,37 +172,70 @@ __global__ __launch_bounds__(256, 2) void conv_patch_kernel(PatchParams p) {
     }
 }
 
-static void patch_geom(const CgsLayer& L, PatchParams& p) {
-    p.Hin = L.Hb; p.Win = L.Wb; p.Cred = L.Cb; p.Hout = L.Hs; p.Wout = L.Ws; p.N = L.Cs; p.Np = cgs_round_up(L.Cs, PBN);
-    p.kh = L.kh; p.kw = L.kw; p.pt = cgs_same_pad_before(L.Hb, L.kh, 2); p.pl = cgs_same_pad_before(L.Wb, L.kw, 2);
-    p.K = L.kh * L.kw * L.Cb; p.Kp = cgs_round_up(p.K, 2);
-    p.PH = 2 * (TR - 1) + L.kh; p.PW = 2 * (TC - 1) + L.kw;
-    p.pitch = p.PW * L.Cb + 1;
+// dirT = false: the conv itself (big -> small, Cb <= 4 input channels, stride 1 or 2).
+// dirT = true : the backward-data of a STRIDE-1 conv whose output has <= 4 channels (small -> big at the same resolution):
+//               dx[i] = sum_ky dy[i + pt - ky] w[ky] = sum_ky' dy[i - (kh-1-pt) + ky'] w[kh-1-ky'] -- the same stride-1
+//               correlation with the taps flipped, the padding mirrored and the weight matrix transposed (pack kernel).
+static void patch_geom(const CgsLayer& L, bool dirT, PatchParams& p) {
+    const int S = dirT ? 1 : L.sh;
+    const int pt = cgs_same_pad_before(L.Hb, L.kh, L.sh), pl = cgs_same_pad_before(L.Wb, L.kw, L.sw);
+    if (!dirT) { p.Hin = L.Hb; p.Win = L.Wb; p.Cred = L.Cb; p.Hout = L.Hs; p.Wout = L.Ws; p.N = L.Cs; p.pt = pt; p.pl = pl; }
+    else { p.Hin = L.Hs; p.Win = L.Ws; p.Cred = L.Cs; p.Hout = L.Hb; p.Wout = L.Wb; p.N = L.Cb; p.pt = L.kh - 1 - pt; p.pl = L.kw - 1 - pl; }
+    p.Np = cgs_round_up(p.N, PBN);
+    p.kh = L.kh; p.kw = L.kw; p.S = S;
+    p.K = L.kh * L.kw * p.Cred; p.Kp = cgs_round_up(p.K, 2);
+    p.PH = S * (TR - 1) + L.kh; p.PW = S * (TC - 1) + L.kw;
+    p.pitch = p.PW * p.Cred + 1;
 }
 
-// F direction only (big -> small), stride 2, <= 4 input channels, output tiles of 8 x 16 pixels, N % 4 == 0
+// <= 4 reduction channels, output tiles of 8 x 16 pixels, N % 4 == 0
 int cgs_conv_patch_ok(const CgsLayer& L, int epilogue) {
     (void)epilogue;
-    return L.Cb <= 4 && L.sh == 2 && L.sw == 2 && (L.Hs % TR) == 0 && (L.Ws % TC) == 0 && (L.Cs % 4) == 0 &&
-           L.kh * L.kw * L.Cb <= 128 && L.kh <= 7 && L.kw <= 7 &&
-           (2 * (TR - 1) + L.kh) * (2 * (TC - 1) + L.kw) * L.Cb <= 10 * 256;
+    return L.Cb <= 4 && L.sh == L.sw && (L.sh == 1 || L.sh == 2) && (L.Hs % TR) == 0 && (L.Ws % TC) == 0 && (L.Cs % 4) == 0 &&
+           L.kh * L.kw * L.Cb <= 160 && L.kh <= 7 && L.kw <= 7 &&
+           (L.sh * (TR - 1) + L.kh) * (L.sh * (TC - 1) + L.kw) * L.Cb <= 10 * 256;
 }
 
-size_t cgs_conv_patch_ws_floats(const CgsLayer& L) {
-    return (size_t)cgs_round_up(L.kh * L.kw * L.Cb, 2) * cgs_round_up(L.Cs, PBN);
+int cgs_conv_patch_T_ok(const CgsLayer& L) {
+    return L.Cs <= 4 && L.sh == 1 && L.sw == 1 && (L.Hb % TR) == 0 && (L.Wb % TC) == 0 && (L.Cb % 4) == 0 &&
+           L.kh * L.kw * L.Cs <= 160 && L.kh <= 7 && L.kw <= 7 && ((TR - 1) + L.kh) * ((TC - 1) + L.kw) * L.Cs <= 10 * 256;
 }
 
-int cgs_conv_patch_launch(const CgsLayer& L, int B, const float* in, const float* w, const float* bias, float* out, int epilogue,
-                          const float* ep_a, const float* ep_b, const float* ep_aux, float* ws, size_t ws_bytes, int prepacked,
-                          hipStream_t s) {
+size_t cgs_conv_patch_ws_floats(const CgsLayer& L, bool dirT) {
+    return dirT ? (size_t)cgs_round_up(L.kh * L.kw * L.Cs, 2) * cgs_round_up(L.Cb, PBN)
+                : (size_t)cgs_round_up(L.kh * L.kw * L.Cb, 2) * cgs_round_up(L.Cs, PBN);
+}
+
+// dirT: wk[(ky', kx', c)][n] = w[kh-1-ky'][kw-1-kx'][n][c]   (w is [kh][kw][Cb = n][Cs = c])
+__global__ void pack_patch_weights_T_kernel(const float* __restrict__ w, float* __restrict__ wk, int kh, int kw, int Cb, int Cs,
+                                            int K, int Kp, int Np) {
+    const int total = Kp * Np;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int k = i / Np, n = i - k * Np;
+        float v = 0.f;
+        if (k < K && n < Cb) {
+            const int c = k % Cs, t = k / Cs, kx = t % kw, ky = t / kw;
+            v = w[(((size_t)(kh - 1 - ky) * kw + (kw - 1 - kx)) * Cb + n) * Cs + c];
+        }
+        wk[i] = v;
+    }
+}
+
+int cgs_conv_patch_launch(const CgsLayer& L, bool dirT, int B, const float* in, const float* w, const float* bias, float* out,
+                          int epilogue, const float* ep_a, const float* ep_b, const float* ep_aux, float* ws, size_t ws_bytes,
+                          int prepacked, hipStream_t s) {
     PatchParams p;
-    patch_geom(L, p);
+    patch_geom(L, dirT, p);
     p.in = in; p.wk = ws; p.bias = bias; p.ep_a = ep_a; p.ep_b = ep_b; p.ep_aux = ep_aux; p.out = out; p.B = B; p.epilogue = epilogue;
-    const size_t need = cgs_conv_patch_ws_floats(L) * sizeof(float);
+    const size_t need = cgs_conv_patch_ws_floats(L, dirT) * sizeof(float);
     if (!ws || ws_bytes < need) return cgs_set_error(CGS_EWORKSPACE, "conv_patch: workspace %zu < %zu bytes", ws_bytes, need);
-    if ((long)B * L.Hb * L.Wb * L.Cb * 4 > 0x7fffffffL) return cgs_set_error(CGS_EINVAL, "conv_patch: input exceeds 2 GiB");
+    if ((long)B * p.Hin * p.Win * p.Cred * 4 > 0x7fffffffL) return cgs_set_error(CGS_EINVAL, "conv_patch: input exceeds 2 GiB");
     if (!prepacked) {
-        hipLaunchKernelGGL(pack_patch_weights_kernel, dim3(cgs_ceil_div(p.Kp * p.Np, 256)), dim3(256), 0, s, w, ws, p.K, p.Kp, p.N, p.Np);
+        if (dirT)
+            hipLaunchKernelGGL(pack_patch_weights_T_kernel, dim3(cgs_ceil_div(p.Kp * p.Np, 256)), dim3(256), 0, s, w, ws, L.kh, L.kw, L.Cb,
+                               L.Cs, p.K, p.Kp, p.Np);
+        else
+            hipLaunchKernelGGL(pack_patch_weights_kernel, dim3(cgs_ceil_div(p.Kp * p.Np, 256)), dim3(256), 0, s, w, ws, p.K, p.Kp, p.N, p.Np);
         CGS_CHECK_LAUNCH("pack_patch_weights");
     }
     size_t kloop = ((size_t)p.Kp * PBN + (size_t)p.PH * p.pitch + p.Kp) * sizeof(float);
@@ -213,7 +247,7 @@ int cgs_conv_patch_launch(const CgsLayer& L, int B, const float* in, const float
         done = true;
     }
     if (smem > 96 * 1024 || p.PH * p.PW * p.Cred > 10 * 256) return cgs_set_error(CGS_EINVAL, "conv_patch: patch too large");
-    const long blocks = (long)B * (L.Hs / TR) * (L.Ws / TC) * (p.Np / PBN);
+    const long blocks = (long)B * (p.Hout / TR) * (p.Wout / TC) * (p.Np / PBN);
     if (blocks == 0) return CGS_OK;
     if (blocks > 0x7fffffffL) return cgs_set_error(CGS_EINVAL, "conv_patch: grid too large");
     hipLaunchKernelGGL(conv_patch_kernel, dim3((unsigned)blocks), dim3(256), smem, s, p);

@@ -43,7 +43,9 @@ CONV_CASES = [  # B,H,W,Cin,Cout,k,s
     (8, 128, 128, 64, 3, 7, 1),      # c7s1-3 RGB head: stride-1 small-N VALU kernel (>= 512 tiles)
     (2, 256, 256, 16, 1, 3, 1),      # same kernel, N=1, 3x3, one channel chunk
     (32, 64, 64, 32, 4, 5, 1),       # same kernel, N=4
-    (2, 32, 32, 64, 3, 7, 1),        # too few tiles for it: N-padded MFMA path
+    (2, 32, 32, 64, 3, 7, 1),        # too few tiles for the VALU head kernel; its backward-data = LDS-patch kernel, transposed stride-1 form
+    (2, 16, 32, 3, 64, 7, 1),        # c7s1-64 from RGB: LDS-patch kernel at stride 1 (K = 147)
+    (3, 8, 16, 4, 32, 3, 1),         # LDS-patch, stride 1, 4 input channels
     (2, 64, 32, 1, 32, 4, 2),        # 1 channel, 4x4 kernel, 32x16 quads -> global-load quad kernel (Ws % 32 != 0)
     (2, 16, 64, 2, 16, 5, 2),        # 2 channels, 8x32 quads: LDS-patch kernel with a single 16-channel chunk
 ]
@@ -60,6 +62,25 @@ def test_conv2d_fwd(B, H, W, Cin, Cout, k, s, epi):
     got = K.conv2d_fwd(x.to(dev()), w.to(dev()), b.to(dev()), s, s, lib.EPI_LRELU if epi == "lrelu" else lib.EPI_NONE)
     assert got.shape == want.shape
     close(got, want, 2e-5)
+
+
+def test_stride1_rgb_layers_use_the_patch_kernel():
+    """c7s1-64 (3 -> 64, stride 1) forward and the backward-data of c7s1-3 (64 <- 3): both are stride-1 correlations over a
+    3-channel tensor and run on conv_patch_kernel (the latter with flipped taps / transposed weights)."""
+    from cgs_amd import kernels as K, lib
+    d = dev()
+    x, w, b = rnd((2, 16, 32, 3), 1), rnd((7, 7, 3, 64), 2, 0.05), rnd((64,), 3, 0.1)
+    got = K.conv2d_fwd(x.to(d), w.to(d), b.to(d), 1, 1)
+    assert lib.last_kernel() == "conv_patch_kernel"
+    close(got, R.conv2d(x, w, b, 1, 1), 2e-5)
+    xs = rnd((2, 16, 32, 64), 4).requires_grad_(True)
+    w2 = rnd((7, 7, 64, 3), 5, 0.05)
+    y = R.conv2d(xs, w2, torch.zeros(3), 1, 1)
+    dy = rnd(tuple(y.shape), 6)
+    (y * dy).sum().backward()
+    got = K.conv2d_bwd_data(dy.to(d), w2.to(d), (16, 32), 1, 1)
+    assert lib.last_kernel() == "conv_patch_kernel"
+    close(got, xs.grad, 2e-5)
 
 
 def test_conv2d_smalln_head_tanh():
