@@ -171,7 +171,8 @@ __global__ __launch_bounds__(64 * NW, 2) void igemm_kernel(IgemmParams p) {
     float* As = smem;                              // [2][BM][LDA]
     float* Bs = smem + 2 * BM * LDA;               // [2][BK/4][BN][4]
     constexpr int KLOOP_F = 2 * BM * LDA + 2 * BK * BN;              // floats of the K-loop double buffers
-    constexpr int STAGE_F = NW * (BM / 2) * (BN / WN + 4);            // floats of the epilogue staging tiles
+    constexpr int EH = (VEC && TBK == 16) ? 2 : 1;                    // epilogue passes (the 16-deep variant stages half a wave tile at a time)
+    constexpr int STAGE_F = NW * (BM / 2 / EH) * (BN / WN + 4);       // floats of the epilogue staging tiles
     int* rowpix = (int*)(smem + (KLOOP_F > STAGE_F ? KLOOP_F : STAGE_F));   // [BM] output pixel of each tile row, -1 = out of range
 
     // block id -> (m-tile, n-tile); class = blockIdx.y (heaviest class first).  Measured and rejected: computing all
@@ -290,7 +291,7 @@ __global__ __launch_bounds__(64 * NW, 2) void igemm_kernel(IgemmParams p) {
     auto next_chunk = [&](int kt) -> int {
         if (!skip_ok) return kt;
         while (kt < nk) {
-            const int t = kt % ntaps;
+            const int t = (VEC && TBK == 16 ? kt >> 1 : kt) % ntaps;     // 16-deep tiles: two per (32-channel chunk, tap)
             const int ia = t / c.ntx, ib = t - ia * c.ntx;
             const int ta = cgs_tap_order(ia, c.nty, PAR), tb = cgs_tap_order(ib, c.ntx, PAR);
             const int iy = u_iy + ta * p.dstep, ix = u_ix + tb * p.dstep;
@@ -308,8 +309,9 @@ __global__ __launch_bounds__(64 * NW, 2) void igemm_kernel(IgemmParams p) {
 #define LOAD_TILE(kt_)                                                                                          \
     do {                                                                                                        \
         if constexpr (VEC) {                                                                                    \
-            const int chunk_ = (kt_) / ntaps, t = (kt_) - chunk_ * ntaps;                                       \
-            const int ci = chunk_ * BK + aq * 4;                                                                \
+            const int kt32_ = TBK == 16 ? (kt_) >> 1 : (kt_);        /* K order is packed in 32-channel granules */     \
+            const int chunk_ = kt32_ / ntaps, t = kt32_ - chunk_ * ntaps;                                       \
+            const int ci = chunk_ * 32 + (TBK == 16 ? ((kt_) & 1) * 16 : 0) + aq * 4;                           \
             const int ia_ = t / c.ntx, ib_ = t - ia_ * c.ntx;                                                   \
             const int ta = cgs_tap_order(ia_, c.nty, PAR), tb = cgs_tap_order(ib_, c.ntx, PAR);                 \
             const int dy = ta * p.dstep, dx = tb * p.dstep;                                                     \
@@ -440,37 +442,48 @@ __global__ __launch_bounds__(64 * NW, 2) void igemm_kernel(IgemmParams p) {
         // the aux loads / output stores are 16 bytes per lane, 256 contiguous bytes per 16 lanes: 4x fewer
         // store (and aux load) instructions than the per-register scalar form below.
         constexpr int LDE = WTN + 4;
-        float* E = smem + wave * (BM / 2) * LDE;  // this wave's [BM/2][LDE] staging tile (launch_cfg sizes the LDS for it)
+        constexpr int ER = BM / 2 / EH;           // rows staged per pass
+        float* E = smem + wave * ER * LDE;        // this wave's [ER][LDE] staging tile (launch_cfg sizes the LDS for it)
         constexpr int LPR = WTN / 4;              // lanes per row (16 for 64 columns, 8 for 32)
         constexpr int RPP = 64 / LPR;             // rows per pass
         const int c4 = (lane % LPR) * 4, rsub = lane / LPR;
         const int n = n0 + wn * WTN + c4;
-        // all waves are past the loop's final barrier: the K-loop buffers are dead (rowpix lives behind the staging area)
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    E[(tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * LDE + tn * 32 + j] = acc[tm][tn][r];
-        // the same wave reads what it wrote: LDS ops of one wave complete in order; only the compiler must keep it
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        f32x4 bias = {0.f, 0.f, 0.f, 0.f}, ea = {1.f, 1.f, 1.f, 1.f}, eb = {0.f, 0.f, 0.f, 0.f};
         if (n < p.N) {
-            f32x4 bias = {0.f, 0.f, 0.f, 0.f}, ea = {1.f, 1.f, 1.f, 1.f}, eb = {0.f, 0.f, 0.f, 0.f};
             if (p.bias) bias = *(const f32x4*)(p.bias + n);
             if (p.epilogue == CGS_EPI_AFFINE_RELU) { ea = *(const f32x4*)(p.ep_a + n); eb = *(const f32x4*)(p.ep_b + n); }
             if (p.epilogue == CGS_EPI_RELU_BWD_AFFINE) ea = *(const f32x4*)(p.ep_a + n);
-            const int* rp = rowpix + wm * (BM / 2);
-            switch (p.epilogue) {     // wave-uniform; each case is one compact branch-free row loop
-                case CGS_EPI_NONE: epilogue_rows<CGS_EPI_NONE, BM / 2, RPP, LDE>(p, E, rp, rsub, c4, n, bias, ea, eb); break;
-                case CGS_EPI_LRELU: epilogue_rows<CGS_EPI_LRELU, BM / 2, RPP, LDE>(p, E, rp, rsub, c4, n, bias, ea, eb); break;
-                case CGS_EPI_AFFINE_RELU: epilogue_rows<CGS_EPI_AFFINE_RELU, BM / 2, RPP, LDE>(p, E, rp, rsub, c4, n, bias, ea, eb); break;
-                case CGS_EPI_TANH: epilogue_rows<CGS_EPI_TANH, BM / 2, RPP, LDE>(p, E, rp, rsub, c4, n, bias, ea, eb); break;
-                case CGS_EPI_RELU_BWD_AFFINE: epilogue_rows<CGS_EPI_RELU_BWD_AFFINE, BM / 2, RPP, LDE>(p, E, rp, rsub, c4, n, bias, ea, eb); break;
-                case CGS_EPI_LRELU_BWD: epilogue_rows<CGS_EPI_LRELU_BWD, BM / 2, RPP, LDE>(p, E, rp, rsub, c4, n, bias, ea, eb); break;
-                default: epilogue_rows<CGS_EPI_TANH_BWD, BM / 2, RPP, LDE>(p, E, rp, rsub, c4, n, bias, ea, eb); break;
+        }
+        // all waves are past the loop's final barrier: the K-loop buffers are dead (rowpix lives behind the staging area)
+#pragma unroll
+        for (int ph = 0; ph < EH; ++ph) {
+#pragma unroll
+            for (int tm = ph * (TM / EH); tm < (ph + 1) * (TM / EH); ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        E[((tm - ph * (TM / EH)) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * LDE + tn * 32 + j] = acc[tm][tn][r];
+            // the same wave reads what it wrote: LDS ops of one wave complete in order; only the compiler must keep it
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (n < p.N) {
+                const int* rp = rowpix + wm * (BM / 2) + ph * ER;
+                switch (p.epilogue) {     // wave-uniform; each case is one compact branch-free row loop
+                    case CGS_EPI_NONE: epilogue_rows<CGS_EPI_NONE, ER, RPP, LDE>(p, E, rp, rsub, c4, n, bias, ea, eb); break;
+                    case CGS_EPI_LRELU: epilogue_rows<CGS_EPI_LRELU, ER, RPP, LDE>(p, E, rp, rsub, c4, n, bias, ea, eb); break;
+                    case CGS_EPI_AFFINE_RELU: epilogue_rows<CGS_EPI_AFFINE_RELU, ER, RPP, LDE>(p, E, rp, rsub, c4, n, bias, ea, eb); break;
+                    case CGS_EPI_TANH: epilogue_rows<CGS_EPI_TANH, ER, RPP, LDE>(p, E, rp, rsub, c4, n, bias, ea, eb); break;
+                    case CGS_EPI_RELU_BWD_AFFINE: epilogue_rows<CGS_EPI_RELU_BWD_AFFINE, ER, RPP, LDE>(p, E, rp, rsub, c4, n, bias, ea, eb); break;
+                    case CGS_EPI_LRELU_BWD: epilogue_rows<CGS_EPI_LRELU_BWD, ER, RPP, LDE>(p, E, rp, rsub, c4, n, bias, ea, eb); break;
+                    default: epilogue_rows<CGS_EPI_TANH_BWD, ER, RPP, LDE>(p, E, rp, rsub, c4, n, bias, ea, eb); break;
+                }
+            }
+            if (ph + 1 < EH) {            // the next pass overwrites the staging tile this wave has just read
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             }
         }
 #ifdef CGS_DIAG_STAMPS
@@ -580,7 +593,8 @@ size_t cgs_igemm_splitk_bytes(const IgemmParams& p) {
 
 template <int BM, int BN, int NW, bool VEC, int TBK, bool PAR = false>
 static int launch_cfg(const IgemmParams& p, hipStream_t s) {
-    constexpr size_t kloop_f = (size_t)2 * BM * (TBK + 4) + 2 * TBK * BN, stage_f = (size_t)NW * (BM / 2) * (BN / (NW / 2) + 4);
+    constexpr int EH = (VEC && TBK == 16) ? 2 : 1;
+    constexpr size_t kloop_f = (size_t)2 * BM * (TBK + 4) + 2 * TBK * BN, stage_f = (size_t)NW * (BM / 2 / EH) * (BN / (NW / 2) + 4);
     constexpr size_t smem = (kloop_f > stage_f ? kloop_f : stage_f) * sizeof(float) + BM * sizeof(int);
     static bool attr_done[64] = {};       // per device: the attribute belongs to the device's code object
     int dev_ = 0;
@@ -671,6 +685,21 @@ int cgs_igemm_launch(const IgemmParams& p_in, void* slab, size_t slab_bytes, hip
     }
     // K tile: 32 when every tile lies inside one tap (VEC); 16 for the generic-K gather (small K: less padding waste)
     // (8-wave 128x128 blocks, 4 waves per SIMD: +1.3 % with one batch in flight, +-0 with two -- not kept)
+    // 16-deep K tiles (LDS 37 KB, 110 VGPRs -> FOUR blocks per CU instead of two: more independent waves to fill the matrix
+    // pipe's gaps; the epilogue stages half a wave tile at a time to fit) win 2.5-9 % when every parity class brings at
+    // least two blocks per CU, and lose up to 11 % on smaller grids, where a CU holds one block and the doubled barrier
+    // count per FLOP is all that is left of the change (measured per layer, 40 launches each, dcgan64 / dcgan32 / config 5).
+    bool deep = true;
+    if (vec && p.splitk == 1) {
+        long min_blocks = 1L << 40;
+        for (int i = 0; i < p.nclasses; ++i) {
+            const long m = (long)p.B * p.cls[i].R * p.cls[i].C;
+            if (m > 0) { const long bl = (m + 127) / 128 * (p.Np / (wide ? 128 : 64)); if (bl < min_blocks) min_blocks = bl; }
+        }
+        deep = min_blocks < 512;        // (thresholds 256 / 512 / 1024 measured: 512 is best on dcgan64 and neutral elsewhere)
+    }
+    if (vec && !deep && !p.tap_parity) return wide ? launch_cfg<128, 128, 4, true, 16>(p, s) : launch_cfg<128, 64, 4, true, 16>(p, s);
+    if (vec && !deep && p.tap_parity) return wide ? launch_cfg<128, 128, 4, true, 16, true>(p, s) : launch_cfg<128, 64, 4, true, 16, true>(p, s);
     if (vec && p.tap_parity) return wide ? launch_cfg<128, 128, 4, true, 32, true>(p, s) : launch_cfg<128, 64, 4, true, 32, true>(p, s);
     if (vec) return wide ? launch_cfg<128, 128, 4, true, 32>(p, s) : launch_cfg<128, 64, 4, true, 32>(p, s);
     return wide ? launch_cfg<128, 128, 4, false, 16>(p, s) : launch_cfg<128, 64, 4, false, 16>(p, s);

@@ -336,3 +336,47 @@ def test_edge_shapes_and_argument_errors():
     rc = lib.load().cgs_conv2d_nhwc_fwd(xd.data_ptr(), wd.data_ptr(), None, yd.data_ptr(), 0, 8, 8, 32, 64, 5, 5, 2, 2, 0, None, None,
                                        small.data_ptr(), small.numel() * 4, 0, None)
     assert rc == lib.EINVAL
+
+
+@pytest.mark.parametrize("case", ["conv_pixmajor", "conv_parity", "conv_bwd_T", "deconv_fwd_T_tanh", "deconv_bwd_F"])
+def test_many_block_grids_use_the_16_deep_variant(case):
+    """Grids with >= 512 blocks per parity class run the 16-deep K-tile instantiation (four blocks per CU, half-staged
+    epilogue); every direction / tap order of it against the oracle, and that it really is the kernel that ran."""
+    from cgs_amd import kernels as K, lib
+    d = dev()
+    if case in ("conv_pixmajor", "conv_parity"):
+        B, H, Cin, Cout = (1024, 16, 32, 64) if case == "conv_pixmajor" else (256, 32, 32, 64)      # 8x8 grid: pixel-major; 16x16: parity taps
+        x, w, b = rnd((B, H, H, Cin), 1), rnd((5, 5, Cin, Cout), 2, 0.05), rnd((Cout,), 3, 0.1)
+        got = K.conv2d_fwd(x.to(d), w.to(d), b.to(d), 2, 2, lib.EPI_LRELU)
+        name = lib.last_kernel()
+        close(got, R.lrelu(R.conv2d(x, w, b, 2, 2)), 2e-5)
+        assert name == f"igemm_kernel<128, 64, 4, true, 16, {'true' if case == 'conv_parity' else 'false'}>", name
+    elif case == "conv_bwd_T":
+        B, H, Cin, Cout = 1024, 32, 32, 64
+        w = rnd((5, 5, Cin, Cout), 2, 0.05)
+        x = rnd((B, H, H, Cin), 1).requires_grad_(True)
+        y = R.conv2d(x, w, torch.zeros(Cout), 2, 2)
+        dy = rnd(tuple(y.shape), 4)
+        (y * dy).sum().backward()
+        got = K.conv2d_bwd_data(dy.to(d), w.to(d), (H, H), 2, 2)
+        name = lib.last_kernel()
+        close(got, x.grad, 2e-5)
+        assert name == "igemm_kernel<128, 64, 4, true, 16, false>", name
+    elif case == "deconv_fwd_T_tanh":
+        B, H, Cin, Cout = 1024, 16, 32, 64
+        x, w, b = rnd((B, H, H, Cin), 1), rnd((5, 5, Cout, Cin), 2, 0.05), rnd((Cout,), 3, 0.1)
+        got = K.deconv2d_fwd(x.to(d), w.to(d), b.to(d), (2 * H, 2 * H), 2, 2, lib.EPI_TANH)
+        name = lib.last_kernel()
+        close(got, torch.tanh(R.deconv2d(x, w, b, (B, 2 * H, 2 * H, Cout), 2, 2)), 2e-5)
+        assert name == "igemm_kernel<128, 64, 4, true, 16, false>", name
+    else:
+        B, H, Cin, Cout = 256, 16, 128, 32                                                         # F direction over dy [B,32,32,32] -> dx [B,16,16,128]
+        x = rnd((B, H, H, Cin), 1).requires_grad_(True)
+        w = rnd((5, 5, Cout, Cin), 2, 0.05)
+        y = R.deconv2d(x, w, torch.zeros(Cout), (B, 2 * H, 2 * H, Cout), 2, 2)
+        dy = rnd(tuple(y.shape), 4)
+        (y * dy).sum().backward()
+        got = K.deconv2d_bwd_data(dy.to(d), w.to(d), (H, H), 2, 2)
+        name = lib.last_kernel()
+        close(got, x.grad, 2e-5)
+        assert name == "igemm_kernel<128, 128, 4, true, 16, true>", name

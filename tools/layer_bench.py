@@ -15,7 +15,7 @@ convs = [(s, 3, 64), (s // 2, 64, 128), (s // 4, 128, 256), (s // 8, 256, 512)] 
 deconvs = [(s // 8, 256, 128), (s // 4, 128, 64), (s // 2, 64, 3)]                       # H, Cin, Cout
 
 
-def timeit(fn, n=5):
+def timeit(fn, n=int(os.environ.get("LB_ITERS", "5"))):
     fn(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
