@@ -13,9 +13,10 @@
 // k-ordered fma chain).  The transposed direction runs as s*s parity classes (blockIdx.y), each a
 // dense GEMM over only the taps that hit that output parity (no zero-stuffing).
 //
-// Tiling: 256 threads = 4 waves (2x2), block tile BM x BN x 32, each wave (BM/2)x(BN/2) as 32x32
+// Tiling: 256 threads = 4 waves (2x2), block tile BM x BN x {32,16}, each wave (BM/2)x(BN/2) as 32x32
 // MFMA tiles; double-buffered LDS with the next tile's global loads issued before the MFMA block
-// and written after it (register staging), one barrier per K tile; 2 blocks per CU.
+// and written after it (register staging), one barrier per K tile; 2 blocks per CU with 32-deep K
+// tiles, 4 with 16-deep ones (chosen per launch from the grid size, see cgs_igemm_launch).
 //
 // K ordering trick: inside a 32-deep chunk lane-half h of MFMA step (jj,e) contracts
 // k = 4*(2*jj+h)+e for BOTH operands, so every lane fetches its 4 consecutive k of a row / column
