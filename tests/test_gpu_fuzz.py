@@ -170,3 +170,36 @@ def test_conv_weight_gradient_random_shapes(B, H, W, Cin, Cout, k, s):
     got = K.conv2d_bwd_weight(x.to(d), dy.to(d), k, k, s, s)
     close(got, w.grad, 2e-5 * max(1.0, (B * y.shape[1] * y.shape[2] / 1000.0) ** 0.5))
     close(K.bias_grad(dy.to(d)), b.grad, 1e-5 * max(1.0, (B * y.shape[1] * y.shape[2] / 1000.0) ** 0.5))
+
+
+def big_cases(seed, n):
+    rs = np.random.RandomState(seed)
+    out = []
+    for _ in range(n):
+        H = int(rs.choice([8, 16, 32]))
+        out.append((1024 if H <= 16 else 256, H, int(rs.choice([32, 64, 96])), int(rs.choice([32, 64, 128])), int(rs.choice([3, 4, 5]))))
+    return out
+
+
+@pytest.mark.parametrize("B,H,Cin,Cout,k", big_cases(77 + SEED, max(6, N_CASES // 4)))
+def test_many_block_launch_equals_its_small_batch_pieces(B, H, Cin, Cout, k):
+    """Large grids take other code paths than small ones (16-deep K tiles at four blocks per CU, per-XCD block decode, pixel-major
+    rows with zero-tap skipping, parity-first taps) and are too big for the CPU oracle.  A convolution is independent per sample,
+    so the big launch must agree with the same op run on 64-sample pieces -- which take the small-grid paths the oracle tests
+    pin.  (Same tolerance as against the oracle: the pieces may split K and so add in another order.)"""
+    from cgs_amd import kernels as K
+    d = dev()
+    x = rnd((B, H, H, Cin), 1).to(d)
+    w, b = rnd((k, k, Cin, Cout), 2, 0.1).to(d), rnd((Cout,), 3, 0.2).to(d)
+    pieces = lambda fn, *ts: torch.cat([fn(*[t[i:i + 64].contiguous() for t in ts]) for i in range(0, B, 64)])
+    y = K.conv2d_fwd(x, w, b, 2, 2)
+    assert torch.allclose(y, pieces(lambda xx: K.conv2d_fwd(xx, w, b, 2, 2), x), rtol=0, atol=2e-5 * y.abs().max().item())
+    dy = rnd(tuple(y.shape), 4).to(d)
+    dx = K.conv2d_bwd_data(dy, w, (H, H), 2, 2)
+    assert torch.allclose(dx, pieces(lambda g: K.conv2d_bwd_data(g, w, (H, H), 2, 2), dy), rtol=0, atol=2e-5 * dx.abs().max().item())
+    wt = rnd((k, k, Cout, Cin), 5, 0.1).to(d)                      # deconv Cin -> Cout at twice the resolution
+    z = K.deconv2d_fwd(x, wt, b, (2 * H, 2 * H), 2, 2)
+    assert torch.allclose(z, pieces(lambda xx: K.deconv2d_fwd(xx, wt, b, (2 * H, 2 * H), 2, 2), x), rtol=0, atol=2e-5 * z.abs().max().item())
+    dz = rnd(tuple(z.shape), 6).to(d)
+    dxx = K.deconv2d_bwd_data(dz, wt, (H, H), 2, 2)
+    assert torch.allclose(dxx, pieces(lambda g: K.deconv2d_bwd_data(g, wt, (H, H), 2, 2), dz), rtol=0, atol=2e-5 * dxx.abs().max().item())
