@@ -5,7 +5,9 @@ A "step" = one pass of the hot path over one z-batch: propose (G head) + K-step 
 refinement (K+1 G-tail/D forwards, K backward-datas, momentum update, best-sample select) + final
 render, images left in HBM.  Default workload = BASELINE configs[2]: DCGAN CelebA 64x64, batch 1024
 per GPU, K = 20 (the configuration the 10k samples/s target is quoted on; it fits one GPU).
-Inputs (z batches) and weights are resident in HBM before the timed region.
+Inputs (z batches) and weights are resident in HBM before the timed region.  Two steps are in flight per GPU
+(--streams), and for the small configurations several logical batches share one launch, each with its own
+batch-norm statistics (--fuse; dcgan32 4 x 256, mnist 16 x 64): the work and the results of a step are unchanged.
 
 N > 1: one process per GPU (torch.distributed, backend nccl = RCCL), independent z-batches per rank
 (seed 2019+rank, weak scaling), and ONE RCCL all-gather per step of the refined images into the
