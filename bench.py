@@ -129,6 +129,21 @@ def bench_synthetic2d(args, dev, rank, world):
         print(json.dumps(out), flush=True)
 
 
+def self_launch(n_gpus):
+    """`python bench.py --gpus N` (N > 1) outside torch.distributed.run: start the N ranks as CHILD processes
+    (`python -m torch.distributed.run --nproc-per-node N bench.py <same arguments>`) before this process has touched the
+    GPU -- never an in-place exec -- and relay rank 0's JSON line (the children inherit stdout) and the exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as so:                                 # a free rendezvous port on the loopback interface
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -156,6 +171,8 @@ def main():
         args.steps = 256 if args.arch == "synthetic2d" else 4
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC for RCCL; must be set before HIP initialises
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args.gpus)
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
     if world != args.gpus:

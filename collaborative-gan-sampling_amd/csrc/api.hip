@@ -42,6 +42,25 @@ static int make_layer(CgsLayer& L, int kh, int kw, int sh, int sw, int Hb, int W
     return CGS_OK;
 }
 
+// Which kernel family (and therefore which packed-weight layout in the workspace) serves a call.  ONE decision function:
+// run_dir() dispatches on it and cgs_conv_family() reports it, so a caller that caches packed workspaces can key them by
+// the family and never hand one family's packed image to another (the epilogue and the pointer alignment take
+// part in the choice, not only the geometry).
+static int choose_family(const CgsLayer& L, bool dirT, int B, int epilogue, bool have_ws, size_t ws_bytes, bool in_al,
+                         bool ws_al, bool rest_al) {
+    if (dirT && smalln_ok(L, epilogue)) {
+        if ((L.Cs % 16) == 0 && have_ws && cgs_convt_quad_fits(L)) return CGS_FAMILY_QUAD;
+        if (epilogue < CGS_EPI_RELU_BWD_AFFINE) return CGS_FAMILY_SMALLN_T;             // VALU form (any Cs % 4 == 0), packs nothing
+    }
+    if (!dirT && cgs_conv_smalln_f_ok(L, B, epilogue) && have_ws && ws_bytes >= cgs_conv_smalln_f_ws_floats(L) * sizeof(float) &&
+        in_al && ws_al)
+        return CGS_FAMILY_SMALLN_F;
+    const bool patch_f = !dirT && cgs_conv_patch_ok(L, epilogue), patch_t = dirT && cgs_conv_patch_T_ok(L);
+    if ((patch_f || patch_t) && have_ws && ws_bytes >= cgs_conv_patch_ws_floats(L, dirT) * sizeof(float) && ws_al && rest_al)
+        return CGS_FAMILY_PATCH;
+    return CGS_FAMILY_IGEMM;
+}
+
 static int run_dir(const CgsLayer& L, bool dirT, int B, const float* in, const float* w, const float* bias, float* out,
                    int epilogue, const float* ep_a, const float* ep_b, const float* ep_aux, void* ws, size_t ws_bytes,
                    int prepacked, hipStream_t s, const char* who) {
@@ -52,21 +71,18 @@ static int run_dir(const CgsLayer& L, bool dirT, int B, const float* in, const f
     if (epilogue >= CGS_EPI_RELU_BWD_AFFINE && (!ep_aux || (epilogue == CGS_EPI_RELU_BWD_AFFINE && !ep_a)))
         return cgs_set_error(CGS_EINVAL, "%s: backward epilogue %d needs aux%s", who, epilogue, epilogue == CGS_EPI_RELU_BWD_AFFINE ? " and a" : "");
     if (dirT && (L.sh > 2 || L.sw > 2)) return cgs_set_error(CGS_EINVAL, "%s: transposed direction supports stride <= 2", who);
-    if (dirT && smalln_ok(L, epilogue)) {
-        if ((L.Cs % 16) == 0 && ws && cgs_convt_quad_fits(L))
+    const bool rest_al = !(((uintptr_t)out & 15) || ((uintptr_t)bias & 15) || ((uintptr_t)ep_a & 15) || ((uintptr_t)ep_b & 15) ||
+                           ((uintptr_t)ep_aux & 15));
+    switch (choose_family(L, dirT, B, epilogue, ws != nullptr, ws_bytes, !((uintptr_t)in & 15), !((uintptr_t)ws & 15), rest_al)) {
+        case CGS_FAMILY_QUAD:
             return cgs_convt_quad_launch(L, B, in, w, bias, out, epilogue, ep_a, ep_aux, (float*)ws, ws_bytes, prepacked, s);
-        if (epilogue < CGS_EPI_RELU_BWD_AFFINE)
-            return cgs_convt_smalln_launch(L, B, in, w, bias, out, epilogue, s);     // VALU form (any Cs % 4 == 0)
-    }
-    if (!dirT && cgs_conv_smalln_f_ok(L, B, epilogue) && ws && ws_bytes >= cgs_conv_smalln_f_ws_floats(L) * sizeof(float) &&
-        !(((uintptr_t)in & 15) || ((uintptr_t)ws & 15)))
-        return cgs_conv_smalln_f_launch(L, B, in, w, bias, out, epilogue, (float*)ws, ws_bytes, prepacked, s);
-    {
-        const bool patch_f = !dirT && cgs_conv_patch_ok(L, epilogue), patch_t = dirT && cgs_conv_patch_T_ok(L);
-        if ((patch_f || patch_t) && ws && ws_bytes >= cgs_conv_patch_ws_floats(L, dirT) * sizeof(float) &&
-            !(((uintptr_t)ws & 15) || ((uintptr_t)out & 15) || ((uintptr_t)bias & 15) || ((uintptr_t)ep_a & 15) ||
-              ((uintptr_t)ep_b & 15) || ((uintptr_t)ep_aux & 15)))
+        case CGS_FAMILY_SMALLN_T:
+            return cgs_convt_smalln_launch(L, B, in, w, bias, out, epilogue, s);
+        case CGS_FAMILY_SMALLN_F:
+            return cgs_conv_smalln_f_launch(L, B, in, w, bias, out, epilogue, (float*)ws, ws_bytes, prepacked, s);
+        case CGS_FAMILY_PATCH:
             return cgs_conv_patch_launch(L, dirT, B, in, w, bias, out, epilogue, ep_a, ep_b, ep_aux, (float*)ws, ws_bytes, prepacked, s);
+        default: break;
     }
     IgemmParams p;
     p.in = in; p.bias = bias; p.ep_a = ep_a; p.ep_b = ep_b; p.ep_aux = ep_aux; p.out = out; p.B = B; p.epilogue = epilogue;
@@ -121,6 +137,20 @@ size_t cgs_conv_ws_bytes_for(int op, int B, int H, int W, int Cin, int Cout, int
     p.B = B;
     if (dirT) cgs_geom_T(L, p); else cgs_geom_F(L, p);
     return packed + cgs_igemm_splitk_bytes(p);
+}
+
+int cgs_conv_family(int op, int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int sh, int sw, int epilogue,
+                    size_t ws_bytes) {
+    if (op < CGS_CONV_FWD || op > CGS_DECONV_BWD_DATA || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || kh <= 0 || kw <= 0 ||
+        sh <= 0 || sw <= 0)
+        return cgs_set_error(CGS_EINVAL, "conv_family: bad argument");
+    const bool deconv = (op == CGS_DECONV_FWD || op == CGS_DECONV_BWD_DATA);
+    const bool dirT = (op == CGS_CONV_BWD_DATA || op == CGS_DECONV_FWD);
+    CgsLayer L;
+    L.kh = kh; L.kw = kw; L.sh = sh; L.sw = sw;
+    if (!deconv) { L.Hb = H; L.Wb = W; L.Cb = Cin; L.Hs = cgs_ceil_div(H, sh); L.Ws = cgs_ceil_div(W, sw); L.Cs = Cout; }
+    else { L.Hs = H; L.Ws = W; L.Cs = Cin; L.Hb = Ho; L.Wb = Wo; L.Cb = Cout; }
+    return choose_family(L, dirT, B, epilogue, ws_bytes > 0, ws_bytes, true, true, true);
 }
 
 static size_t conv_packed_bytes(int op, int kh, int kw, int sh, int sw, int Cin, int Cout) {

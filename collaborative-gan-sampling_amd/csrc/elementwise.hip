@@ -152,6 +152,40 @@ int cgs_bce_ones_grad_rowmean(const float* logits, float* dlogits, float* logit_
     return CGS_OK;
 }
 
+// OP 0: softplus(-l) (stable form);  1: dy * (sigmoid(l) - 1);  2: clip
+template <int OP>
+__global__ __launch_bounds__(256) void loss_unary_kernel(const float* __restrict__ p0, const float* __restrict__ p1, float lo, float hi,
+                                                         float* __restrict__ o, size_t n) {
+    GRID_STRIDE(i, n) {
+        float r;
+        if (OP == 0) { const float v = p0[i]; r = fmaxf(-v, 0.f) + log1pf(expf(-fabsf(v))); }
+        else if (OP == 1) { const float v = p1[i]; r = p0[i] * (v >= 0.f ? -expf(-v) / (1.f + expf(-v)) : -1.f / (1.f + expf(v))); }
+        else r = fminf(fmaxf(p0[i], lo), hi);
+        o[i] = r;
+    }
+}
+
+int cgs_bce_ones_fwd(const float* logits, float* loss, size_t n, void* stream) {
+    if (n == 0) return CGS_OK;
+    hipLaunchKernelGGL(loss_unary_kernel<0>, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, logits, nullptr, 0.f, 0.f, loss, n);
+    CGS_CHECK_LAUNCH("bce_ones_fwd");
+    return CGS_OK;
+}
+
+int cgs_bce_ones_bwd(const float* dloss, const float* logits, float* dlogits, size_t n, void* stream) {
+    if (n == 0) return CGS_OK;
+    hipLaunchKernelGGL(loss_unary_kernel<1>, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, dloss, logits, 0.f, 0.f, dlogits, n);
+    CGS_CHECK_LAUNCH("bce_ones_bwd");
+    return CGS_OK;
+}
+
+int cgs_clip(const float* x, float vmin, float vmax, float* y, size_t n, void* stream) {
+    if (n == 0) return CGS_OK;
+    hipLaunchKernelGGL(loss_unary_kernel<2>, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, x, nullptr, vmin, vmax, y, n);
+    CGS_CHECK_LAUNCH("clip");
+    return CGS_OK;
+}
+
 __global__ __launch_bounds__(256) void refine_update_kernel(float* __restrict__ theta, float* __restrict__ m,
                                                             const float* __restrict__ g, float rate, float alpha,
                                                             int first, int use_clip, float vmin, float vmax, size_t n) {

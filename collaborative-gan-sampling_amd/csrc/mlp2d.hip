@@ -9,7 +9,7 @@
 // Both LDS walks are stride-1 across lanes (conflict free).  All layers' weights (and transposes) live in LDS.
 #include "cgs_internal.h"
 
-#define MLP_MAX_LAYERS 8
+#define MLP_MAX_LAYERS 6      // all layers (and their transposes) LDS-resident: 6 layers = 133 KB of 160 KB
 
 struct MlpParams {
     const float* w[MLP_MAX_LAYERS];   // layer l: [din_l][dout_l] row-major (tf.layers.dense kernel)
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(1024) void refine2d_kernel(MlpParams p, const float
 }
 
 static int mlp_fill(MlpParams& p, const float* const* w, const float* const* b, int nlayers, int nh, const char* who) {
-    if (nlayers < 2 || nlayers > MLP_MAX_LAYERS || nh < 1 || nh > 64) return cgs_set_error(CGS_EINVAL, "%s: nlayers=%d nhidden=%d (need 2..8, 1..64)", who, nlayers, nh);
+    if (nlayers < 2 || nlayers > MLP_MAX_LAYERS || nh < 1 || nh > 64) return cgs_set_error(CGS_EINVAL, "%s: nlayers=%d nhidden=%d (need 2..6, 1..64)", who, nlayers, nh);
     for (int l = 0; l < nlayers; ++l) {
         if (!w[l] || !b[l]) return cgs_set_error(CGS_EINVAL, "%s: null weight", who);
         p.w[l] = w[l]; p.b[l] = b[l];

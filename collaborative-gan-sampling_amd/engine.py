@@ -398,6 +398,7 @@ class RefineEngine:
             self.images = torch.empty((B,) + tuple(A["img"]), **f32)
         self.use_graph = use_graph
         self._graphs = {}
+        self._gstream = None                 # the side stream hipGraphs are warmed up and captured on
         # sync_bn = True (default process group) or a process group: this engine's batch is one shard of a logical batch of
         # world_size * batch_size samples; D's batch statistics are all-reduced so the result equals the unsplit batch's
         # bn_groups = G: ``batch_size`` holds G logical batches of batch_size / G samples back to back.  Convolutions do not
@@ -507,22 +508,38 @@ class RefineEngine:
             else:
                 g = self._graphs.get(key)
                 if g is None:
-                    self._program(steps, rate, alpha, prob, vmin, vmax)      # warm-up: packs weights, sizes workspaces
-                    self.theta.copy_(feature0)
+                    # Warm-up and capture run on ONE explicit side stream: the packed-weight and bn workspaces are keyed by
+                    # the stream, so the warm-up packs the very buffers the capture then finds (ws_prepacked = 1 inside the
+                    # graph: no pack kernels are recorded, a replay does not re-pack ~100 MB of weights).
+                    if self._gstream is None:
+                        self._gstream = torch.cuda.Stream(self.dev)
+                    cur = torch.cuda.current_stream(self.dev)
+                    self._gstream.wait_stream(cur)
+                    with torch.cuda.stream(self._gstream):
+                        self._program(steps, rate, alpha, prob, vmin, vmax)
+                        self.theta.copy_(feature0)
                     torch.cuda.synchronize(self.dev)
                     g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g):
+                    with torch.cuda.graph(g, stream=self._gstream):
                         self._program(steps, rate, alpha, prob, vmin, vmax)
+                    cur.wait_stream(self._gstream)
                     self._graphs[key] = g
                 g.replay()
         return self.images, self.default_logit, self.best_logit, self.best_step, self.best_theta
 
     def refresh_weights(self):
         """Call after the parameter tensors were updated in place (``shaping.DShaper.step``): re-packs every layer's
-        weights into the existing workspaces (one eager forward + backward), so captured hipGraphs stay valid."""
+        weights into the existing workspaces (one eager forward + backward on the current stream and, if hipGraphs were
+        captured, one on their capture stream -- the workspaces the graphs read), so captured hipGraphs stay valid."""
         K.WS.invalidate()
         with torch.cuda.device(self.dev):
             self.compute_forward_logits_and_grad(self.theta)
+            if self._gstream is not None:        # the captured graphs read the workspaces packed on the capture stream
+                cur = torch.cuda.current_stream(self.dev)
+                self._gstream.wait_stream(cur)
+                with torch.cuda.stream(self._gstream):
+                    self.compute_forward_logits_and_grad(self.theta)
+                cur.wait_stream(self._gstream)
 
     def refine_from_z(self, z, steps, rate, **kw):
         """Propose (G head) + refine + render: one whole unit of the BASELINE metric."""

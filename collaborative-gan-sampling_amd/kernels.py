@@ -64,23 +64,44 @@ def same_out(size, stride):
 
 
 class _WsCache:
-    """Packed-weight workspaces, keyed by the weight tensor (identity + version)."""
+    """Packed-weight workspaces, keyed by the weight tensor (identity + version), the op, the call geometry, the HIP
+    stream AND the kernel family the library will run (``cgs_conv_family``): every family keeps its own packed layout,
+    and which one serves a call depends on the fused epilogue too, so the family is part of the key -- a workspace is
+    only ever reported as pre-packed to the family that packed it."""
 
     def __init__(self):
         self._d = {}
+        self._family = {}
 
-    def get(self, w, op, kh, kw, sh, sw, cin, cout, bhw=(0, 0, 0)):
-        """``bhw`` = (B, H, W) of the call: sizes the optional split-K slab area behind the packed weights."""
+    def plan(self, op, B, H, W, cin, ho, wo, cout, kh, kw, sh, sw, epilogue):
+        """(kernel family, workspace bytes) of a call; asked of the library once per distinct call signature."""
+        key = (op, B, H, W, cin, ho, wo, cout, kh, kw, sh, sw, epilogue)
+        hit = self._family.get(key)
+        if hit is None:
+            nbytes = max(L.conv_ws_bytes_for(op, B, H, W, cin, cout, kh, kw, sh, sw), 16)
+            f = int(L.load().cgs_conv_family(op, B, H, W, cin, ho, wo, cout, kh, kw, sh, sw, epilogue, nbytes))
+            if f < 0:
+                raise L.CgsError(f"cgs_conv_family failed ({f}): {L.load().cgs_last_error().decode()}")
+            hit = self._family[key] = (f, nbytes)
+        return hit
+
+    def get(self, w, op, kh, kw, sh, sw, cin, cout, bhw=(0, 0, 0), epilogue=0, out_hw=(0, 0), ptrs=()):
+        """``bhw`` = (B, H, W) of the call: sizes the optional split-K slab area behind the packed weights.
+        ``ptrs``: every device pointer of the call; if one is not 16-byte aligned the library may pick another family than
+        the planned one, so such calls get a scratch workspace and always re-pack."""
+        fam, nbytes = self.plan(op, bhw[0], bhw[1], bhw[2], cin, out_hw[0], out_hw[1], cout, kh, kw, sh, sw, epilogue)
+        aligned = not any(p is not None and (p & 15) for p in ptrs)
+        if not aligned:
+            fam = -1
         # one packed copy per HIP stream: the pack kernel is ordered only with later work of the stream that ran it
-        key = (w.data_ptr(), op, kh, kw, sh, sw, cin, cout, w.device.index, bhw, torch.cuda.current_stream(w.device).cuda_stream)
+        key = (w.data_ptr(), op, kh, kw, sh, sw, cin, cout, w.device.index, bhw, fam, torch.cuda.current_stream(w.device).cuda_stream)
         hit = self._d.get(key)
         if hit is not None and hit[0]() is w:
-            if hit[1] == w._version:
+            if hit[1] == w._version and aligned:
                 return hit[2], 1
             self._d[key] = (hit[0], w._version, hit[2])      # stale: re-pack into the SAME buffer (hipGraphs keep its address)
             return hit[2], 0
-        nbytes = L.conv_ws_bytes_for(op, bhw[0], bhw[1], bhw[2], cin, cout, kh, kw, sh, sw)
-        ws = torch.empty(max(nbytes, 16) // 4, dtype=torch.float32, device=w.device)
+        ws = torch.empty(nbytes // 4, dtype=torch.float32, device=w.device)
         if len(self._d) > 512:
             self._d.clear()
         self._d[key] = (weakref.ref(w), w._version, ws)
@@ -118,7 +139,8 @@ def conv2d_fwd(x, w, bias, sh=2, sw=2, epilogue=L.EPI_NONE, ep_a=None, ep_b=None
     if Cin2 != Cin:
         raise L.CgsError(f"conv2d: weight Cin {Cin2} != input channels {Cin}")
     y = out if out is not None else torch.empty((B, same_out(H, sh), same_out(W, sw), Cout), dtype=torch.float32, device=x.device)
-    ws, pre = WS.get(w, L.CONV_FWD, kh, kw, sh, sw, Cin, Cout, (B, H, W))
+    ws, pre = WS.get(w, L.CONV_FWD, kh, kw, sh, sw, Cin, Cout, (B, H, W), epilogue,
+                     ptrs=(_ptr(x), _ptr(bias), _ptr(y), _ptr(ep_a), _ptr(ep_b)))
     Ho, Wo = y.shape[1], y.shape[2]
     pr = _Prof(2.0 * B * Ho * Wo * Cout * kh * kw * Cin, f"conv_fwd {H}x{W} {Cin}->{Cout}") if PROFILE is not None else None
     L.call("cgs_conv2d_nhwc_fwd", _ptr(x), _ptr(w), _ptr(bias), _ptr(y), B, H, W, Cin, Cout, kh, kw, sh, sw,
@@ -136,7 +158,8 @@ def conv2d_bwd_data(dy, w, in_hw, sh=2, sw=2, out=None, epilogue=L.EPI_NONE, ep_
     B = dy.shape[0]
     H, W = in_hw
     dx = out if out is not None else torch.empty((B, H, W, Cin), dtype=torch.float32, device=dy.device)
-    ws, pre = WS.get(w, L.CONV_BWD_DATA, kh, kw, sh, sw, Cin, Cout, (B, H, W))
+    ws, pre = WS.get(w, L.CONV_BWD_DATA, kh, kw, sh, sw, Cin, Cout, (B, H, W), epilogue,
+                     ptrs=(_ptr(dy), _ptr(dx), _ptr(ep_a), _ptr(ep_aux)))
     Ho, Wo = dy.shape[1], dy.shape[2]
     pr = _Prof(2.0 * B * Ho * Wo * Cout * kh * kw * Cin, f"conv_bwd {H}x{W} {Cin}<-{Cout}") if PROFILE is not None else None
     L.call("cgs_conv2d_nhwc_bwd_data", _ptr(dy), _ptr(w), _ptr(dx), B, H, W, Cin, Cout, kh, kw, sh, sw,
@@ -155,7 +178,8 @@ def deconv2d_fwd(x, w, bias, out_hw, sh=2, sw=2, epilogue=L.EPI_NONE, ep_a=None,
         raise L.CgsError(f"deconv2d: weight Cin {Cin2} != input channels {Cin}")
     Ho, Wo = out_hw
     y = out if out is not None else torch.empty((B, Ho, Wo, Cout), dtype=torch.float32, device=x.device)
-    ws, pre = WS.get(w, L.DECONV_FWD, kh, kw, sh, sw, Cin, Cout, (B, H, W))
+    ws, pre = WS.get(w, L.DECONV_FWD, kh, kw, sh, sw, Cin, Cout, (B, H, W), epilogue, (Ho, Wo),
+                     ptrs=(_ptr(x), _ptr(bias), _ptr(y), _ptr(ep_a), _ptr(ep_b)))
     pr = _Prof(2.0 * B * H * W * Cin * kh * kw * Cout, f"deconv_fwd {H}x{W} {Cin}->{Cout}") if PROFILE is not None else None
     L.call("cgs_deconv2d_nhwc_fwd", _ptr(x), _ptr(w), _ptr(bias), _ptr(y), B, H, W, Cin, Ho, Wo, Cout, kh, kw, sh, sw,
            epilogue, _ptr(ep_a), _ptr(ep_b), _ptr(ws), ws.numel() * 4, pre, _stream())
@@ -171,7 +195,8 @@ def deconv2d_bwd_data(dy, w, in_hw, sh=2, sw=2, out=None, epilogue=L.EPI_NONE, e
     B, Ho, Wo, _ = dy.shape
     H, W = in_hw
     dx = out if out is not None else torch.empty((B, H, W, Cin), dtype=torch.float32, device=dy.device)
-    ws, pre = WS.get(w, L.DECONV_BWD_DATA, kh, kw, sh, sw, Cin, Cout, (B, H, W))
+    ws, pre = WS.get(w, L.DECONV_BWD_DATA, kh, kw, sh, sw, Cin, Cout, (B, H, W), epilogue, (Ho, Wo),
+                     ptrs=(_ptr(dy), _ptr(dx), _ptr(ep_a), _ptr(ep_aux)))
     pr = _Prof(2.0 * B * H * W * Cin * kh * kw * Cout, f"deconv_bwd {H}x{W} {Cin}<-{Cout}") if PROFILE is not None else None
     L.call("cgs_deconv2d_nhwc_bwd_data", _ptr(dy), _ptr(w), _ptr(dx), B, H, W, Cin, Ho, Wo, Cout, kh, kw, sh, sw,
            epilogue, _ptr(ep_a), _ptr(ep_aux), _ptr(ws), ws.numel() * 4, pre, _stream())
@@ -191,7 +216,7 @@ def linear_fwd(x, w, bias, epilogue=L.EPI_NONE, out=None):
     if N == 1:
         L.call("cgs_linear_fwd", _ptr(x), _ptr(w), _ptr(bias), _ptr(y), B, K, N, epilogue, None, 0, 0, _stream())
         return y
-    ws, pre = WS.get(w, L.CONV_FWD, 1, 1, 1, 1, K, N, (B, 1, 1))
+    ws, pre = WS.get(w, L.CONV_FWD, 1, 1, 1, 1, K, N, (B, 1, 1), epilogue, ptrs=(_ptr(x), _ptr(bias), _ptr(y)))
     L.call("cgs_linear_fwd", _ptr(x), _ptr(w), _ptr(bias), _ptr(y), B, K, N, epilogue, _ptr(ws), ws.numel() * 4, pre, _stream())
     return y
 
@@ -204,7 +229,7 @@ def linear_bwd_data(dy, w, out=None):
     if N == 1:
         L.call("cgs_linear_bwd_data", _ptr(dy), _ptr(w), _ptr(dx), B, K, N, None, 0, 0, _stream())
         return dx
-    ws, pre = WS.get(w, L.CONV_BWD_DATA, 1, 1, 1, 1, K, N, (B, 1, 1))
+    ws, pre = WS.get(w, L.CONV_BWD_DATA, 1, 1, 1, 1, K, N, (B, 1, 1), ptrs=(_ptr(dy), _ptr(dx)))
     L.call("cgs_linear_bwd_data", _ptr(dy), _ptr(w), _ptr(dx), B, K, N, _ptr(ws), ws.numel() * 4, pre, _stream())
     return dx
 
@@ -408,6 +433,30 @@ def bce_ones_grad_rowmean(logits, dlogits=None, logit_mean=None):
     lm = logit_mean if logit_mean is not None else torch.empty(B, dtype=torch.float32, device=logits.device)
     L.call("cgs_bce_ones_grad_rowmean", _ptr(logits), _ptr(dl), _ptr(lm), B, P, _stream())
     return dl, lm
+
+
+def bce_ones_fwd(logits, out=None):
+    """softplus(-logits): sigmoid_cross_entropy_with_logits(labels=1), unreduced (nsgan/GAN.py:176-177)."""
+    _chk(logits, "logits")
+    o = out if out is not None else torch.empty_like(logits)
+    L.call("cgs_bce_ones_fwd", _ptr(logits), _ptr(o), logits.numel(), _stream())
+    return o
+
+
+def bce_ones_bwd(dloss, logits, out=None):
+    """dloss * (sigmoid(logits) - 1)."""
+    _chk(dloss, "dloss"); _chk(logits, "logits")
+    o = out if out is not None else torch.empty_like(logits)
+    L.call("cgs_bce_ones_bwd", _ptr(dloss), _ptr(logits), _ptr(o), logits.numel(), _stream())
+    return o
+
+
+def clip(x, vmin, vmax, out=None):
+    """tf.clip_by_value (sampling/collaborator.py:69-70)."""
+    _chk(x, "x")
+    o = out if out is not None else torch.empty_like(x)
+    L.call("cgs_clip", _ptr(x), float(vmin), float(vmax), _ptr(o), x.numel(), _stream())
+    return o
 
 
 def refine_update(theta, m, g, rate, alpha, first, vmin=None, vmax=None):

@@ -13,6 +13,7 @@ OK, EINVAL, EWORKSPACE, ELAUNCH = 0, -1, -2, -3
 EPI_NONE, EPI_LRELU, EPI_AFFINE_RELU, EPI_TANH = 0, 1, 2, 3
 EPI_RELU_BWD_AFFINE, EPI_LRELU_BWD, EPI_TANH_BWD = 4, 5, 6
 CONV_FWD, CONV_BWD_DATA, DECONV_FWD, DECONV_BWD_DATA = 0, 1, 2, 3
+FAMILY_IGEMM, FAMILY_QUAD, FAMILY_SMALLN_T, FAMILY_SMALLN_F, FAMILY_PATCH = 0, 1, 2, 3, 4
 
 _p, _i, _f, _z = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 _ll = C.c_longlong
@@ -24,6 +25,7 @@ SIGNATURES = {
     "cgs_last_kernel": (C.c_char_p, []),
     "cgs_conv_ws_bytes": (_z, [_i] * 7),
     "cgs_conv_ws_bytes_for": (_z, [_i] * 10),
+    "cgs_conv_family": (_i, [_i] * 13 + [_z]),
     "cgs_conv2d_nhwc_fwd": (_i, [_p] * 4 + [_i] * 9 + [_i, _p, _p, _p, _z, _i, _p]),
     "cgs_conv2d_nhwc_bwd_data": (_i, [_p] * 3 + [_i] * 9 + [_i, _p, _p, _p, _z, _i, _p]),
     "cgs_deconv2d_nhwc_fwd": (_i, [_p] * 4 + [_i] * 11 + [_i, _p, _p, _p, _z, _i, _p]),
@@ -51,6 +53,9 @@ SIGNATURES = {
     "cgs_tanh_fwd": (_i, [_p, _p, _z, _p]),
     "cgs_tanh_bwd": (_i, [_p, _p, _p, _z, _p]),
     "cgs_bce_ones_grad_rowmean": (_i, [_p, _p, _p, _i, _i, _p]),
+    "cgs_bce_ones_fwd": (_i, [_p, _p, _z, _p]),
+    "cgs_bce_ones_bwd": (_i, [_p, _p, _p, _z, _p]),
+    "cgs_clip": (_i, [_p, _f, _f, _p, _z, _p]),
     "cgs_refine_update": (_i, [_p, _p, _p, _f, _f, _i, _i, _f, _f, _z, _p]),
     "cgs_refine_select": (_i, [_p, _p, _p, _i, _p, _p, _p, _i, _i, _p]),
     "cgs_refine_select_rows": (_i, [_p, _p, _p, _i, _p, _p, _i, _i, _p]),

@@ -16,7 +16,7 @@ import numpy as np
 import torch
 
 from . import ops
-from .nets import ARCHS
+from .nets import ARCHS, g_input_shape, layer_ks
 
 
 class GAN(object):
@@ -36,9 +36,10 @@ class GAN(object):
 
     # -- layer-list interpreter over the operator API ------------------------------------------
     def _run(self, layers, net, is_training):
-        k, s = self.A["k"], self.A["stride"]
+        k0, s0 = self.A["k"], self.A["stride"]
         for L in layers:
             kind = L[0]
+            k, s = layer_ks(L, k0, s0) if kind in ("conv", "deconv") else (k0, s0)      # per-layer kernel size / stride
             if kind == "linear":
                 net = ops.linear(net, L[2], scope=L[1])
             elif kind == "reshape":
@@ -57,6 +58,10 @@ class GAN(object):
                 net = ops.lrelu(net)
             elif kind == "tanh":
                 net = ops.tanh(net)
+            elif kind == "instnorm":
+                net = ops.instance_norm(net, scope=L[1])
+            elif kind == "res":
+                net = ops.add(net, self._run(L[1], net, is_training))
             else:
                 raise KeyError(kind)
         return net
@@ -94,7 +99,7 @@ class GAN(object):
     def build_variables(self):
         """Create every variable (the reference does this by building the training graph, :117-121)."""
         with torch.no_grad():
-            z = torch.zeros([2, self.z_dim], device=self.device)
+            z = torch.zeros((2,) + g_input_shape(self.A), device=self.device)      # a z vector, or a source image (image-to-image nets)
             self.discriminator(self.generator(z, is_training=False, reuse=False), is_training=False, reuse=False)
         return ops.variables()
 
@@ -103,9 +108,11 @@ class GAN(object):
         from .engine import RefineEngine
         B = int(batch_size or self.batch_size)
         key = (B, use_graph)
-        if key not in self._engines:
-            self._engines[key] = RefineEngine(self.A, self.build_variables(), B, self.device, use_graph=use_graph)
-        return self._engines[key]
+        hit = self._engines.get(key)
+        if hit is None or hit[1] != ops.generation():       # a checkpoint was loaded since: re-fold the G bn affines, re-pack
+            hit = self._engines[key] = (RefineEngine(self.A, self.build_variables(), B, self.device, use_graph=use_graph),
+                                        ops.generation())
+        return hit[0]
 
     def build_refiner(self, rollout_steps, rollout_rate, rollout_method="momentum"):
         """nsgan/GAN.py:179-181."""

@@ -24,6 +24,7 @@ _VARS = {}
 _SCOPE = []
 _REUSE = [False]
 _DEVICE = [None]
+_GENERATION = 0
 
 
 def set_device(device):
@@ -69,7 +70,24 @@ def set_variables(params, device=None):
     """Load a name -> array checkpoint (TF variable names) into the store."""
     dev = torch.device(device) if device is not None else _device()
     for k, v in params.items():
-        _VARS[k] = torch.as_tensor(v).float().contiguous().to(dev)
+        new = torch.as_tensor(v).float().contiguous()
+        old = _VARS.get(k)
+        if old is not None and old.device == dev and tuple(old.shape) == tuple(new.shape):
+            # restore INTO the existing tensor (tf.train.Saver.restore assigns to the variables, nsgan/GAN.py:473-491):
+            # engines and refiners built before the load keep pointing at live storage
+            with torch.no_grad():
+                old.copy_(new)
+        else:
+            _VARS[k] = new.to(dev)
+    K.WS.invalidate()                     # packed copies of the old values are stale
+    global _GENERATION
+    _GENERATION += 1
+
+
+def generation():
+    """Bumped by every set_variables(): consumers that derived state from the values (folded inference-bn affines in a
+    compiled engine) rebuild when it moves."""
+    return _GENERATION
 
 
 def reset_variables():
@@ -219,6 +237,44 @@ class _Tanh(torch.autograd.Function):
         return K.tanh_bwd(dy.contiguous(), y)
 
 
+class _InstNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, scale, offset, leak):
+        x = x.contiguous()
+        y, mean, invstd = K.instnorm_lrelu_fwd(x, scale, offset, leak)
+        ctx.save_for_backward(x, scale, offset, mean, invstd)
+        ctx.leak = leak
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, scale, offset, mean, invstd = ctx.saved_tensors
+        return K.instnorm_lrelu_bwd_data(dy.contiguous(), x, scale, offset, mean, invstd, ctx.leak), None, None, None
+
+
+class _Add(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        return K.add(a.contiguous(), b.contiguous())
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, dy
+
+
+class _BceOnes(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits):
+        logits = logits.contiguous()
+        ctx.save_for_backward(logits)
+        return K.bce_ones_fwd(logits)
+
+    @staticmethod
+    def backward(ctx, dloss):
+        (logits,) = ctx.saved_tensors
+        return K.bce_ones_bwd(dloss.contiguous(), logits)
+
+
 # ----------------------------------------------------------------------------- the operator API
 def concat(tensors, axis, *args, **kwargs):
     """nsgan/ops.py:12-17."""
@@ -244,6 +300,21 @@ def bn(x, is_training, scope, leak=1.0):
     a, b = K.bn_fold(gamma, beta, mm, mv)
     y = _Affine.apply(x, a, b)
     return y if leak == 1.0 else _Lrelu.apply(y, float(leak))
+
+
+def instance_norm(x, scope, leak=1.0):
+    """Instance norm over the pixels of every (sample, channel), variables ``scale`` / ``offset`` (extension: the CycleGAN /
+    PatchGAN nets of BASELINE config 5; the reference has no such op).  Frozen parameters: input gradient only."""
+    C = x.shape[-1]
+    with variable_scope(scope):
+        scale = get_variable("scale", [C], constant_initializer(1.0))
+        offset = get_variable("offset", [C], constant_initializer(0.0))
+    return _InstNorm.apply(x, scale, offset, float(leak))
+
+
+def add(a, b):
+    """a + b (residual connections) on the HIP path."""
+    return _Add.apply(a, b)
 
 
 def conv_out_size_same(size, stride):
@@ -305,4 +376,4 @@ def linear(input_, output_size, scope=None, stddev=0.02, bias_start=0.0, with_w=
 
 def sigmoid_cross_entropy_with_logits_ones(logits):
     """tf.nn.sigmoid_cross_entropy_with_logits(logits, labels=ones), unreduced (nsgan/GAN.py:176-177)."""
-    return torch.nn.functional.softplus(-logits)
+    return _BceOnes.apply(logits)

@@ -49,8 +49,8 @@ class Refiner():
             if need_grad:
                 forward_loss = self.func_loss(forward_logits)
                 forward_grad = torch.autograd.grad(forward_loss.sum(), feature)[0]   # tf.gradients sums ys
-        flat = forward_logits.detach().reshape(forward_logits.shape[0], -1)
-        return flat.mean(dim=1), forward_grad                                        # per-sample mean logit
+        flat = forward_logits.detach().reshape(forward_logits.shape[0], -1).contiguous()
+        return K.bce_ones_grad_rowmean(flat)[1], forward_grad                        # per-sample mean logit (:34-37)
 
     # -- engine detection ------------------------------------------------------------------------
     def _engine_for(self, batch):
@@ -82,9 +82,13 @@ class Refiner():
             img, d_l, o_l, o_s, o_f = eng.refine(fake_feature, K_steps, self.optimizer.lambda_, self.optimizer.method,
                                                  mode, self.indices_batch if mode == 'probabilistic' else None,
                                                  self.vmin, self.vmax)
-            self.default_logit, self.optimal_logit, self.optimal_step, self.optimal_feature = d_l, o_l, o_s, o_f
+            # the engine returns its own (cached, reused) buffers: hand out copies, so that a second build_refiner -- the
+            # reference builds a deterministic and a probabilistic refiner side by side, nsgan/GAN.py:182-183 -- does not
+            # overwrite the first one's results in place
+            self.default_logit, self.optimal_logit = d_l.clone(), o_l.clone()
+            self.optimal_step, self.optimal_feature = o_s.clone(), o_f.clone()
             self.optimizer.reset_moving_average()
-            return img
+            return img.clone()
 
         # ---- generic path -----------------------------------------------------------------------
         self.current_feature = fake_feature.detach().clone().contiguous()
@@ -100,7 +104,7 @@ class Refiner():
         for i in range(K_steps):
             self.current_feature = self.optimizer.apply_gradient(self.current_feature, self.forward_grad)
             if self.vmin and self.vmax:                       # the reference's truthiness test (:69)
-                self.current_feature = torch.clamp(self.current_feature, self.vmin, self.vmax)
+                self.current_feature = K.clip(self.current_feature, self.vmin, self.vmax)
             self.current_logit, self.forward_grad = self.compute_forward_logits_and_grad(
                 self.current_feature, need_grad=(i + 1 < K_steps))     # the K-th gradient is dead code in the reference graph
             K.refine_select(self.current_feature, self.current_logit.contiguous(), forced, i,

@@ -34,8 +34,9 @@ class MLPDiscriminator:
         self.w = [torch.as_tensor(np.asarray(params[f"discriminator/d_fc{i + 1}/kernel"]), dtype=torch.float32).contiguous().to(self.dev) for i in range(n)]
         self.b = [torch.as_tensor(np.asarray(params[f"discriminator/d_fc{i + 1}/bias"]), dtype=torch.float32).contiguous().to(self.dev) for i in range(n)]
         self.nhidden = int(self.w[0].shape[1])
-        if self.w[0].shape[0] != 2 or self.w[-1].shape[1] != 1 or self.nhidden > 64 or not 2 <= n <= 8:
-            raise L.CgsError(f"MLPDiscriminator: unsupported shape (2 -> {self.nhidden} x {n - 1} -> 1; need nhidden <= 64, 2..8 layers)")
+        if self.w[0].shape[0] != 2 or self.w[-1].shape[1] != 1 or self.nhidden > 64 or not 2 <= n <= 6:
+            # every layer's weights (and their transposes) are LDS-resident: 6 layers = 133 KB of the CU's 160 KB
+            raise L.CgsError(f"MLPDiscriminator: unsupported shape (2 -> {self.nhidden} x {n - 1} -> 1; need nhidden <= 64, 2..6 layers)")
         self._wp = (C.c_void_p * n)(*[t.data_ptr() for t in self.w])
         self._bp = (C.c_void_p * n)(*[t.data_ptr() for t in self.b])
 

@@ -69,6 +69,19 @@ size_t cgs_conv_ws_bytes(int op, int kh, int kw, int sh, int sw, int Cin, int Co
  * Layout: [packed weights | slabs]; ws_prepacked refers to the first part only. */
 size_t cgs_conv_ws_bytes_for(int op, int B, int H, int W, int Cin, int Cout, int kh, int kw, int sh, int sw);
 
+/* Kernel family a conv-family call with these arguments will run, given 16-byte aligned pointers and a workspace of
+ * ws_bytes (B, H, W, Cin, Cout as passed to the entry point; Ho, Wo = the deconv ops' output size, ignored for the conv
+ * ops).  Each family keeps its OWN packed-weight layout in the workspace, so a caller
+ * that sets ws_prepacked must key its cached workspaces by (weights, op, geometry, family): the epilogue takes part in
+ * the choice.  CGS_FAMILY_SMALLN_T packs nothing.  Negative = error. */
+#define CGS_FAMILY_IGEMM 0      /* implicit GEMM on the fp32 matrix cores (igemm.hip)                     */
+#define CGS_FAMILY_QUAD 1       /* <= 4 output channels, transposed stride 2 (convt_quad.hip)             */
+#define CGS_FAMILY_SMALLN_T 2   /* same, VALU form (convt_smalln.hip)                                     */
+#define CGS_FAMILY_SMALLN_F 3   /* stride-1 forward conv with <= 4 output channels (conv_smalln_f.hip)    */
+#define CGS_FAMILY_PATCH 4      /* 3-channel strided / stem convs from an LDS patch (conv_patch.hip)      */
+int cgs_conv_family(int op, int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int sh, int sw,
+                    int epilogue, size_t ws_bytes);
+
 /* conv2d: y[B,Ho,Wo,Cout] = conv(x[B,H,W,Cin], w[kh,kw,Cin,Cout], stride, 'SAME') + bias, then epilogue.
  * Replaces tf.nn.conv2d + tf.nn.bias_add at nsgan/ops.py:41-44 (Ho = ceil(H/sh)).
  * ws/ws_bytes: see cgs_conv_ws_bytes; ws_prepacked != 0 means ws already holds the packed
@@ -175,6 +188,13 @@ int cgs_tanh_bwd(const float* dy, const float* y, float* dx, size_t n, void* str
  * sampling/collaborator.py:31), and the per-sample mean logit over P patch entries
  * (sampling/collaborator.py:34-37).  logits is [B,P]. */
 int cgs_bce_ones_grad_rowmean(const float* logits, float* dlogits, float* logit_mean, int B, int P, void* stream);
+
+/* loss[i] = softplus(-logits[i]) = tf.nn.sigmoid_cross_entropy_with_logits(labels=1), unreduced (nsgan/GAN.py:176-177),
+ * and its input gradient dlogits[i] = dloss[i] * (sigmoid(logits[i]) - 1)  (what tf.gradients emits, collaborator.py:31). */
+int cgs_bce_ones_fwd(const float* logits, float* loss, size_t n, void* stream);
+int cgs_bce_ones_bwd(const float* dloss, const float* logits, float* dlogits, size_t n, void* stream);
+/* y = min(max(x, vmin), vmax): tf.clip_by_value on the refined map (sampling/collaborator.py:69-70). */
+int cgs_clip(const float* x, float vmin, float vmax, float* y, size_t n, void* stream);
 
 /* One refinement step's state update, fused (sampling/policy.py:31-37 momentum / :27-29 sgd,
  * sampling/collaborator.py:66-70 clip):

@@ -187,7 +187,7 @@ def g2_policy():
 
 
 # --------------------------------------------------------------------------- G3/G4
-def collab_case(arch, B, K, mode, rate, seed, constraints=None):
+def collab_case(arch, B, K, mode, rate, seed, constraints=None, compact=False):
     torch.manual_seed(0)
     P = N.init_params(arch, seed=2019, perturb=True)
     A = N.ARCHS[arch]
@@ -212,6 +212,9 @@ def collab_case(arch, B, K, mode, rate, seed, constraints=None):
     idx = np.random.randint(K + 1, size=B) if mode == "probabilistic" else np.zeros(0, dtype=np.int64)
     assert ref.optimizer.momentum is None
     tag = f"g3_collab_{arch}_K{K}_{mode}" + ("_clip" if constraints else "")
+    if compact:      # the large-batch cases: `real` only feeds the reference's dead real_logits (collaborator.py:44-45)
+        tag = f"g3_collab_{arch}_B{B}_K{K}_{mode}"
+        real = np.zeros(0, dtype=np.float32)
     save(tag + ".npz", arch=np.array([arch]), z=z, real=real, feature0=feat0.numpy(), K=np.array([K]),
          rate=np.array([rate]), mode=np.array([mode]), indices=idx, np_seed=np.array([seed]),
          constraints=np.array(constraints if constraints else [np.nan, np.nan]),
@@ -300,3 +303,7 @@ if __name__ == "__main__":
     collab_case("dcgan32", 4, 5, "probabilistic", 0.1, seed=22)
     collab_case("dcgan64", 2, 2, "deterministic", 0.1, seed=31)     # the headline architecture (BASELINE configs 3/4)
     collab_case("cyclegan_tiny", 3, 3, "deterministic", 0.1, seed=41)   # PatchGAN logit map: collaborator.py:34-37
+    # batch 64 at the reference's own rollout lengths (nsgan/main.py:32,47: B=64, K=50; BASELINE configs[1]: K=20): enough
+    # samples for the "optimal_step agrees on >= 99 %" statistic of SURVEY.md section 7 to be expressible
+    collab_case("mnist", 64, 50, "deterministic", 0.1, seed=51, compact=True)
+    collab_case("dcgan32", 64, 20, "deterministic", 0.1, seed=52, compact=True)

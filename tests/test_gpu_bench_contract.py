@@ -47,3 +47,37 @@ def test_smoke_entry():
     sys.path.insert(0, ROOT)
     import __graft_entry__ as g
     g.smoke()
+
+
+def test_bench_under_torchrun_runs_the_rccl_gather():
+    """`python -m torch.distributed.run --nproc-per-node 1 bench.py --gpus 1`: the launch form the driver uses for N > 1,
+    at the one world size a 1-GPU box can hold -- init_process_group("nccl") (= RCCL), all_gather_into_tensor of the refined
+    pool inside the timed region, barrier, MAX all-reduce of the time."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+                          "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--arch", "mnist", "--steps", "2",
+                          "--warmup", "1", "--refine-steps", "3", "--no-cpu-baseline"], cwd=ROOT, capture_output=True, text=True,
+                         timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and "RCCL" not in d["config"]["parallelism"]
+
+
+def test_gather_pool_on_rccl_world1_is_identity_through_the_collective():
+    """dist.gather_pool's all_gather_into_tensor on the nccl (RCCL) backend, in-process at world size 1."""
+    code = (
+        "import os, sys, torch, torch.distributed as dist\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29534', RANK='0', WORLD_SIZE='1')\n"
+        "dev = torch.device('cuda:0'); torch.cuda.set_device(dev)\n"
+        "dist.init_process_group('nccl', device_id=dev)\n"
+        "x = torch.arange(24, dtype=torch.float32, device=dev).view(4, 6)\n"
+        "pool = torch.empty_like(x); dist.all_gather_into_tensor(pool, x)\n"
+        "assert torch.equal(pool, x)\n"
+        "t = torch.tensor([3.5], dtype=torch.float64, device=dev); dist.all_reduce(t, op=dist.ReduceOp.MAX); assert t.item() == 3.5\n"
+        "dist.destroy_process_group(); print('RCCL_OK')\n")
+    out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert out.returncode == 0 and "RCCL_OK" in out.stdout, out.stderr[-3000:]

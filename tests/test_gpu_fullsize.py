@@ -1,0 +1,79 @@
+"""Oracle parity at BASELINE's FULL sizes: every single-GPU configuration of BASELINE.json, at its
+own batch and rollout length, against ``oracle.collaborative_refine`` (torch-CPU fp32 restatement of
+sampling/collaborator.py:41-88) on the same seeded z.  D's batch-norm couples all samples of a batch
+(nsgan/GAN.py:175), so the batch size is part of the result -- the small goldens do not cover it.
+
+Tolerances (SURVEY.md section 7 "hard parts" (c)): the first forward pass (default_logit) 1e-4; the K-step
+trajectory's optimal_logit 2e-3; optimal_step equal on >= 99 % of the samples and, on the rest, only where the
+two candidate steps' logits tie within the trajectory tolerance; the render of the oracle's optimal_feature 1e-4.
+Host cost on the GPU box: about 60 s for dcgan64 (23 TFLOP of CPU convolutions), seconds for the others."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import nets_ref as N
+from oracle import sampling_ref as S
+
+
+def relerr(got, want):
+    got, want = np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64)
+    return np.abs(got - want).max() / (np.abs(want).max() + 1e-30)
+
+
+def oracle_refine(arch, P, f0, K, rate):
+    n = torch.get_num_threads()
+    torch.set_num_threads(min(32, os.cpu_count() or 1))        # oneDNN on 256 threads is slower than on 32 at these sizes
+    try:
+        return S.collaborative_refine(f0, lambda f: N.feature_to_data(arch, P, f), lambda x: N.discriminator(arch, P, x), K, rate)
+    finally:
+        torch.set_num_threads(n)
+
+
+def check_group(tag, got, want, K, traj_tol=2e-3, min_agree=0.99):
+    img, dl, ol, st, of = [t.cpu().numpy() for t in got]
+    wimg, wdl, wol, wst, wof = [t.numpy() for t in want]
+    assert relerr(dl, wdl) < 1e-4, (tag, "default_logit", relerr(dl, wdl))
+    same = st == wst
+    scale = np.abs(wol).max()
+    # a flipped select is tolerable only on a numerical tie: both arithmetics saw (almost) the same best logit
+    assert np.all(np.abs(ol[~same] - wol[~same]) < traj_tol * scale), (tag, "non-tie step flips", np.abs(ol[~same] - wol[~same]).max() / scale)
+    assert same.mean() >= min_agree, (tag, "optimal_step agreement", same.mean())
+    assert relerr(ol, wol) < traj_tol, (tag, "optimal_logit", relerr(ol, wol))
+    assert ((st >= 1) & (st <= max(K, 1))).all()
+    assert relerr(of[same], wof[same]) < traj_tol, (tag, "optimal_feature", relerr(of[same], wof[same]))
+    return same.mean(), relerr(ol, wol)
+
+
+# (arch, logical batch, K, logical batches fused per launch) -- BASELINE configs[1], [2], the reference's in-tree net at
+# its own defaults (nsgan/main.py:32,47), config 5's per-GPU share, and bench.py's fused default for the small nets
+CASES = [("dcgan64", 1024, 20, 1), ("dcgan32", 256, 20, 1), ("mnist", 64, 50, 1), ("cyclegan256", 8, 2, 1),
+         ("dcgan32", 256, 20, 4), ("mnist", 64, 50, 16)]
+
+
+@pytest.mark.parametrize("arch,B,K,G", CASES, ids=[f"{a}-B{b}-K{k}" + (f"-fused{g}" if g > 1 else "") for a, b, k, g in CASES])
+def test_full_size_refinement_matches_the_oracle(arch, B, K, G):
+    from cgs_amd.engine import RefineEngine
+    from cgs_amd.nets import ARCHS, g_input_shape, to_device
+    d = torch.device("cuda:0")
+    P = N.init_params(arch, 2019, True)
+    A = ARCHS[arch]
+    z = torch.from_numpy(np.random.RandomState(2019).uniform(-1, 1, (G * B,) + g_input_shape(A)).astype(np.float32))
+    eng = RefineEngine(arch, to_device(P, d), G * B, d, bn_groups=G)
+    f0_dev = eng.input_to_feature(z.to(d)).clone()
+    with torch.no_grad():
+        f0 = N.input_to_feature(arch, P, z)
+    assert relerr(f0_dev.cpu().numpy(), f0.numpy()) < 1e-4                         # propose (G head) at full batch
+    got = [t.clone() for t in eng.refine(f0.to(d), K, 0.1)]                        # same theta0 for both arithmetics
+    for gi in range(G):
+        sl = slice(gi * B, (gi + 1) * B)
+        want = oracle_refine(arch, P, f0[sl], K, 0.1)
+        agree, lerr = check_group(f"{arch} group {gi}", [t[sl] for t in got], want, K)
+        print(f"{arch} B={B} K={K} group {gi}/{G}: optimal_step agreement {agree:.4f}, optimal_logit relerr {lerr:.2e}")
+        if G == 1:     # the render itself, tightly, on the ORACLE's selected feature (trajectory drift excluded)
+            again = eng.feature_to_data(want[4].to(d))
+            assert relerr(again.cpu().numpy(), want[0].numpy()) < 1e-4
+            assert torch.equal(eng.feature_to_data(got[4]), got[0])               # returned images ARE G_tail(optimal_feature)

@@ -338,7 +338,8 @@ def test_edge_shapes_and_argument_errors():
     assert rc == lib.EINVAL
 
 
-@pytest.mark.parametrize("case", ["conv_pixmajor", "conv_parity", "conv_bwd_T", "deconv_fwd_T_tanh", "deconv_bwd_F"])
+@pytest.mark.parametrize("case", ["conv_pixmajor", "conv_parity", "conv_bwd_T", "deconv_fwd_T_tanh", "deconv_bwd_F",
+                                  "dominant_F", "dominant_T", "dominant_T_bwd"])
 def test_many_block_grids_use_the_16_deep_variant(case):
     """Grids with >= 512 blocks per parity class run the 16-deep K-tile instantiation (four blocks per CU, half-staged
     epilogue); every direction / tap order of it against the oracle, and that it really is the kernel that ran."""
@@ -351,6 +352,36 @@ def test_many_block_grids_use_the_16_deep_variant(case):
         name = lib.last_kernel()
         close(got, R.lrelu(R.conv2d(x, w, b, 2, 2)), 2e-5)
         assert name == f"igemm_kernel<128, 64, 4, true, 16, {'true' if case == 'conv_parity' else 'false'}>", name
+    elif case == "dominant_F":
+        # the headline's dominant instantiation (33 % of the dcgan64 step: d_h2 fwd, g_h2 bwd), forward direction:
+        # 16x16 -> 8x8 pixel-major grid, N = 256 (two 128-wide n-tiles), 1024 blocks
+        B, H, Cin, Cout = 1024, 16, 32, 256
+        x, w, b = rnd((B, H, H, Cin), 1), rnd((5, 5, Cin, Cout), 2, 0.05), rnd((Cout,), 3, 0.1)
+        got = K.conv2d_fwd(x.to(d), w.to(d), b.to(d), 2, 2, lib.EPI_LRELU)
+        name = lib.last_kernel()
+        close(got, R.lrelu(R.conv2d(x, w, b, 2, 2)), 2e-5)
+        assert name == "igemm_kernel<128, 128, 4, true, 16, false>", name
+    elif case == "dominant_T":
+        # ... and transposed direction (g_h2 fwd): 8x8 -> 16x16, four parity classes of 512 blocks each, N = 128
+        B, H, Cin, Cout = 1024, 8, 32, 128
+        x, w, b = rnd((B, H, H, Cin), 1), rnd((5, 5, Cout, Cin), 2, 0.05), rnd((Cout,), 3, 0.1)
+        got = K.deconv2d_fwd(x.to(d), w.to(d), b.to(d), (2 * H, 2 * H), 2, 2, lib.EPI_NONE)
+        name = lib.last_kernel()
+        close(got, R.deconv2d(x, w, b, (B, 2 * H, 2 * H, Cout), 2, 2), 2e-5)
+        assert name == "igemm_kernel<128, 128, 4, true, 16, false>", name
+    elif case == "dominant_T_bwd":
+        # ... and as a conv's backward-data with the lrelu gradient of the layer below folded in (d_h2 bwd)
+        B, H, Cin, Cout = 1024, 16, 128, 32
+        w = rnd((5, 5, Cin, Cout), 2, 0.05)
+        x = rnd((B, H, H, Cin), 1).requires_grad_(True)
+        y = R.conv2d(x, w, torch.zeros(Cout), 2, 2)
+        dy = rnd(tuple(y.shape), 4)
+        (y * dy).sum().backward()
+        below = rnd((B, H, H, Cin), 6)                       # saved lrelu output of the layer below
+        got = K.conv2d_bwd_data(dy.to(d), w.to(d), (H, H), 2, 2, epilogue=lib.EPI_LRELU_BWD, ep_aux=below.to(d))
+        name = lib.last_kernel()
+        close(got, x.grad * torch.where(below > 0, 1.0, 0.2), 2e-5)
+        assert name == "igemm_kernel<128, 128, 4, true, 16, false>", name
     elif case == "conv_bwd_T":
         B, H, Cin, Cout = 1024, 32, 32, 64
         w = rnd((5, 5, Cin, Cout), 2, 0.05)

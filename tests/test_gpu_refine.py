@@ -50,7 +50,7 @@ def check_against_golden(g, img, dl, ol, os_, of, traj_tol=2e-3, render=None):
         bad = ~steps_ok
         assert np.all(np.abs(ol.cpu().numpy()[bad] - g["optimal_logit"][bad]) < traj_tol * np.abs(g["optimal_logit"]).max())
     ok = steps_ok
-    assert ok.mean() >= 0.75
+    assert ok.mean() >= (0.99 if len(ok) >= 64 else 0.75)      # >= 99 % (expressible from batch 64 up)
     assert relerr(of.cpu().numpy()[ok], g["optimal_feature"][ok]) < traj_tol
     # images: the G tail amplifies feature drift (inference bn divides by sqrt(moving_var ~ 0.02) three times),
     # so the trajectory comparison is loose and the RENDER itself is checked tightly on the golden feature.

@@ -1,0 +1,178 @@
+"""Regression tests for the round-1 review findings (ADVICE.md / VERDICT.md): result aliasing of the cached engine,
+packed-weight workspaces across kernel families, checkpoint load after the engine was built, the generic (ops + autograd)
+path on per-layer kernel sizes / instance norm / residual blocks, and the checkpoint-file -> refinement round trip."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import nets_ref as N
+from oracle import ops_ref as R
+
+
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def rnd(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).float()
+
+
+def close(got, want, tol):
+    got, want = got.detach().cpu().double(), want.detach().cpu().double()
+    err = (got - want).abs().max().item()
+    ref = want.abs().max().item() + 1e-30
+    assert err <= tol * ref, f"max|delta|={err:.3e} vs max|ref|={ref:.3e} (tol {tol})"
+
+
+def test_two_build_refiner_results_are_independent():
+    """nsgan/GAN.py:182-183 builds a deterministic and a probabilistic refiner on the same batch, back to back: the second
+    call must not overwrite what the first returned (the engine is cached per batch size and reuses its buffers)."""
+    from cgs_amd import ops
+    from cgs_amd.model import GAN
+    d = dev()
+    ops.reset_variables()
+    B, K = 8, 4
+    gan = GAN("mnist", batch_size=B, device=d, params=N.init_params("mnist", 2019, True))
+    z = torch.from_numpy(np.random.RandomState(0).uniform(-1, 1, (B, 62)).astype(np.float32)).to(d)
+    f0 = gan.input_to_feature(z)
+    ref = gan.build_refiner(K, 0.1)
+    g_refine_detem = ref.build_refiner(f0, None, "deterministic")
+    keep = [t.clone() for t in (g_refine_detem, ref.default_logit, ref.optimal_logit, ref.optimal_step, ref.optimal_feature)]
+    held = (g_refine_detem, ref.default_logit, ref.optimal_logit, ref.optimal_step, ref.optimal_feature)
+    g_refine_proba = ref.build_refiner(f0 * 0.5, None, "probabilistic", indices=np.zeros(B, dtype=np.int64))
+    assert not torch.equal(g_refine_proba, g_refine_detem)
+    for a, b in zip(held, keep):
+        assert torch.equal(a, b)                    # the first call's tensors still hold the first call's values
+    ops.reset_variables()
+
+
+def test_one_weight_through_two_kernel_families():
+    """The fused epilogue takes part in the kernel-family choice (a 3-channel transposed layer runs the quad MFMA kernel,
+    but with the folded-bn+relu epilogue the implicit GEMM): the packed-weight cache must keep one image per family, in
+    either call order, instead of handing one family's packed workspace to the other."""
+    from cgs_amd import kernels as K, lib
+    d = dev()
+    B, H, Cin, Cout = 4, 8, 32, 3
+    x, w, b = rnd((B, H, H, Cin), 1), rnd((5, 5, Cout, Cin), 2, 0.05), rnd((Cout,), 3, 0.1)
+    a, c = rnd((Cout,), 4).abs() + 0.5, rnd((Cout,), 5, 0.1)
+    y_lin = R.deconv2d(x, w, b, (B, 2 * H, 2 * H, Cout), 2, 2)
+    want = {lib.EPI_TANH: torch.tanh(y_lin), lib.EPI_AFFINE_RELU: torch.relu(a * y_lin + c), lib.EPI_NONE: y_lin}
+    for order in ([lib.EPI_TANH, lib.EPI_AFFINE_RELU, lib.EPI_NONE], [lib.EPI_AFFINE_RELU, lib.EPI_TANH, lib.EPI_TANH, lib.EPI_AFFINE_RELU]):
+        K.WS.clear()
+        wd = w.to(d)                                 # ONE weight tensor: same cache identity for every call below
+        seen = set()
+        for epi in order:
+            got = K.deconv2d_fwd(x.to(d), wd, b.to(d), (2 * H, 2 * H), 2, 2, epi, a.to(d) if epi == lib.EPI_AFFINE_RELU else None,
+                                 c.to(d) if epi == lib.EPI_AFFINE_RELU else None)
+            seen.add(lib.last_kernel().split("<")[0])
+            close(got, want[epi], 2e-5)
+        assert len(seen) == 2, seen                  # both families really ran
+    fam = lambda epi: lib.load().cgs_conv_family(lib.DECONV_FWD, B, H, H, Cin, 2 * H, 2 * H, Cout, 5, 5, 2, 2, epi, 1 << 20)
+    assert fam(lib.EPI_TANH) == lib.FAMILY_QUAD and fam(lib.EPI_AFFINE_RELU) == lib.FAMILY_IGEMM
+
+
+def test_checkpoint_loaded_after_the_engine_was_built_is_used():
+    """The reference's order is build model / refiner, THEN saver.restore (nsgan/GAN.py:103-183 then :473-491).
+    ops.set_variables must reach the already-compiled engine: weights, re-folded G bn affines, re-packed workspaces."""
+    from cgs_amd import ops
+    from cgs_amd.model import GAN
+    d = dev()
+    ops.reset_variables()
+    B, K = 8, 3
+    P0, P1 = N.init_params("mnist", 2019, True), N.init_params("mnist", 7, True)
+    gan = GAN("mnist", batch_size=B, device=d, params=P0)
+    z = torch.from_numpy(np.random.RandomState(1).uniform(-1, 1, (B, 62)).astype(np.float32)).to(d)
+    ref = gan.build_refiner(K, 0.1)
+    img0 = ref.build_refiner(gan.input_to_feature(z), None)             # engine compiled on P0
+    ops.set_variables(P1, d)                                            # "restore" over live variables
+    f1 = gan.input_to_feature(z)
+    img1 = ref.build_refiner(f1, None)
+    ops.reset_variables()
+    gan2 = GAN("mnist", batch_size=B, device=d, params=P1)              # a model that only ever saw P1
+    ref2 = gan2.build_refiner(K, 0.1)
+    want = ref2.build_refiner(gan2.input_to_feature(z), None)
+    assert torch.equal(img1, want) and not torch.equal(img1, img0)
+    assert torch.equal(ref.optimal_logit, ref2.optimal_logit)
+    ops.reset_variables()
+
+
+def test_checkpoint_file_to_refinement_round_trip(tmp_path):
+    """checkpoint file (TF variable names) -> check_against_arch -> GAN(params=load(path)) -> the refinement is
+    bit-equal to the one on the in-memory parameters; both the .safetensors and the .npz container."""
+    from cgs_amd import checkpoint, ops
+    from cgs_amd.model import GAN
+    d = dev()
+    B, K = 8, 3
+    P = N.init_params("dcgan32", 2019, True)
+    z = torch.from_numpy(np.random.RandomState(2).uniform(-1, 1, (B, 100)).astype(np.float32)).to(d)
+
+    def run(params):
+        ops.reset_variables()
+        gan = GAN("dcgan32", batch_size=B, device=d, params=params)
+        ref = gan.build_refiner(K, 0.1)
+        img = ref.build_refiner(gan.input_to_feature(z), None)
+        out = (img, ref.optimal_logit, ref.optimal_step)
+        ops.reset_variables()
+        return out
+    want = run(P)
+    for ext in ("safetensors", "npz"):
+        path = str(tmp_path / f"model-200.{ext}")
+        # a TF dump carries ':0' suffixes and optimizer slots: cleaned on the way in
+        dump = {k + ":0": v.numpy() for k, v in P.items()}
+        dump["discriminator/d_h0_conv/w/Adam:0"] = np.zeros((5, 5, 3, 64), np.float32)
+        dump["beta1_power:0"] = np.float32(0.5)
+        checkpoint.save(path, checkpoint.clean_tf_names(dump))
+        loaded = checkpoint.load(path)
+        assert checkpoint.check_against_arch(loaded, "dcgan32") and set(loaded) == set(P)
+        got = run(loaded)
+        for a, b in zip(got, want):
+            assert torch.equal(a, b)
+    bad = dict(loaded); bad.pop("generator/g_h2/w")
+    with pytest.raises(KeyError):
+        checkpoint.check_against_arch(bad, "dcgan32")
+
+
+def test_generic_path_handles_per_layer_geometry_instnorm_and_residuals():
+    """model.GAN._run (the ops + autograd path the Refiner falls back to) on the CycleGAN-style arch: per-layer kernel size
+    / stride, instance norm and residual blocks -- one logits + gradient evaluation against the oracle and the engine."""
+    from cgs_amd import ops
+    from cgs_amd.model import GAN
+    from cgs_amd.sampling.collaborator import Refiner
+    from oracle import sampling_ref as S
+    d = dev()
+    arch, B = "cyclegan_tiny", 3
+    ops.reset_variables()
+    P = N.init_params(arch, 2019, True)
+    gan = GAN(arch, batch_size=B, device=d, params=P)
+    src = torch.from_numpy(np.random.RandomState(3).uniform(-1, 1, (B,) + tuple(N.ARCHS[arch]["g_in"])).astype(np.float32))
+    f0 = gan.input_to_feature(src.to(d))
+    with torch.no_grad():
+        f0_o = N.input_to_feature(arch, P, src)
+    close(f0, f0_o, 1e-4)
+    ref = Refiner(2, 0.1)
+    ref.set_env(lambda x: gan.discriminator(x, is_training=True, reuse=True), lambda f: gan.feature_to_data(f), gan.loss_refine)
+    lm, grad = ref.compute_forward_logits_and_grad(f0_o.to(d))
+    lm_o, grad_o = S.forward_logits_and_grad(f0_o, lambda f: N.feature_to_data(arch, P, f), lambda x: N.discriminator(arch, P, x))
+    close(lm, lm_o, 1e-4)
+    close(grad, grad_o, 2e-3)
+    lm_e, grad_e = gan.engine(B).compute_forward_logits_and_grad(f0_o.to(d))
+    close(lm_e, lm_o, 1e-4)
+    close(grad_e, grad_o, 2e-3)
+    ops.reset_variables()
+
+
+def test_loss_and_clip_entry_points():
+    from cgs_amd import kernels as K, ops
+    d = dev()
+    l = (rnd((257, 1), 1, 6.0)).to(d).requires_grad_(True)
+    loss = ops.sigmoid_cross_entropy_with_logits_ones(l)
+    want = torch.nn.functional.softplus(-l.detach().cpu().double())
+    assert (loss.detach().cpu().double() - want).abs().max().item() < 1e-6
+    (g,) = torch.autograd.grad(loss.sum(), l)
+    assert (g.cpu().double() - (torch.sigmoid(l.detach().cpu().double()) - 1)).abs().max().item() < 1e-6
+    x = rnd((1000,), 2, 3.0)
+    assert torch.equal(K.clip(x.to(d), -0.5, 1.25).cpu(), torch.clamp(x, -0.5, 1.25))

@@ -128,3 +128,29 @@ def test_shape_step_loop_runs_and_lowers_d_loss_on_refined():
     np.random.seed(0)
     losses = [float(shape_step(eng, sh, z, real, 3, 0.1)) for _ in range(6)]
     assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+
+
+def test_graph_replay_sees_the_shaped_discriminator():
+    """hipGraphs are warmed up and captured on one explicit stream, so the capture finds the packed weights
+    (no pack kernel is recorded) and ``refresh_weights`` re-packs those very buffers: after a D shaping step a graph REPLAY
+    must give what a freshly built eager engine gives on the new weights -- and not what it gave before the step."""
+    from cgs_amd.engine import RefineEngine
+    from cgs_amd.nets import to_device
+    from cgs_amd.shaping import DShaper
+    d = dev()
+    B, arch, K = 16, "mnist", 3
+    Pd = to_device(N.init_params(arch, 2019, True), d)
+    geng = RefineEngine(arch, Pd, B, d, use_graph=True)
+    sh = DShaper(arch, Pd, B, d, learning_rate=2e-3)
+    real = rnd((B, 28, 28, 1), 1).clamp(-1, 1).to(d)
+    z = rnd((B, 62), 2).clamp(-1, 1).to(d)
+    before = [t.clone() for t in geng.refine_from_z(z, K, 0.1)]           # capture
+    again = [t.clone() for t in geng.refine_from_z(z, K, 0.1)]            # replay
+    assert all(torch.equal(a, b) for a, b in zip(before, again))
+    sh.step(real, before[0])
+    geng.refresh_weights()
+    after = [t.clone() for t in geng.refine_from_z(z, K, 0.1)]            # replay on the shaped D
+    fresh = [t.clone() for t in RefineEngine(arch, Pd, B, d).refine_from_z(z, K, 0.1)]
+    assert not torch.equal(after[2], before[2])
+    for a, b in zip(after, fresh):
+        assert torch.equal(a, b)

@@ -250,3 +250,35 @@ def test_sharding_and_gather_over_gloo(tmp_path):
     assert not np.array_equal(D.z_batches(0, 1, 4, 5), D.z_batches(1, 1, 4, 5))                  # disjoint shards
     assert D.batch_owner(5, 4) == (1, 1) and D.rank_seed(3) == 2022
     assert D.gather_pool(torch.ones(2, 3)).shape == (2, 3)                                        # no group: identity
+
+
+def test_bench_self_launches_its_ranks_as_child_processes(monkeypatch):
+    """`python bench.py --gpus N` (N > 1, no WORLD_SIZE): the parent must start torch.distributed.run as a CHILD process
+    with the same arguments, on the loopback rendezvous, before touching the GPU, and exit with the child's code."""
+    import importlib
+    import subprocess
+    import sys
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    seen = {}
+
+    class R:
+        returncode = 7
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+        return R()
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.delenv("RANK", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1"])
+    import torch
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: (_ for _ in ()).throw(AssertionError("GPU touched before the launch")))
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nproc-per-node=2" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-6:] == ["--gpus", "2", "--steps", "2", "--warmup", "1"] and cmd[-7].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
