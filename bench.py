@@ -35,9 +35,15 @@ TRAFFIC_JSON = os.path.join(ROOT, "profiles", "traffic.json")
 
 
 def measured_traffic(kernel):
+    """HBM bytes per launch of ``kernel`` from the committed PMC passes -- or None when profiles/traffic.json was collected
+    on other kernel sources than the ones this run executes (a stale number is worse than none)."""
     try:
+        from cgs_amd.lib import source_hash
         with open(TRAFFIC_JSON) as f:
-            return json.load(f).get(kernel, {}).get("hbm_bytes_per_launch_corrected")
+            t = json.load(f)
+        if t.get("_source_sha256") != source_hash():
+            return None
+        return t.get(kernel, {}).get("hbm_bytes_per_launch_corrected")
     except (OSError, ValueError):
         return None
 
@@ -79,35 +85,40 @@ def cpu_baseline(arch, refine_steps, rate, budget_batch=64):
                       f"{dt:.1f} s wall, {best_n} of {ncpu} host threads (fastest of a 8/16/32/64/all calibration)"}
 
 
-def bench_synthetic2d(args, dev, rank, world):
-    """BASELINE config 1: Imbal-8Gaussians MLP-GAN (D: 2 -> 64 x 5 -> 1), batch 512, K = 10, ladam rate 0.1
-    (synthetic/main.py:32-62) -- the whole refiner_cpu loop as one launch per batch (cgs_amd.synthetic)."""
+def run_synthetic2d(dev, rank, B, Ksteps, rate, steps, warmup, n_streams):
+    """BASELINE config 1 on the fused device refiner: (seconds for ``steps`` batches, the pieces the cpu_baseline leg needs)."""
     from cgs_amd.synthetic import MLPDiscriminator
     from oracle import sampling_ref as S                      # only for the seeded weights + the cpu_baseline leg
-    B, Ksteps = args.batch or 512, args.refine_steps or 10
     Ws, bs = S.mlp_init(64, 6, seed=2019, scale=2.0)
     D = MLPDiscriminator.from_lists([w.numpy() for w in Ws], [b.numpy() for b in bs], dev)
-    n = args.steps + args.warmup
+    n = steps + warmup
     x = torch.from_numpy((3.0 * np.random.RandomState(2019 + rank).randn(n, B, 2)).astype(np.float32)).to(dev)
     real = torch.from_numpy(S.toy_next_batch("Imbal-8Gaussians", 10.0, 0.9, B, np.random.RandomState(7)).astype(np.float32)).to(dev)
 
     # one wave per sample: a 512-sample batch occupies 6 % of the GPU's wave slots and is latency-bound (K+1 dependent MLP
     # evaluations), so independent batches are kept in flight on several streams (nothing synchronises with the host)
-    n_streams = args.streams if args.streams > 0 else 8
     streams = [torch.cuda.Stream(dev) for _ in range(n_streams)]
 
     def step(i):
         with torch.cuda.stream(streams[i % n_streams]):
             base = D.sigmoid_and_saliency(real, want_saliency=False)[0].mean()        # np.mean(real_sigmoid), refiner_cpu.py:23,28 (stays on the device)
-            return D.refine(x[i], base, Ksteps, args.rate, "ladam")[0]
-    for i in range(args.warmup):
+            return D.refine(x[i], base, Ksteps, rate, "ladam")[0]
+    for i in range(warmup):
         step(i)
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    for i in range(args.warmup, n):
+    for i in range(warmup, n):
         step(i)
     torch.cuda.synchronize(dev)
-    dt = time.perf_counter() - t0
+    return time.perf_counter() - t0, (S, Ws, bs, x, real)
+
+
+def bench_synthetic2d(args, dev, rank, world):
+    """BASELINE config 1: Imbal-8Gaussians MLP-GAN (D: 2 -> 64 x 5 -> 1), batch 512, K = 10, ladam rate 0.1
+    (synthetic/main.py:32-62) -- the whole refiner_cpu loop as one launch per batch (cgs_amd.synthetic)."""
+    B, Ksteps = args.batch or 512, args.refine_steps or 10
+    n_streams = args.streams if args.streams > 0 else 8
+    dt, (S, Ws, bs, x, real) = run_synthetic2d(dev, rank, B, Ksteps, args.rate, args.steps, args.warmup, n_streams)
     if rank == 0:
         out = {"metric": f"refined samples/sec @ {Ksteps} refinement steps", "value": round(world * B * args.steps / dt, 1), "unit": "samples/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
@@ -127,6 +138,43 @@ def bench_synthetic2d(args, dev, rank, world):
             out["cpu_baseline"] = {"value": round(B / c, 1), "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
                                    "sample": f"oracle.refine_2d (refiner_cpu.manipulate_sample restated; torch-CPU D), batch {B}, K={Ksteps}, {reps} reps"}
         print(json.dumps(out), flush=True)
+
+
+def other_configs(dev, skip):
+    """samples/s of the other single-GPU configurations ("always report MNIST"; BASELINE configs[0], [1]) at
+    their bench.py defaults, timed AFTER and OUTSIDE the headline's timed region: a handful of steps each, value only."""
+    from cgs_amd import nets
+    from cgs_amd.engine import RefineEngine
+    out = {}
+    for arch, B, Ksteps, G, steps in (("mnist", 64, 50, 16, 6), ("dcgan32", 256, 20, 4, 6)):
+        if arch == skip:
+            continue
+        A = nets.ARCHS[arch]
+        P = nets.init_params(arch, dev, seed=2019)
+        engines = [RefineEngine(arch, P, B * G, dev, bn_groups=G) for _ in range(2)]
+        streams = [torch.cuda.Stream(dev) for _ in engines]
+        z = torch.from_numpy(np.random.RandomState(2019).uniform(-1, 1, (steps + 2, B * G) + nets.g_input_shape(A)).astype(np.float32)).to(dev)
+
+        def step(i):
+            with torch.cuda.stream(streams[i % 2]):
+                engines[i % 2].refine_from_z(z[i], Ksteps, 0.1)
+        step(0); step(1)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for i in range(2, steps + 2):
+            step(i)
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+        out[arch] = {"samples_per_s": round(B * G * steps / dt, 1), "batch": B, "refine_steps": Ksteps, "fused_per_launch": G,
+                     "batches_in_flight": 2 * G, "steps": steps,
+                     "algorithmic_tflops": round(B * G * steps / dt * nets.refine_flops_per_sample(arch, Ksteps) / 1e12, 2)}
+        del engines, z, P
+        torch.cuda.empty_cache()
+    if skip != "synthetic2d":
+        dt, _ = run_synthetic2d(dev, 0, 512, 10, 0.1, 256, 16, 8)
+        out["synthetic2d"] = {"samples_per_s": round(512 * 256 / dt, 1), "batch": 512, "refine_steps": 10, "method": "ladam",
+                              "batches_in_flight": 8, "steps": 256}
+    return out
 
 
 def self_launch(n_gpus):
@@ -165,6 +213,8 @@ def main():
                     help="treat the N ranks' batches as ONE logical batch of N*B samples: all-reduce D's batch-norm sums "
                          "(needs the torch.distributed launch; eager only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the mnist / dcgan32 / synthetic2d samples/s that are measured after the headline's timed region")
     ap.add_argument("--by-layer", action="store_true", help="key the per-kernel timing records by layer shape too (diagnostic)")
     args = ap.parse_args()
     if args.steps <= 0:
@@ -272,19 +322,25 @@ def main():
         if prof:
             dom = max(prof.items(), key=lambda kv: sum(a.elapsed_time(b) for a, b in kv[1][1]))
             per = {}
-            for name, (fl, evs) in prof.items():
+            for name, (fl, evs, ex) in prof.items():
                 ms = sum(a.elapsed_time(b) for a, b in evs)
                 per[name] = {"launches": len(evs), "avg_us": round(1e3 * ms / len(evs), 2), "tflops": round(fl / ms / 1e9, 2),
-                             "share_of_step": round(ms / prof_ms, 3)}
-            name, (fl, evs) = dom
+                             "executed_tflops": round(ex / ms / 1e9, 2), "share_of_step": round(ms / prof_ms, 3)}
+            name, (fl, evs, ex) = dom
             ms = sum(a.elapsed_time(b) for a, b in evs)
             ach = fl / ms / 1e9
+            # "achieved" divides the ALGORITHMIC flop count (zero-padding taps included, the contract's definition) by the
+            # launch time; "executed_frac" counts only what the kernel issues to the matrix cores: it skips the K tiles of
+            # taps that fall into the padding on the <= 8x8 grids (exact: they add zeros), 14-28 % of those layers
             out["roofline"] = {"kernel": name, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MATRIX_TFLOPS,
                                "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MATRIX_TFLOPS, 4),
+                               "executed": round(ex / ms / 1e9, 2), "executed_frac": round(ex / ms / 1e9 / PEAK_FP32_MATRIX_TFLOPS, 4),
                                "traffic": measured_traffic(name) if args.arch == "dcgan64" and B == 1024 else None,
                                "launches": len(evs), "avg_launch_us": round(1e3 * ms / len(evs), 2), "timing": prof_note,
-                               "flop_per_launch_avg": round(fl / len(evs), 0)}
+                               "flop_per_launch_avg": round(fl / len(evs), 0), "executed_flop_per_launch_avg": round(ex / len(evs), 0)}
             out["kernels"] = per
+        if world == 1 and not args.no_other_configs:
+            out["other_configs"] = other_configs(dev, args.arch)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.arch, Ksteps, args.rate)
         print(json.dumps(out), flush=True)

@@ -8,7 +8,10 @@
 static thread_local char g_err[512] = "";
 static thread_local const char* g_last_kernel = "";
 
+static thread_local double g_last_flops = 0.0;
+
 void cgs_note_kernel(const char* name) { g_last_kernel = name; }
+void cgs_note_flops(double f) { g_last_flops = f; }
 
 int cgs_set_error(int code, const char* fmt, ...) {
     va_list ap;
@@ -23,6 +26,7 @@ extern "C" {
 int cgs_version(void) { return 100; }
 const char* cgs_last_error(void) { return g_err; }
 const char* cgs_last_kernel(void) { return g_last_kernel; }
+double cgs_last_executed_flops(void) { return g_last_flops; }
 
 }  // extern "C"
 
@@ -64,6 +68,7 @@ static int choose_family(const CgsLayer& L, bool dirT, int B, int epilogue, bool
 static int run_dir(const CgsLayer& L, bool dirT, int B, const float* in, const float* w, const float* bias, float* out,
                    int epilogue, const float* ep_a, const float* ep_b, const float* ep_aux, void* ws, size_t ws_bytes,
                    int prepacked, hipStream_t s, const char* who) {
+    cgs_note_flops(0.0);
     if (B <= 0) return cgs_set_error(CGS_EINVAL, "%s: B=%d", who, B);
     if (!in || !w || !out) return cgs_set_error(CGS_EINVAL, "%s: null tensor", who);
     if (epilogue < CGS_EPI_NONE || epilogue > CGS_EPI_TANH_BWD) return cgs_set_error(CGS_EINVAL, "%s: epilogue %d", who, epilogue);

@@ -8,6 +8,7 @@
 
 int cgs_set_error(int code, const char* fmt, ...);
 void cgs_note_kernel(const char* name);   // remembered per thread, read back by cgs_last_kernel()
+void cgs_note_flops(double executed);     // ... by cgs_last_executed_flops()
 
 #define CGS_CHECK_LAUNCH(name)                                                        \
     do {                                                                              \

@@ -678,6 +678,30 @@ int cgs_igemm_launch(const IgemmParams& p_in, void* slab, size_t slab_bytes, hip
         }
     }
     const bool vec = (p.Cred % BK) == 0;
+    {   // multiply-accumulates this launch really issues: the algorithmic count minus the zero-padding taps whose K tiles the
+        // kernel skips (pixel-major tiles whose 128 rows are one base pixel; exact, see igemm_kernel) -- for honest rooflines
+        double macs = 0.0;
+        for (int ci = 0; ci < p.nclasses; ++ci) {
+            const IgemmClass& c = p.cls[ci];
+            const long M = (long)p.B * c.R * c.C;
+            const int ntaps = c.nty * c.ntx;
+            if (!(vec && p.pix_major)) { macs += (double)M * p.N * p.Cred * ntaps; continue; }
+            for (long m0 = 0; m0 < M; m0 += 128) {
+                const long ml = m0 + 127 < M ? m0 + 127 : M - 1;
+                const int pf = (int)(m0 / p.B), pl = (int)(ml / p.B);
+                int taps = ntaps;
+                if (pf == pl) {
+                    const int r = pf / c.C, cc = pf - r * c.C;
+                    int ny = 0, nx = 0;
+                    for (int ta = 0; ta < c.nty; ++ta) { const int iy = r * p.S + c.dy0 + ta * p.dstep; ny += (iy >= 0 && iy < p.Hin); }
+                    for (int tb = 0; tb < c.ntx; ++tb) { const int ix = cc * p.S + c.dx0 + tb * p.dstep; nx += (ix >= 0 && ix < p.Win); }
+                    taps = ny * nx;
+                }
+                macs += (double)(ml - m0 + 1) * p.N * p.Cred * taps;
+            }
+        }
+        cgs_note_flops(2.0 * macs);
+    }
     bool wide = (p.Np % 128) == 0;
     if (wide && p.lpt) {      // uneven tiles need >= 2 rounds of blocks over the 512 block slots to balance: halve BN if short
         long blocks = 0;

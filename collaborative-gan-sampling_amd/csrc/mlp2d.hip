@@ -160,6 +160,135 @@ __global__ __launch_bounds__(1024) void refine2d_kernel(MlpParams p, const float
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// D shaping step of the 2-D net (synthetic/main.py:366-370 -> synthetic/GAN.py:69-74,98-99):
+//   d_loss = mean_b BCE(D(real_b), 1) + mean_b BCE(D(refined_b), 0);  GradientDescentOptimizer(lrd).minimize(d_loss, d_vars)
+// Pass A (one wave per sample, the same LDS-resident walk as above): forward keeping every hidden activation, backward
+// from the loss seed keeping every pre-activation gradient.  Pass B (one block per layer): dW_l = A_{l-1}^T Delta_l and
+// db_l = column sums of Delta_l, summed over the samples in a FIXED order (deterministic), then w -= lr * g in place.
+// ------------------------------------------------------------------------------------------------------------------
+// acts / deltas: [B_total][nlayers-1][64]; dlast / bce: [B_total]
+__global__ __launch_bounds__(1024) void mlp_train_fwdbwd_kernel(MlpParams p, const float* __restrict__ x, int B, int row0, float target,
+                                                                float scale, float* __restrict__ acts, float* __restrict__ deltas,
+                                                                float* __restrict__ dlast, float* __restrict__ bce) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const MlpLds L = mlp_lds(smem, p.nlayers);
+    mlp_load(p, L);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int nhid = p.nlayers - 1;
+    for (int s = blockIdx.x * nw + wave; s < B; s += gridDim.x * nw) {
+        float* A = acts + (size_t)(row0 + s) * nhid * 64;
+        float* D = deltas + (size_t)(row0 + s) * nhid * 64;
+        unsigned long long masks[MLP_MAX_LAYERS];
+        const float x0 = x[2 * s], x1 = x[2 * s + 1];
+        float h = fmaf(x1, L.w1[64 + lane], fmaf(x0, L.w1[lane], L.bias[lane]));
+        masks[0] = __ballot(h > 0.f);
+        h = fmaxf(h, 0.f);
+        A[lane] = h;
+        for (int l = 1; l < nhid; ++l) {
+            const float* W = L.wh + (size_t)(l - 1) * 8192;
+            float a = L.bias[l * 64 + lane];
+#pragma unroll 8
+            for (int k = 0; k < 64; ++k) a = fmaf(bcast(h, k), W[k * 64 + lane], a);
+            masks[l] = __ballot(a > 0.f);
+            h = fmaxf(a, 0.f);
+            A[l * 64 + lane] = h;
+        }
+        float part = h * L.wl[lane];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+        const float logit = part + L.bias[(p.nlayers - 1) * 64];
+        const float seed = scale * (sigmoidf_(logit) - target);            // d (scale * BCE(logit, target)) / d logit
+        if (lane == 0) {
+            dlast[row0 + s] = seed;
+            bce[row0 + s] = scale * (fmaxf(logit, 0.f) - logit * target + log1pf(expf(-fabsf(logit))));
+        }
+        float g = seed * L.wl[lane];
+        for (int l = nhid - 1; l >= 1; --l) {
+            g = ((masks[l] >> lane) & 1ull) ? g : 0.f;
+            D[l * 64 + lane] = g;
+            const float* WT = L.wh + (size_t)(l - 1) * 8192 + 4096;
+            float a = 0.f;
+#pragma unroll 8
+            for (int jj = 0; jj < 64; ++jj) a = fmaf(bcast(g, jj), WT[jj * 64 + lane], a);
+            g = a;
+        }
+        g = ((masks[0] >> lane) & 1ull) ? g : 0.f;
+        D[lane] = g;
+    }
+}
+
+struct MlpTrainPtrs {
+    float* w[MLP_MAX_LAYERS];
+    float* b[MLP_MAX_LAYERS];
+    float* gw[MLP_MAX_LAYERS];      // may be null
+    float* gb[MLP_MAX_LAYERS];
+};
+
+// block l < nlayers: gradient (+ SGD step) of layer l; block nlayers: the two loss sums.  1024 threads: thread -> row i = t / 16
+// of the [din][dout] kernel and 4 columns j4 .. j4+3; the sample dimension is walked in tiles of 64 staged through LDS.
+__global__ __launch_bounds__(1024) void mlp_train_grad_kernel(MlpTrainPtrs q, int nlayers, int nh, const float* __restrict__ xr, int Br,
+                                                              const float* __restrict__ xf, int Bf, const float* __restrict__ acts,
+                                                              const float* __restrict__ deltas, const float* __restrict__ dlast,
+                                                              const float* __restrict__ bce, float lr, float* __restrict__ loss) {
+    __shared__ float As[64][65];
+    __shared__ __attribute__((aligned(16))) float Ds[64][64];
+    const int t = threadIdx.x, Bt = Br + Bf, nhid = nlayers - 1;
+    const int l = blockIdx.x;
+    if (l == nlayers) {            // d_loss_real, d_loss_fake: fixed-order strided sums + a fixed tree
+        float* red = &As[0][0];
+        for (int part = 0; part < 2; ++part) {
+            const int lo = part ? Br : 0, hi = part ? Bt : Br;
+            float s = 0.f;
+            for (int i = lo + t; i < hi; i += 1024) s += bce[i];
+            red[t] = s;
+            __syncthreads();
+            for (int w = 512; w > 0; w >>= 1) { if (t < w) red[t] += red[t + w]; __syncthreads(); }
+            if (t == 0 && loss) loss[part] = red[0];
+            __syncthreads();
+        }
+        return;
+    }
+    const int din = l == 0 ? 2 : nh, dout = l == nlayers - 1 ? 1 : nh;
+    const int i = t >> 4, j4 = (t & 15) * 4;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f}, accb[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int b0 = 0; b0 < Bt; b0 += 64) {
+        for (int e = t; e < 4096; e += 1024) {             // stage 64 samples: inputs of the layer and its output gradients
+            const int bb = e >> 6, c = e & 63, b = b0 + bb;
+            float a = 0.f, d = 0.f;
+            if (b < Bt) {
+                if (l == 0) { if (c < 2) a = b < Br ? xr[2 * b + c] : xf[2 * (b - Br) + c]; }
+                else a = acts[((size_t)b * nhid + (l - 1)) * 64 + c];
+                if (l == nlayers - 1) { if (c == 0) d = dlast[b]; }
+                else d = deltas[((size_t)b * nhid + l) * 64 + c];
+            }
+            As[bb][c] = a; Ds[bb][c] = d;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int bb = 0; bb < 64; ++bb) {
+            const float a = As[bb][i];
+            const float4 d = *(const float4*)&Ds[bb][j4];
+            acc[0] = fmaf(a, d.x, acc[0]); acc[1] = fmaf(a, d.y, acc[1]); acc[2] = fmaf(a, d.z, acc[2]); acc[3] = fmaf(a, d.w, acc[3]);
+            accb[0] += d.x; accb[1] += d.y; accb[2] += d.z; accb[3] += d.w;
+        }
+        __syncthreads();
+    }
+    for (int e = 0; e < 4; ++e) {
+#pragma clang fp contract(off)      // var -= lr * grad as two roundings (GradientDescentOptimizer's ApplyGradientDescent)
+        const int j = j4 + e;
+        if (i < din && j < dout) {
+            const size_t o = (size_t)i * dout + j;
+            if (q.gw[l]) q.gw[l][o] = acc[e];
+            if (lr != 0.f) q.w[l][o] = q.w[l][o] - lr * acc[e];
+        }
+        if (i == 0 && j < dout) {
+            if (q.gb[l]) q.gb[l][j] = accb[e];
+            if (lr != 0.f) q.b[l][j] = q.b[l][j] - lr * accb[e];
+        }
+    }
+}
+
 static int mlp_fill(MlpParams& p, const float* const* w, const float* const* b, int nlayers, int nh, const char* who) {
     if (nlayers < 2 || nlayers > MLP_MAX_LAYERS || nh < 1 || nh > 64) return cgs_set_error(CGS_EINVAL, "%s: nlayers=%d nhidden=%d (need 2..6, 1..64)", who, nlayers, nh);
     for (int l = 0; l < nlayers; ++l) {
@@ -215,6 +344,44 @@ int cgs_refine2d_devbase(const float* const* w, const float* const* b, int nlaye
                          float* best_step, float* traj, int B, void* stream) {
     if (!real_sigmoid_mean_dev) return cgs_set_error(CGS_EINVAL, "refine2d_devbase: null baseline pointer");
     return refine2d_launch(w, b, nlayers, nhidden, x, 0.f, real_sigmoid_mean_dev, inv_batch, steps, rate, method, best_x, best_step, traj, B, stream);
+}
+
+size_t cgs_mlp2d_train_ws_bytes(int B_total, int nlayers) {
+    if (B_total <= 0 || nlayers < 2 || nlayers > MLP_MAX_LAYERS) return 0;
+    return ((size_t)B_total * (nlayers - 1) * 64 * 2 + (size_t)B_total * 2) * sizeof(float);
+}
+
+int cgs_mlp2d_d_step(float* const* w, float* const* b, int nlayers, int nhidden, const float* real, int B_real, const float* fake,
+                     int B_fake, float lr, float* const* gw, float* const* gb, float* loss, void* ws, size_t ws_bytes, void* stream) {
+    MlpParams p;
+    int rc = mlp_fill(p, (const float* const*)w, (const float* const*)b, nlayers, nhidden, "mlp2d_d_step");
+    if (rc) return rc;
+    if (B_real <= 0 || B_fake <= 0 || !real || !fake) return cgs_set_error(CGS_EINVAL, "mlp2d_d_step: bad argument");
+    const int Bt = B_real + B_fake;
+    const size_t need = cgs_mlp2d_train_ws_bytes(Bt, nlayers);
+    if (!ws || ws_bytes < need) return cgs_set_error(CGS_EWORKSPACE, "mlp2d_d_step: workspace %zu < %zu bytes", ws_bytes, need);
+    float* acts = (float*)ws;
+    float* deltas = acts + (size_t)Bt * (nlayers - 1) * 64;
+    float* dlast = deltas + (size_t)Bt * (nlayers - 1) * 64;
+    float* bce = dlast + Bt;
+    const size_t smem = mlp_smem(nlayers);
+    (void)hipFuncSetAttribute((const void*)mlp_train_fwdbwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    for (int part = 0; part < 2; ++part) {      // real rows (target 1) then refined rows (target 0); each loss term is a MEAN
+        const int B = part ? B_fake : B_real;
+        int blocks = (B + 15) / 16; if (blocks > 256) blocks = 256;
+        hipLaunchKernelGGL(mlp_train_fwdbwd_kernel, dim3(blocks), dim3(1024), smem, (hipStream_t)stream, p, part ? fake : real, B,
+                           part ? B_real : 0, part ? 0.f : 1.f, 1.f / (float)B, acts, deltas, dlast, bce);
+        CGS_CHECK_LAUNCH("mlp_train_fwdbwd");
+    }
+    MlpTrainPtrs q;
+    for (int l = 0; l < MLP_MAX_LAYERS; ++l) {
+        q.w[l] = l < nlayers ? w[l] : nullptr; q.b[l] = l < nlayers ? b[l] : nullptr;
+        q.gw[l] = (gw && l < nlayers) ? gw[l] : nullptr; q.gb[l] = (gb && l < nlayers) ? gb[l] : nullptr;
+    }
+    hipLaunchKernelGGL(mlp_train_grad_kernel, dim3(nlayers + 1), dim3(1024), 0, (hipStream_t)stream, q, nlayers, nhidden, real, B_real, fake,
+                       B_fake, acts, deltas, dlast, bce, lr, loss);
+    CGS_CHECK_LAUNCH("mlp_train_grad");
+    return CGS_OK;
 }
 
 }  // extern "C"

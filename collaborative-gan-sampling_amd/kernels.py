@@ -31,7 +31,7 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-# ---- optional per-kernel timing (bench.py): {kernel_name: [flops, [(ev_start, ev_end), ...]]} or None.
+# ---- optional per-kernel timing (bench.py): {kernel_name: [flops, [(ev_start, ev_end), ...], executed_flops]} or None.
 # Events are recorded on the stream the kernel is launched on (torch's current stream).
 PROFILE = None
 
@@ -53,9 +53,11 @@ class _Prof:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record()
             kname = L.load().cgs_last_kernel().decode()        # the instantiation the dispatcher actually launched
-            rec = PROFILE.setdefault(kname + " " + self.name if PROFILE_BY_LAYER else kname, [0.0, []])
+            executed = float(L.load().cgs_last_executed_flops()) or self.flops     # minus the skipped zero-padding taps
+            rec = PROFILE.setdefault(kname + " " + self.name if PROFILE_BY_LAYER else kname, [0.0, [], 0.0])
             rec[0] += self.flops
             rec[1].append((self.e0, e1))
+            rec[2] += executed
 
 
 def same_out(size, stride):

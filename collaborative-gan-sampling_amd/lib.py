@@ -23,6 +23,7 @@ SIGNATURES = {
     "cgs_version": (_i, []),
     "cgs_last_error": (C.c_char_p, []),
     "cgs_last_kernel": (C.c_char_p, []),
+    "cgs_last_executed_flops": (C.c_double, []),
     "cgs_conv_ws_bytes": (_z, [_i] * 7),
     "cgs_conv_ws_bytes_for": (_z, [_i] * 10),
     "cgs_conv_family": (_i, [_i] * 13 + [_z]),
@@ -62,6 +63,8 @@ SIGNATURES = {
     "cgs_mlp2d_sigmoid_saliency": (_i, [_p, _p, _i, _i, _p, _p, _p, _i, _f, _p]),
     "cgs_refine2d": (_i, [_p, _p, _i, _i, _p, _f, _f, _i, _f, _i, _p, _p, _p, _i, _p]),
     "cgs_refine2d_devbase": (_i, [_p, _p, _i, _i, _p, _p, _f, _i, _f, _i, _p, _p, _p, _i, _p]),
+    "cgs_mlp2d_train_ws_bytes": (_z, [_i, _i]),
+    "cgs_mlp2d_d_step": (_i, [_p, _p, _i, _i, _p, _i, _p, _i, _f, _p, _p, _p, _p, _z, _p]),
     "cgs_conv_wgrad_ws_bytes": (_z, [_i] * 9),
     "cgs_conv2d_nhwc_bwd_weight": (_i, [_p] * 3 + [_i] * 9 + [_i, _p, _z, _p]),
     "cgs_linear_bwd_weight": (_i, [_p] * 3 + [_i] * 3 + [_i, _p, _z, _p]),
@@ -116,3 +119,18 @@ def conv_ws_bytes_for(op, b, h, w, cin, cout, kh, kw, sh, sw):
 
 def bn_ws_bytes(m, c):
     return int(load().cgs_bn_ws_bytes(m, c))
+
+
+def source_hash():
+    """sha256 over the kernel sources (csrc/*.hip, *.h and include/cgs_hip.h): identifies the code measured numbers such as
+    profiles/traffic.json belong to (bench.py reports ``roofline.traffic`` only while it matches)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(_HERE, "csrc", "*.hip")) + glob.glob(os.path.join(_HERE, "csrc", "*.h")))
+    files.append(os.path.join(os.path.dirname(_HERE), "include", "cgs_hip.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()

@@ -128,3 +128,88 @@ class Refiner:
             pick = np.random.randint(self.forward_steps + 1, size=n)
             return traj.cpu().numpy().astype(np.float64)[np.arange(n), pick, :]
         return best.cpu().numpy().astype(fake_batch.dtype, copy=False)
+
+
+class DShaper:
+    """The D update of the 2-D shaping loop (synthetic/main.py:366-370): one ``tf.train.GradientDescentOptimizer(lrd)`` step on
+    d_loss = mean BCE(D(real), 1) + mean BCE(D(refined), 0) (synthetic/GAN.py:69-74,98-99), run on the device IN PLACE on the
+    ``MLPDiscriminator``'s own weight tensors (two per-sample forward/backward launches + one gradient/update launch).
+    The refiner reads the same tensors, so the next ``manipulate_sample`` sees the shaped D."""
+
+    def __init__(self, discriminator, lrd=1e-2):                      # synthetic/main.py:39 (--lrd 1e-2)
+        self.D, self.lrd = discriminator, float(lrd)
+        self.loss = torch.zeros(2, dtype=torch.float32, device=discriminator.dev)
+        self.gw = [torch.zeros_like(t) for t in discriminator.w]
+        self.gb = [torch.zeros_like(t) for t in discriminator.b]
+        n = discriminator.nlayers
+        self._gwp = (C.c_void_p * n)(*[t.data_ptr() for t in self.gw])
+        self._gbp = (C.c_void_p * n)(*[t.data_ptr() for t in self.gb])
+        self._ws = None
+
+    def _run(self, real, refined, lr):
+        D = self.D
+        xr, xf = D._x(real), D._x(refined)
+        need = int(L.load().cgs_mlp2d_train_ws_bytes(xr.shape[0] + xf.shape[0], D.nlayers))
+        if self._ws is None or self._ws.numel() * 4 < need:
+            self._ws = torch.empty(need // 4 + 4, dtype=torch.float32, device=D.dev)
+        L.call("cgs_mlp2d_d_step", D._wp, D._bp, D.nlayers, D.nhidden, xr.data_ptr(), xr.shape[0], xf.data_ptr(), xf.shape[0],
+               float(lr), self._gwp, self._gbp, self.loss.data_ptr(), self._ws.data_ptr(), self._ws.numel() * 4,
+               torch.cuda.current_stream(D.dev).cuda_stream)
+        return self.loss
+
+    def loss_and_grads(self, real, refined):
+        """((d_loss_real, d_loss_fake) device tensor, [dW...], [db...]) without touching the weights."""
+        return self._run(real, refined, 0.0), self.gw, self.gb
+
+    def step(self, real, refined):
+        """One SGD step of D; returns (d_loss_real, d_loss_fake) as evaluated BEFORE the update (device tensor)."""
+        return self._run(real, refined, self.lrd)
+
+
+def shape_step(refiner, shaper, noise_sample, real_batch):
+    """One iteration of synthetic/main.py:366-370:
+    ``refined = refiner.manipulate_sample(noise_sample, 'probabilistic'); sess.run(d_optim, {inputs: real, generates: refined})``."""
+    refined = refiner.manipulate_sample(noise_sample, 'probabilistic')
+    return shaper.step(real_batch, refined), refined
+
+
+def proposer(refiner, generate, discriminator):
+    """propose() / score() closures for ``evaluate.collaborate`` on the 2-D path (synthetic/main.py:240-243):
+    ``generate()`` -> a generator batch (``sess.run(gan.generates, {z: noise.next_batch(n)})`` in the reference -- G is outside
+    the hot path, so the caller supplies it); propose = the device refiner on it; score = the device D's sigmoid."""
+    def propose():
+        return refiner.manipulate_sample(generate())
+
+    def score(batch):
+        return discriminator.sigmoid_and_saliency(batch, want_saliency=False)[0].cpu().numpy().astype(np.float64)
+
+    return propose, score
+
+
+def evaluate_collaborative(refiner, discriminator, generate, eval_batch, target_batch, centeroids, std, mh_sampler=None):
+    """The "shape"-mode evaluation of synthetic/main.py:215-263 on the device refiner: refine the evaluation batch, report its
+    quality, then D-score -> MH fill (thinning T = 20, chain seeded with mean(real_sigmoid)) until ``len(eval_batch)`` samples
+    are accepted (proposal counter advancing only for productive batches, :251) and report the collaborative sample's
+    quality.  Returns {"refinement": {...}, "collaborate": {..., "eff": accepted / proposed}} with the reference's four 2-D
+    metrics (utils_sampling.py:132-184; ``thres`` = 4 std as in main.py:221)."""
+    from . import metrics as Mx
+    from .evaluate import collaborate
+    from .sampling import IndependenceSampler
+    thres = std * 4
+
+    def quality(samples):
+        mean_dist, good = Mx.metrics_distance(samples, centeroids, thres)
+        return {"mean_dist": float(mean_dist), "good": float(good),
+                "kl": float(Mx.metrics_diversity(target_batch, samples, centeroids, thres)),
+                "js": float(Mx.metrics_distribution(target_batch, samples, centeroids, thres))}
+    _, score = proposer(refiner, generate, discriminator)
+    real_sigmoid = score(target_batch)                                                 # main.py:116
+    out = {"standard": quality(eval_batch)}
+    refined = refiner.manipulate_sample(eval_batch)                                    # :217
+    out["refinement"] = quality(refined)
+    mh = mh_sampler if mh_sampler is not None else IndependenceSampler(T=20)           # main.py:80
+    propose = lambda: refiner.manipulate_sample(generate())                            # :239-241 (eval_size proposals per round)
+    samples, eff = collaborate(propose, score, mh, len(eval_batch), float(np.mean(real_sigmoid)),
+                               base=(refined, score(refined)), count_only_productive=True)      # :229-253
+    out["collaborate"] = dict(quality(samples), eff=float(eff))
+    return out

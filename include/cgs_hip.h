@@ -58,6 +58,9 @@ int cgs_version(void);
 const char* cgs_last_error(void);
 /* Name of the compute kernel the calling thread's most recent conv-family call launched (for profiling). */
 const char* cgs_last_kernel(void);
+/* Floating-point operations that call really issued to the matrix cores: 2 x (algorithmic multiply-accumulates minus those
+ * of zero-padding taps the kernel skipped).  0 = the kernel skips nothing (executed = algorithmic).  For rooflines. */
+double cgs_last_executed_flops(void);
 
 /* Bytes of workspace a conv-family call needs for its packed copy of the weights
  * (op = one of CGS_CONV_* above; Cin/Cout are those of the LAYER, i.e. of the
@@ -233,6 +236,17 @@ int cgs_refine2d(const float* const* w, const float* const* b, int nlayers, int 
 int cgs_refine2d_devbase(const float* const* w, const float* const* b, int nlayers, int nhidden, const float* x,
                          const float* real_sigmoid_mean_dev, float inv_batch, int steps, float rate, int method,
                          float* best_x, float* best_step, float* traj, int B, void* stream);
+
+/* The 2-D net's D shaping step (synthetic/main.py:366-370): gradients of
+ *   d_loss = mean_b BCE(D(real_b), 1) + mean_b BCE(D(fake_b), 0)                     synthetic/GAN.py:69-74
+ * w.r.t. every D variable and, if lr != 0, tf.train.GradientDescentOptimizer(lr)'s step w -= lr*g IN PLACE (synthetic/GAN.py:98-99).
+ * w / b (and the optional gw / gb gradient outputs, same shapes; NULL or NULL entries = not returned) are HOST arrays of nlayers
+ * DEVICE pointers; loss (device, 2 floats, may be NULL) <- (d_loss_real, d_loss_fake) BEFORE the update.  Deterministic
+ * (fixed summation order).  ws: cgs_mlp2d_train_ws_bytes(B_real + B_fake, nlayers). */
+size_t cgs_mlp2d_train_ws_bytes(int B_total, int nlayers);
+int cgs_mlp2d_d_step(float* const* w, float* const* b, int nlayers, int nhidden, const float* real, int B_real,
+                     const float* fake, int B_fake, float lr, float* const* gw, float* const* gb, float* loss,
+                     void* ws, size_t ws_bytes, void* stream);
 
 /* ---- discriminator shaping step (the caller after the refinement path: nsgan/GAN.py:270-272, 126-146) ----------
  * Weight gradients of D's layers, the BCE seed with 0/1 targets, and the Adam update.  NOT part of the frozen-weight

@@ -18,6 +18,7 @@ Fixtures:
   g7_mh.npz            IndependenceSampler.sampling over 2 calls
   g8_toy.npz           ToyDataset.next_batch draws
   g9_metrics.npz       utils_sampling 2-D metrics (distance / good rate / KL / JS)
+  g10_shape2d.npz      one 2-D D-shaping iteration: reference refiner (probabilistic) -> D SGD step -> reference refiner
 """
 import os
 import sys
@@ -154,6 +155,44 @@ def g1_refiner_cpu():
     save("g1_refiner_cpu.npz", fake=fake, mlp_seed=np.array([2019]), mlp_scale=np.array([2.0]),
          W=np.array([w.numpy() for w in Ws], dtype=object), b=np.array([b.numpy() for b in bs], dtype=object),
          **out)
+
+
+# --------------------------------------------------------------------------- G10
+def g10_shape2d():
+    """One iteration of the 2-D D-shaping loop (synthetic/main.py:354-370, mode "shape") and the refinement that follows it:
+    the reference's refiner_cpu.Refiner (probabilistic) refines the generator batch -> one GradientDescentOptimizer step of D
+    on (real, refined) -> the reference's Refiner (deterministic) on the SHAPED D.  The refiner is the reference's class; the
+    optimizer step is TF's (not runnable here): it is restated as var -= lr*grad with torch autograd on the harness MLP
+    (oracle.mlp_d_sgd_step), canonical flags of synthetic/run_shaping.sh:2 (batch 1000, lrd 8e-3, ratio 0.9, K 50 -> 10 here)."""
+    B, K, lrd = 1000, 10, 8e-3
+    Ws, bs = S.mlp_init(64, 6, seed=2019, scale=2.0)
+    state = {"W": Ws, "b": bs}
+
+    class Gan:
+        fake_samples, fake_sigmoid, fake_saliency = "fake_samples", "fake_sigmoid", "fake_saliency"
+
+    class Sess:
+        def run(self, fetches, feed_dict):
+            sig, sal = S.mlp_sigmoid_and_saliency(state["W"], state["b"], feed_dict[Gan.fake_samples])
+            return [{"fake_sigmoid": sig, "fake_saliency": sal}[f] for f in fetches]
+
+    args = types.SimpleNamespace(rollout_steps=K, rollout_rate=0.1, rollout_method="ladam")
+    data = Datasets.ToyDataset(distr="Imbal-8Gaussians", scale=10.0, ratio=0.9)
+    ref = refiner_cpu.Refiner(args)
+    ref.set_env(Gan, Sess(), data)
+    np.random.seed(2019)
+    real_batch = data.next_batch(B)                                   # main.py:359
+    noise_sample = (3.0 * np.random.RandomState(11).randn(B, 2)).astype(np.float32)      # stands for sess.run(gan.generates)
+    refined = ref.manipulate_sample(noise_sample, "probabilistic")    # main.py:369 (float64 out)
+    W1, b1, losses = S.mlp_d_sgd_step(Ws, bs, real_batch.astype(np.float32), refined.astype(np.float32), lrd)   # main.py:370
+    state["W"], state["b"] = W1, b1
+    eval_batch = (3.0 * np.random.RandomState(12).randn(512, 2)).astype(np.float32)
+    np.random.seed(7)
+    refined_after = ref.manipulate_sample(eval_batch, "deterministic")   # main.py:217 on the shaped D
+    save("g10_shape2d.npz", real_batch=real_batch, noise_sample=noise_sample, refined=refined, lrd=np.array([lrd]), K=np.array([K]),
+         d_loss=np.array(losses), eval_batch=eval_batch, refined_after=refined_after,
+         W0=np.array([w.numpy() for w in Ws], dtype=object), b0=np.array([b.numpy() for b in bs], dtype=object),
+         W1=np.array([w.numpy() for w in W1], dtype=object), b1=np.array([b.numpy() for b in b1], dtype=object))
 
 
 # --------------------------------------------------------------------------- G2
@@ -294,7 +333,7 @@ def g9_metrics():
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    g1_refiner_cpu(); g2_policy(); g6_rejector(); g7_mh(); g8_toy(); g9_metrics()
+    g1_refiner_cpu(); g2_policy(); g6_rejector(); g7_mh(); g8_toy(); g9_metrics(); g10_shape2d()
     for K in (1, 5, 20):
         collab_case("mnist", 8, K, "deterministic", 0.1, seed=100 + K)
     collab_case("mnist", 8, 5, "probabilistic", 0.1, seed=7)

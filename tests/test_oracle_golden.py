@@ -107,3 +107,28 @@ def test_g8_toy_dataset_exact():
     for distr, ratio, B in (("Imbal-8Gaussians", 0.9, 512), ("8Gaussians", 0.5, 100), ("25Gaussians", 0.5, 60)):
         np.random.seed(2019)
         np.testing.assert_array_equal(S.toy_next_batch(distr, 10.0, ratio, B), g[distr])
+
+
+def test_g10_shape2d_iteration():
+    """The 2-D D-shaping iteration (synthetic/main.py:366-370): the oracle's refine_2d reproduces what the reference's Refiner
+    produced before and after the D step, and its restated GradientDescentOptimizer step reproduces the stored weights."""
+    g = load_golden("g10_shape2d.npz")
+    B, K, lrd = len(g["noise_sample"]), int(g["K"][0]), float(g["lrd"][0])
+    W0, b0 = [torch.from_numpy(w) for w in g["W0"]], [torch.from_numpy(b) for b in g["b0"]]
+    np.random.seed(2019)
+    real_batch = S.toy_next_batch("Imbal-8Gaussians", 10.0, 0.9, B)
+    np.testing.assert_array_equal(real_batch, g["real_batch"])
+    inner_real = S.toy_next_batch("Imbal-8Gaussians", 10.0, 0.9, B)               # refiner_cpu.py:22
+    idx = np.random.randint(K + 1, size=B)                                        # refiner_cpu.py:72
+    refined, _, _ = S.refine_2d(g["noise_sample"], inner_real, lambda x: S.mlp_sigmoid_and_saliency(W0, b0, x), K, 0.1, "ladam",
+                                "probabilistic", idx)
+    np.testing.assert_allclose(refined, g["refined"], rtol=0, atol=1e-6)
+    W1, b1, losses = S.mlp_d_sgd_step(W0, b0, real_batch.astype(np.float32), g["refined"].astype(np.float32), lrd)
+    np.testing.assert_allclose(losses, g["d_loss"], rtol=1e-6)
+    for a, b in zip(W1 + b1, list(g["W1"]) + list(g["b1"])):
+        np.testing.assert_allclose(a.numpy(), b, rtol=1e-6, atol=1e-8)
+    assert max(float((a - torch.from_numpy(b)).abs().max()) for a, b in zip(W0, g["W1"])) > 1e-5      # the step moved D
+    np.random.seed(7)
+    inner_real = S.toy_next_batch("Imbal-8Gaussians", 10.0, 0.9, len(g["eval_batch"]))
+    after, _, _ = S.refine_2d(g["eval_batch"], inner_real, lambda x: S.mlp_sigmoid_and_saliency(W1, b1, x), K, 0.1, "ladam")
+    np.testing.assert_allclose(after, g["refined_after"], rtol=0, atol=1e-6)

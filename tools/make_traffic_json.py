@@ -44,7 +44,12 @@ def main():
         f, w = sum(F[k]) / len(F[k]), sum(W.get(k, [0.0])) / max(1, len(W.get(k, [])))
         out[k] = {"launches": len(F[k]), "FETCH_SIZE_KB_avg": round(f, 1), "WRITE_SIZE_KB_avg": round(w, 1),
                   "hbm_bytes_per_launch_corrected": int(round((2 * f + w) * 1024))}
+    sys.path.insert(0, ROOT)
+    from cgs_amd.lib import source_hash
+    out["_source_sha256"] = source_hash()        # bench.py prints roofline.traffic = null once the kernel sources move on
+    out["_tag"] = tag
     json.dump(out, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
+    out.pop("_source_sha256"); out.pop("_tag")
     for rows, name in ((frows, "fetch_size"), (wrows, "write_size")):
         with open(os.path.join(ROOT, "profiles", f"{tag}_pmc_{name}.csv"), "w", newline="") as fh:
             wr = csv.DictWriter(fh, fieldnames=list(rows[0].keys()))
