@@ -152,8 +152,11 @@ __global__ __launch_bounds__(256) void convt_quad_mfma_kernel(QuadParams p) {
 // each input element leaves L2 ~1.3x instead of 9x.  The 4 image rows x 64 pixels x N channels a wave produces
 // are transposed through LDS and stored (and the aux tensor loaded) as 16-byte accesses of whole 768-byte rows.
 // ------------------------------------------------------------------------------------------------
+// Persistent: a block copies the packed weights to LDS ONCE and walks a contiguous run of tiles (image-major: the tiles of an
+// image follow each other, so their halo rows are re-read from this CU's L1 / this XCD's L2 instead of from HBM); the patch
+// pipeline runs across tile boundaries (chunk 0 of the next tile is fetched under the last chunk's MFMAs of this one).
 template <int NPAD, int TW>   // NPAD = N (<= 4); TW = tile width in quads (32 or 16), tile height 256 / TW
-__global__ __launch_bounds__(256, 2) void convt_quad_lds_kernel(QuadParams p) {
+__global__ __launch_bounds__(256, 2) void convt_quad_lds_kernel(QuadParams p, int tiles_total, int tiles_per_block) {
     constexpr int TH = 256 / TW;
     constexpr int QR = TH / 4;                              // quad rows per wave (2 or 4)
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -164,28 +167,40 @@ __global__ __launch_bounds__(256, 2) void convt_quad_lds_kernel(QuadParams p) {
     const int patch_f4 = PH * PW * 4;                      // float4 per 16-channel patch
     float* Bs = smem;                                      // [K/4][16][4]
     float* Ps = smem + (size_t)K * 16;                     // [2][PH][PW][16]
+    const int t_begin = blockIdx.x * tiles_per_block;
+    const int t_end = t_begin + tiles_per_block < tiles_total ? t_begin + tiles_per_block : tiles_total;
+    if (t_begin >= t_end) return;
     for (int q = tid; q < K * 4; q += 256) ((f32x4*)Bs)[q] = ((const f32x4*)p.wq)[q];
 
     const int tiles_x = (p.Ws + TW - 1) / TW, tiles_y = (p.Hs + TH - 1) / TH;
     const int tpi = tiles_x * tiles_y;
-    const int b = blockIdx.x / tpi, trem = blockIdx.x - b * tpi;
-    const int r0 = (trem / tiles_x) * TH, c0 = (trem - (trem / tiles_x) * tiles_x) * TW;
 
     const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void*)p.in, 0, (int)((unsigned)p.B * (unsigned)p.Hs * (unsigned)p.Ws * (unsigned)p.Cs * 4u), 0x00020000);
     constexpr int PL = 6;                                  // float4 staged per thread: ceil(10*34*4 / 256), ceil(18*18*4 / 256)
     f32x4 st[PL];
+    int l_rel[PL];                                         // this thread's patch elements: (patch row << 16 | patch col << 2 | c4), -1 = none
+#pragma unroll
+    for (int u = 0; u < PL; ++u) {
+        const int q = tid + 256 * u;
+        const int pixel = q >> 2;
+        const int pr = pixel / PW, pc = pixel - pr * PW;
+        l_rel[u] = q < patch_f4 ? (pr << 16) | (pc << 2) | (q & 3) : -1;
+    }
     const int nchunk = p.Cs >> 4;
-#define LOAD_PATCH(ch_)                                                                                   \
+#define TILE_DECODE(t_, b_, r0_, c0_)                                                                       \
+    do {                                                                                                    \
+        b_ = (t_) / tpi;                                                                                    \
+        const int trem_ = (t_) - b_ * tpi;                                                                  \
+        r0_ = (trem_ / tiles_x) * TH; c0_ = (trem_ - (trem_ / tiles_x) * tiles_x) * TW;                     \
+    } while (0)
+#define LOAD_PATCH(b_, r0_, c0_, ch_)                                                                      \
     _Pragma("unroll") for (int u = 0; u < PL; ++u) {                                                       \
-        const int q = tid + 256 * u;                                                                       \
         unsigned off = 0xFFFFFFF0u;                                                                        \
-        if (q < patch_f4) {                                                                                \
-            const int pixel = q >> 2, c4 = q & 3;                                                          \
-            const int pr = pixel / PW, pc = pixel - pr * PW;                                               \
-            const int iy = r0 + pr + p.dmin_y, ix = c0 + pc + p.dmin_x;                                    \
+        if (l_rel[u] >= 0) {                                                                               \
+            const int iy = (r0_) + (l_rel[u] >> 16) + p.dmin_y, ix = (c0_) + ((l_rel[u] >> 2) & 0x3fff) + p.dmin_x; \
             if ((unsigned)iy < (unsigned)p.Hs && (unsigned)ix < (unsigned)p.Ws)                            \
-                off = (unsigned)(((b * p.Hs + iy) * p.Ws + ix) * p.Cs + (ch_) * 16 + c4 * 4) * 4u;          \
+                off = (unsigned)((((b_) * p.Hs + iy) * p.Ws + ix) * p.Cs + (ch_) * 16 + (l_rel[u] & 3) * 4) * 4u; \
         }                                                                                                  \
         st[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, off, 0, 0));      \
     }
@@ -195,85 +210,101 @@ __global__ __launch_bounds__(256, 2) void convt_quad_lds_kernel(QuadParams p) {
         if (q < patch_f4) ((f32x4*)(Ps + (size_t)(buf_) * patch_f4 * 4))[q] = st[u];                       \
     }
 
-    f32x4 acc[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    LOAD_PATCH(0);
+    int b, r0, c0;
+    TILE_DECODE(t_begin, b, r0, c0);
+    LOAD_PATCH(b, r0, c0, 0);
     STORE_PATCH(0);
     __syncthreads();
-    for (int ch = 0; ch < nchunk; ++ch) {
-        const int buf = ch & 1;
-        if (ch + 1 < nchunk) { LOAD_PATCH(ch + 1); }
-        const float* P = Ps + (size_t)buf * patch_f4 * 4;
-        for (int a = 0; a < p.ny; ++a)
-            for (int bq = 0; bq < p.nx; ++bq) {
-                const int it = (a * p.nx + bq) * nchunk + ch;          // k-quad group index of (neighbour, chunk)
-                const f32x4 fb = *(const f32x4*)(Bs + ((size_t)(it * 4 + g) * 16 + i) * 4);
-                f32x4 fa[4];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const int pr = (TW == 32 ? 2 * wave + (t >> 1) : 4 * wave + t) + a, pc = (TW == 32 ? 16 * (t & 1) : 0) + i + bq;
-                    fa[t] = *(const f32x4*)(P + ((size_t)(pr * PW + pc) * 4 + g) * 4);
-                }
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[t].x, fb.x, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[t].y, fb.y, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[t].z, fb.z, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[t].w, fb.w, acc[t], 0, 0, 0);
-                }
-            }
-        if (ch + 1 < nchunk) { STORE_PATCH(buf ^ 1); }
-        __syncthreads();
-    }
-#undef LOAD_PATCH
-#undef STORE_PATCH
-
-    // ---- epilogue: transpose the wave's 4 image rows x (64 px x N) through LDS, then 16-byte row accesses ----
     constexpr int N = NPAD;
     const int rowf = 2 * TW * N;                           // floats per output image row of the tile
-    float* E = Ps + (size_t)wave * 2 * QR * rowf;          // [2*QR image rows][2*TW*N]   (patch buffers are dead: barrier above)
     const int cls = i / N, n = i - cls * N;
-    if (cls < 4) {
-        const int py = cls >> 1, px = cls & 1;
-        const float bias = p.bias ? p.bias[n] : 0.f;
+    const float bias = (cls < 4 && p.bias) ? p.bias[n] : 0.f;
+    int buf = 0;
+    for (int t = t_begin; t < t_end; ++t) {
+        int nb = b, nr0 = r0, nc0 = c0;
+        const bool more = t + 1 < t_end;
+        if (more) TILE_DECODE(t + 1, nb, nr0, nc0);
+        f32x4 acc[4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int c = (TW == 32 ? 16 * (t & 1) : 0) + g * 4 + r;    // quad column inside the tile
-                E[(2 * (TW == 32 ? (t >> 1) : t) + py) * rowf + (2 * c + px) * N + n] = acc[t][r] + bias;
+        for (int tt = 0; tt < 4; ++tt) acc[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int ch = 0; ch < nchunk; ++ch) {
+            const bool last = ch + 1 == nchunk;
+            const bool fetch = !last || more;                               // next chunk of this tile, or chunk 0 of the next tile
+            if (fetch) {
+                if (!last) { LOAD_PATCH(b, r0, c0, ch + 1); }
+                else { LOAD_PATCH(nb, nr0, nc0, 0); }
             }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const int f4_per_row = rowf / 4;                       // 48 for N = 3, TW = 32
-    const int live_f = 2 * (p.Ws - c0 < TW ? p.Ws - c0 : TW) * N;      // floats of a tile row that lie inside the image
-    for (int q = lane; q < 2 * QR * f4_per_row; q += 64) {
-        const int yr = q / f4_per_row, xq = q - yr * f4_per_row;
-        const int y = 2 * (r0 + QR * wave) + yr;
-        if (y >= 2 * p.Hs || xq * 4 >= live_f) continue;
-        const size_t o = ((size_t)(b * 2 * p.Hs + y) * (2 * p.Ws) + 2 * c0) * N + xq * 4;
-        f32x4 v = *(const f32x4*)(E + yr * rowf + xq * 4);
-        if (p.epilogue == CGS_EPI_TANH) {
+            const float* P = Ps + (size_t)buf * patch_f4 * 4;
+            for (int a = 0; a < p.ny; ++a)
+                for (int bq = 0; bq < p.nx; ++bq) {
+                    const int it = (a * p.nx + bq) * nchunk + ch;          // k-quad group index of (neighbour, chunk)
+                    const f32x4 fb = *(const f32x4*)(Bs + ((size_t)(it * 4 + g) * 16 + i) * 4);
+                    f32x4 fa[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
-        } else if (p.epilogue == CGS_EPI_LRELU) {
+                    for (int tt = 0; tt < 4; ++tt) {
+                        const int pr = (TW == 32 ? 2 * wave + (tt >> 1) : 4 * wave + tt) + a, pc = (TW == 32 ? 16 * (tt & 1) : 0) + i + bq;
+                        fa[tt] = *(const f32x4*)(P + ((size_t)(pr * PW + pc) * 4 + g) * 4);
+                    }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.2f * v[e]);
-        } else if (p.epilogue >= CGS_EPI_RELU_BWD_AFFINE) {
-            const f32x4 y4 = *(const f32x4*)(p.ep_aux + o);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                if (p.epilogue == CGS_EPI_TANH_BWD) v[e] *= (1.f - y4[e] * y4[e]);
-                else if (p.epilogue == CGS_EPI_LRELU_BWD) v[e] = y4[e] > 0.f ? v[e] : 0.2f * v[e];
-                else v[e] = y4[e] > 0.f ? v[e] * p.ep_a[(xq * 4 + e) % N] : 0.f;
-            }
+                    for (int tt = 0; tt < 4; ++tt) {
+                        acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[tt].x, fb.x, acc[tt], 0, 0, 0);
+                        acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[tt].y, fb.y, acc[tt], 0, 0, 0);
+                        acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[tt].z, fb.z, acc[tt], 0, 0, 0);
+                        acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[tt].w, fb.w, acc[tt], 0, 0, 0);
+                    }
+                }
+            if (fetch) { STORE_PATCH(buf ^ 1); }
+            __syncthreads();
+            buf ^= 1;
         }
-        *(f32x4*)(p.out + o) = v;
+        // ---- epilogue: transpose the wave's image rows x (2 TW px x N) through LDS, then 16-byte row accesses.  The staging
+        // area is the patch buffer the last chunk was read from (buf ^ 1 now: free since the barrier above; the other buffer
+        // already holds chunk 0 of the next tile) ----
+        float* E = Ps + (size_t)(buf ^ 1) * patch_f4 * 4 + (size_t)wave * 2 * QR * rowf;      // [2*QR image rows][2*TW*N]
+        if (cls < 4) {
+            const int py = cls >> 1, px = cls & 1;
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int c = (TW == 32 ? 16 * (tt & 1) : 0) + g * 4 + r;    // quad column inside the tile
+                    E[(2 * (TW == 32 ? (tt >> 1) : tt) + py) * rowf + (2 * c + px) * N + n] = acc[tt][r] + bias;
+                }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int f4_per_row = rowf / 4;                       // 48 for N = 3, TW = 32
+        const int live_f = 2 * (p.Ws - c0 < TW ? p.Ws - c0 : TW) * N;      // floats of a tile row that lie inside the image
+        for (int q = lane; q < 2 * QR * f4_per_row; q += 64) {
+            const int yr = q / f4_per_row, xq = q - yr * f4_per_row;
+            const int y = 2 * (r0 + QR * wave) + yr;
+            if (y >= 2 * p.Hs || xq * 4 >= live_f) continue;
+            const size_t o = ((size_t)(b * 2 * p.Hs + y) * (2 * p.Ws) + 2 * c0) * N + xq * 4;
+            f32x4 v = *(const f32x4*)(E + yr * rowf + xq * 4);
+            if (p.epilogue == CGS_EPI_TANH) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
+            } else if (p.epilogue == CGS_EPI_LRELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.2f * v[e]);
+            } else if (p.epilogue >= CGS_EPI_RELU_BWD_AFFINE) {
+                const f32x4 y4 = *(const f32x4*)(p.ep_aux + o);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (p.epilogue == CGS_EPI_TANH_BWD) v[e] *= (1.f - y4[e] * y4[e]);
+                    else if (p.epilogue == CGS_EPI_LRELU_BWD) v[e] = y4[e] > 0.f ? v[e] : 0.2f * v[e];
+                    else v[e] = y4[e] > 0.f ? v[e] * p.ep_a[(xq * 4 + e) % N] : 0.f;
+                }
+            }
+            *(f32x4*)(p.out + o) = v;
+        }
+        if (more) __syncthreads();          // every wave is done with its staging rows before the next tile's chunk 1 lands there
+        b = nb; r0 = nr0; c0 = nc0;
     }
+#undef TILE_DECODE
+#undef LOAD_PATCH
+#undef STORE_PATCH
 }
 
 static void quad_range(int k, int pad, int& lo, int& hi) {
@@ -330,7 +361,12 @@ int cgs_convt_quad_launch(const CgsLayer& L, int B, const float* in, const float
         const int TWr = wide ? 32 : 16, THr = 256 / TWr;
         const int PH = THr + p.ny - 1, PW = TWr + p.nx - 1;
         const size_t smem = need + (size_t)2 * PH * PW * 16 * sizeof(float);
-        const long blocks = (long)B * cgs_ceil_div(L.Hs, THr) * cgs_ceil_div(L.Ws, TWr);
+        const long tiles = (long)B * cgs_ceil_div(L.Hs, THr) * cgs_ceil_div(L.Ws, TWr);
+        // persistent blocks: two per CU, each a contiguous run of tiles (the 37 KB weight image is copied to LDS once per block);
+        // small launches keep one tile per block
+        long per = (tiles + 511) / 512;
+        if (per < 4) per = tiles >= 4 * 256 ? 4 : 1;
+        const long blocks = (tiles + per - 1) / per;
 #define QUAD_LDS_LAUNCH(NN, TT)                                                                                    \
     {                                                                                                              \
         static bool done_ = false;                                                                                 \
@@ -339,7 +375,7 @@ int cgs_convt_quad_launch(const CgsLayer& L, int B, const float* in, const float
             if (e != hipSuccess) return cgs_set_error(CGS_ELAUNCH, "convt_quad_lds smem attr: %s", hipGetErrorString(e)); \
             done_ = true;                                                                                          \
         }                                                                                                          \
-        hipLaunchKernelGGL((convt_quad_lds_kernel<NN, TT>), dim3((unsigned)blocks), dim3(256), smem, s, p);        \
+        hipLaunchKernelGGL((convt_quad_lds_kernel<NN, TT>), dim3((unsigned)blocks), dim3(256), smem, s, p, (int)tiles, (int)per); \
     }
 #define QUAD_LDS_CASE(NN)                                                                                          \
     case NN:                                                                                                       \

@@ -369,11 +369,103 @@ __global__ __launch_bounds__(64 * NW, 2) void igemm_kernel(IgemmParams p) {
     unsigned long long sr_loop0 = 0;
     if (stamp) sr_loop0 = __builtin_amdgcn_s_memrealtime();
 #endif
-    int kt = next_chunk(kbeg);
-    // (a one-off half-tile start delay for every other block -- three pairing guesses -- changed nothing: +-0.4 %)
-    if (kt < nk) {
-        LOAD_TILE(kt);
-        STORE_TILE(0);
+    // ------------------------------------------------------------------------------------------------------------------
+    // K loop.  Per-tile vector-ALU work is kept to a minimum: VALU instructions and MFMAs of a SIMD share its vector issue, and
+    // every VALU op in the loop costs matrix time even from another wave (tools/probe/mfma_probe.hip: 32 MFMAs + 8 ds_read_b128
+    // per wave and K tile run at 151 TFLOP/s; 16 v_mul_lo_u32 more per tile and wave 140; 128 plain VALU ops 130).  So for the
+    // VEC kernels the position in K is a wave-uniform ITERATOR (chunk, tap row, tap column, half) advanced with scalar counters
+    // instead of being re-derived from the tile index by divisions, and a tile's addresses are
+    //   A row i :  rowoff[i] (VGPR, loop invariant)  +  soff (SGPR: tap offset + channel offset)      -> 1 v_add + bounds select
+    //   B       :  b_voff[i] (VGPR, loop invariant)  +  kt * tile bytes as the buffer load's SCALAR offset -> no VALU at all
+    // (33 VALU ops per tile incl. 4 v_mul_lo_u32, 2 v_mad_i64_i32 and 120 SALU ops before; 1-round layers +4..6 %).
+    // ------------------------------------------------------------------------------------------------------------------
+    struct KIt { int kt, sub, ia, ib, chunk; };          // K tile index and its decode (VEC): 32-channel chunk, tap (ia, ib) in visiting order, 16-deep half
+    auto kit_valid = [&](const KIt& s) -> bool {         // is the tap inside the image for this (one-pixel) tile?
+        if (!skip_ok) return true;
+        const int ta = cgs_tap_order(s.ia, c.nty, PAR), tb = cgs_tap_order(s.ib, c.ntx, PAR);
+        const int iy = u_iy + ta * p.dstep, ix = u_ix + tb * p.dstep;
+        return (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
+    };
+    auto kit_next_tap = [&](KIt& s) {                    // s sits on a tap start: move to the next executed tap start (kt = nk when none)
+        for (;;) {
+            if (++s.ib == c.ntx) { s.ib = 0; if (++s.ia == c.nty) { s.ia = 0; ++s.chunk; } }
+            if (s.kt >= nk || kit_valid(s)) break;
+            s.kt += (TBK == 16 ? 2 : 1);
+        }
+        if (s.kt > nk) s.kt = nk;
+    };
+    auto kit_first = [&](int kt0) -> KIt {               // first executed tile >= kt0 (the only place that divides)
+        KIt s;
+        const int kt32 = (VEC && TBK == 16) ? kt0 >> 1 : kt0;
+        s.kt = kt0; s.sub = (VEC && TBK == 16) ? (kt0 & 1) : 0;
+        s.chunk = kt32 / ntaps;
+        const int t = kt32 - s.chunk * ntaps;
+        s.ia = t / c.ntx; s.ib = t - s.ia * c.ntx;
+        if (s.kt < nk && !kit_valid(s)) {
+            s.kt += (TBK == 16 ? 2 - s.sub : 1); s.sub = 0;
+            kit_next_tap(s);
+        }
+        if (s.kt > nk) s.kt = nk;
+        return s;
+    };
+    auto kit_next = [&](KIt s) -> KIt {                  // the tile executed after s
+        if (TBK == 16 && s.sub == 0) { s.sub = 1; ++s.kt; if (s.kt > nk) s.kt = nk; return s; }
+        s.sub = 0; ++s.kt;
+        kit_next_tap(s);
+        return s;
+    };
+    // loop-invariant per-thread address parts (VEC)
+    unsigned rowoff[AI], b_voff[BI];
+#pragma unroll
+    for (int i = 0; i < AI; ++i)
+        rowoff[i] = ((unsigned)(a_base[i] + a_iy[i] * p.Win + a_ix[i]) * (unsigned)p.Cred + (unsigned)aq * 4u) * 4u;
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+        const int idx = tid + NT * i;
+        const int kq = idx / BN, n = idx - kq * BN;
+        b_voff[i] = (unsigned)(kq * p.Np + n0 + n) * 16u;
+    }
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)wsrc, 0, 0x7ffffff0, 0x00020000);
+    const int b_tile_bytes = (BK / 4) * p.Np * 16;
+    unsigned a_off[AI];
+    // VGPR byte offsets of tile s_'s A rows (out-of-range rows -> past num_records: the hardware bounds check returns zeros)
+#define ADDR_TILE_V(s_)                                                                                         \
+    do {                                                                                                        \
+        const int ta_ = cgs_tap_order((s_).ia, c.nty, PAR), tb_ = cgs_tap_order((s_).ib, c.ntx, PAR);           \
+        const int dy_ = ta_ * p.dstep, dx_ = tb_ * p.dstep;                                                     \
+        const unsigned soff_ = (unsigned)(((dy_ * p.Win + dx_) * p.Cred + (s_).chunk * 32 + (TBK == 16 ? (s_).sub * 16 : 0)) * 4); \
+        _Pragma("unroll") for (int i = 0; i < AI; ++i) {                                                        \
+            const bool ok = (unsigned)(a_iy[i] + dy_) < (unsigned)p.Hin && (unsigned)(a_ix[i] + dx_) < (unsigned)p.Win; \
+            a_off[i] = ok ? rowoff[i] + soff_ : 0xFFFFFFF0u;                                                    \
+        }                                                                                                       \
+    } while (0)
+#define ISSUE_TILE_V(s_)                                                                                        \
+    do {                                                                                                        \
+        _Pragma("unroll") for (int i = 0; i < AI; ++i)                                                          \
+            ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, a_off[i], 0, 0));  \
+        const int b_soff_ = (s_).kt * b_tile_bytes;                                                             \
+        _Pragma("unroll") for (int i = 0; i < BI; ++i)                                                          \
+            rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, b_voff[i], b_soff_, 0)); \
+    } while (0)
+
+    // prologue: first tile -> LDS buffer 0
+    KIt cur;
+    int kt;                                            // (generic-K path: plain tile index)
+    if constexpr (VEC) {
+        cur = kit_first(kbeg);
+        kt = cur.kt;
+        if (cur.kt < nk) {
+            ADDR_TILE_V(cur);
+            ISSUE_TILE_V(cur);
+            STORE_TILE(0);
+        }
+    } else {
+        kt = next_chunk(kbeg);
+        cur.kt = kt;
+        if (kt < nk) {
+            LOAD_TILE(kt);
+            STORE_TILE(0);
+        }
     }
     __syncthreads();
 
@@ -397,20 +489,145 @@ __global__ __launch_bounds__(64 * NW, 2) void igemm_kernel(IgemmParams p) {
             }                                                                                                   \
     } while (0)
     constexpr int NG = BK / 8;                       // MFMA groups per tile
-    for (int buf = 0; kt < nk; buf ^= 1) {
-        const int kn = next_chunk(kt + 1);
-        const int kl = kn < nk ? kn : kt;            // tile to prefetch (the current one again after the last)
-        const float* a = As + buf * BM * LDA + (wm * (BM / 2) + j) * LDA;
-        const float* b = Bs + buf * BK * BN + (wn * (BN / WN) + j) * 4;
-        MFMA_GROUP(0);
-        LOAD_TILE(kl);
-#pragma unroll
-        for (int jj = 1; jj < NG - 1; ++jj) MFMA_GROUP(jj);
-        STORE_TILE(buf ^ 1);
-        if (NG > 1) MFMA_GROUP(NG - 1);
-        __syncthreads();
-        kt = kn;
+#ifdef CGS_DIAG_STAMPS
+    int diag_tiles = 0;
+#endif
+    // Fair progress among the blocks of a CU: the hardware arbitrates MFMA issue by priority, then AGE, so of the (equally old
+    // or not) resident blocks the oldest runs ahead and finishes first, and the launch ends with one block per CU that
+    // has most of its work left and nobody to hide its latencies.  Every block therefore starts at priority 3 and steps down as
+    // it passes fixed fractions of its own K loop: leaders wait for the laggards at each step and all finish together.
+    int pt1 = 1 << 30, pt2 = 1 << 30, pt3 = 1 << 30;
+    if (p.prio_t[0] > 0) {
+        const int span = nk - kbeg;
+        pt1 = kbeg + ((span * p.prio_t[0]) >> 8); pt2 = kbeg + ((span * p.prio_t[1]) >> 8); pt3 = kbeg + ((span * p.prio_t[2]) >> 8);
+        __builtin_amdgcn_s_setprio(3);
     }
+#define PRIO_STEP(kt_)                                                                                          \
+    if ((kt_) >= pt1) {        /* (scalar compares; one s_setprio when a threshold is crossed) */               \
+        if ((kt_) >= pt3) { __builtin_amdgcn_s_setprio(0); pt1 = 1 << 30; }                                     \
+        else if ((kt_) >= pt2) { __builtin_amdgcn_s_setprio(1); pt1 = pt3; }                                    \
+        else { __builtin_amdgcn_s_setprio(2); pt1 = pt2; }                                                      \
+    }
+
+    // Software-pipelined across the barrier (the 32-deep VEC kernels: two blocks per CU, i.e. two waves per SIMD, which cannot
+    // cover each other's LDS / global latencies the way the four of the 16-deep variant do; measured: 8x8 256<-512 backward-data
+    // 717 -> 642 us.  On the 16-deep kernels the second fragment set costs the fourth resident block: -6 %, not used there):
+    // the fragments of MFMA group g+1 are read from LDS BEFORE the MFMAs of group g are issued; the LAST group of a tile is
+    // issued AFTER the barrier, behind the first fragment read of the next tile; the next tile's global loads go out at the top
+    // of the iteration (their addresses were computed under the previous tile's last MFMA group) and are staged to LDS just
+    // before the barrier.  sched_barrier pins the phase order: left alone, the compiler sinks the loads to their first use and
+    // re-uses the fragment registers, which serialises everything again.
+#define FRAG_READ(buf_, jj_, fa_, fb_)                                                                          \
+    do {                                                                                                        \
+        const float* a_ = As + (buf_) * BM * LDA + (wm * (BM / 2) + j) * LDA;                                   \
+        const float* b_ = Bs + (buf_) * BK * BN + (wn * (BN / WN) + j) * 4;                                     \
+        const int kq = 2 * (jj_) + h;                                                                           \
+        _Pragma("unroll") for (int tm = 0; tm < TM; ++tm) fa_[tm] = *(const f32x4*)(a_ + tm * 32 * LDA + kq * 4); \
+        _Pragma("unroll") for (int tn = 0; tn < TN; ++tn) fb_[tn] = *(const f32x4*)(b_ + (kq * BN + tn * 32) * 4); \
+    } while (0)
+#define MFMA_EXEC(fa_, fb_)                                                                                     \
+    do {                                                                                                        \
+        _Pragma("unroll") for (int tm = 0; tm < TM; ++tm)                                                       \
+            _Pragma("unroll") for (int tn = 0; tn < TN; ++tn) {                                                 \
+                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa_[tm].x, fb_[tn].x, acc[tm][tn], 0, 0, 0); \
+                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa_[tm].y, fb_[tn].y, acc[tm][tn], 0, 0, 0); \
+                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa_[tm].z, fb_[tn].z, acc[tm][tn], 0, 0, 0); \
+                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa_[tm].w, fb_[tn].w, acc[tm][tn], 0, 0, 0); \
+            }                                                                                                   \
+    } while (0)
+    if constexpr (VEC && TBK == 32) {
+        f32x4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
+        // (field-wise selects: a ternary over the whole struct sends it through scratch memory)
+#define KIT_SEL(d_, c_, a_, b_)                                                                                 \
+    do {                                                                                                        \
+        const bool c__ = (c_);                                                                                  \
+        d_.kt = c__ ? a_.kt : b_.kt; d_.sub = c__ ? a_.sub : b_.sub; d_.ia = c__ ? a_.ia : b_.ia;               \
+        d_.ib = c__ ? a_.ib : b_.ib; d_.chunk = c__ ? a_.chunk : b_.chunk;                                      \
+    } while (0)
+        KIt nxt = cur, ld = cur;
+        if (cur.kt < nk) nxt = kit_next(cur);
+        KIT_SEL(ld, nxt.kt < nk, nxt, cur);          // tile to prefetch (the current one again after the last)
+        if (cur.kt < nk) {
+            FRAG_READ(0, 0, fa0, fb0);
+            ADDR_TILE_V(ld);
+        }
+        for (int buf = 0; cur.kt < nk; buf ^= 1) {
+#ifdef CGS_DIAG_STAMPS
+            ++diag_tiles;
+#endif
+            ISSUE_TILE_V(ld);
+#pragma unroll
+            for (int jj = 0; jj + 1 < NG; jj += 2) {     // NG is even: fragments ping-pong between two register sets
+                FRAG_READ(buf, jj + 1, fa1, fb1);
+                __builtin_amdgcn_sched_barrier(0);
+                MFMA_EXEC(fa0, fb0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (jj + 2 < NG) {
+                    FRAG_READ(buf, jj + 2, fa0, fb0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    MFMA_EXEC(fa1, fb1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            STORE_TILE(buf ^ 1);
+            __syncthreads();
+            FRAG_READ(buf ^ 1, 0, fa0, fb0);         // first fragments of the next tile (a harmless re-read after the last one)
+            __builtin_amdgcn_sched_barrier(0);
+            // last MFMA group of this tile + the address arithmetic of the tile after next
+            cur = nxt;
+            if (cur.kt < nk) {
+                nxt = kit_next(cur);
+                KIT_SEL(ld, nxt.kt < nk, nxt, cur);
+            }
+            ADDR_TILE_V(ld);
+            MFMA_EXEC(fa1, fb1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else if constexpr (VEC) {
+        for (int buf = 0; cur.kt < nk; buf ^= 1) {
+#ifdef CGS_DIAG_STAMPS
+            ++diag_tiles;
+#endif
+            PRIO_STEP(cur.kt);
+            const KIt nxt = kit_next(cur);
+            const KIt ld = nxt.kt < nk ? nxt : cur;      // tile to prefetch (the current one again after the last)
+            const float* a = As + buf * BM * LDA + (wm * (BM / 2) + j) * LDA;
+            const float* b = Bs + buf * BK * BN + (wn * (BN / WN) + j) * 4;
+            MFMA_GROUP(0);
+            ADDR_TILE_V(ld);
+            ISSUE_TILE_V(ld);
+#pragma unroll
+            for (int jj = 1; jj < NG - 1; ++jj) MFMA_GROUP(jj);
+            STORE_TILE(buf ^ 1);
+            if (NG > 1) MFMA_GROUP(NG - 1);
+            __syncthreads();
+            cur = nxt;
+        }
+    } else {
+        for (int buf = 0; kt < nk; buf ^= 1) {
+#ifdef CGS_DIAG_STAMPS
+            ++diag_tiles;
+#endif
+            const int kn = next_chunk(kt + 1);
+            const int kl = kn < nk ? kn : kt;            // tile to prefetch (the current one again after the last)
+            const float* a = As + buf * BM * LDA + (wm * (BM / 2) + j) * LDA;
+            const float* b = Bs + buf * BK * BN + (wn * (BN / WN) + j) * 4;
+            MFMA_GROUP(0);
+            LOAD_TILE(kl);
+#pragma unroll
+            for (int jj = 1; jj < NG - 1; ++jj) MFMA_GROUP(jj);
+            STORE_TILE(buf ^ 1);
+            if (NG > 1) MFMA_GROUP(NG - 1);
+            __syncthreads();
+            kt = kn;
+        }
+    }
+#undef KIT_SEL
+#undef FRAG_READ
+#undef MFMA_EXEC
+#undef ADDR_TILE_V
+#undef ISSUE_TILE_V
+#undef PRIO_STEP
 #undef MFMA_GROUP
 
 #ifdef CGS_DIAG_STAMPS
@@ -420,6 +637,7 @@ __global__ __launch_bounds__(64 * NW, 2) void igemm_kernel(IgemmParams p) {
 #undef LOAD_TILE
 #undef STORE_TILE
 #undef DECODE_ROW
+    if (p.prio_t[0] > 0) __builtin_amdgcn_s_setprio(3);      // retire quickly: the slot is what the next block (or kernel) is waiting for
     // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
     if (p.splitk > 1) {      // raw partial tile -> slab[class][split][m][Np]; bias / epilogue happen in the reduce kernel
         float* slab = p.slab + c.slab_off + (size_t)blockIdx.z * M * p.Np;
@@ -489,8 +707,12 @@ __global__ __launch_bounds__(64 * NW, 2) void igemm_kernel(IgemmParams p) {
         }
 #ifdef CGS_DIAG_STAMPS
         if (stamp) {
-            unsigned long long* dbg = (unsigned long long*)p.slab + (size_t)blockIdx.x * 4;
+            unsigned long long* dbg = (unsigned long long*)p.slab + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8;
             dbg[0] = sr_in; dbg[1] = sr_loop0; dbg[2] = sr_loop1; dbg[3] = __builtin_amdgcn_s_memrealtime();
+            dbg[4] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |                 // HW_ID: wave / simd / cu / sh / se
+                     ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);        // XCC_ID
+            dbg[5] = (unsigned long long)diag_tiles;
+            dbg[6] = (unsigned long long)mb | ((unsigned long long)nb << 32);
         }
 #endif
         return;
@@ -637,6 +859,7 @@ static int launch_cfg(const IgemmParams& p, hipStream_t s) {
 int cgs_igemm_launch(const IgemmParams& p_in, void* slab, size_t slab_bytes, hipStream_t s) {
     IgemmParams p = p_in;
     p.splitk = 1; p.slab = nullptr;
+    p.prio_t[0] = p.prio_t[1] = p.prio_t[2] = 0;
 #ifdef CGS_DIAG_STAMPS
     if (getenv("CGS_STAMP") && slab && slab_bytes >= 64) p.slab = (float*)slab;
 #endif
@@ -723,6 +946,54 @@ int cgs_igemm_launch(const IgemmParams& p_in, void* slab, size_t slab_bytes, hip
         }
         deep = min_blocks < 512;        // (thresholds 256 / 512 / 1024 measured: 512 is best on dcgan64 and neutral elsewhere)
     }
+    {
+        // Launches whose blocks are all resident at once (one "round": <= 4 blocks per CU with the 16-deep tiles, 2 with the
+        // 32-deep ones) end when their slowest CU ends.  Two things even that out (measured per layer with in-kernel stamps,
+        // tools/clock_probe.py: CU finish times 633-761 us before, span 761 -> 700 us for the 16x16 128->256 layer):
+        //  (a) fair progress of the blocks sharing a CU (priority steps, see the kernel);
+        //  (b) the pixel-major tiles have 9..25 valid taps each and the dispatcher hands workgroups to the 32 CUs of an XCD
+        //      round-robin, so the heaviest-first order alone gives the first CUs several 25-tap tiles; instead the tiles are
+        //      dealt to the CUs by greedy bin packing (heaviest tile to the least loaded CU with a free slot).
+        const int bn_sel = wide ? 128 : 64, per_cu = (vec && !deep) ? 4 : 2;
+        const long total_blocks = igemm_blocks(p, bn_sel);
+        const bool one_round = vec && p.splitk == 1 && total_blocks <= 256L * per_cu && total_blocks >= 256;
+        // (a) measured per layer at batch 1024: +2..4 % on every pixel-major layer (one or two rounds of 128x128 / 128x64 blocks),
+        // -3 % on the transposed 128x64 layers with their 8192 short blocks (a fresh block at priority 3 starves the ones about
+        // to finish), neutral elsewhere -> pixel-major launches only
+        if (vec && !deep && p.splitk == 1 && p.pix_major && total_blocks >= 256) { p.prio_t[0] = 64; p.prio_t[1] = 128; p.prio_t[2] = 192; }
+        const int nblk_n = p.Np / bn_sel;
+        if (one_round && p.lpt && p.nclasses == 1 && p.B / 128 == 8 && (32 % nblk_n) == 0) {
+            const IgemmClass& c = p.cls[0];
+            const int RC = c.R * c.C, nbins = 32 / nblk_n, cap = (RC + nbins - 1) / nbins;
+            int cnt[64], load[32] = {}, used[32] = {};
+            unsigned char bin_items[32][64];
+            for (int pix = 0; pix < RC; ++pix) {
+                const int r = pix / c.C, cc = pix - r * c.C;
+                int ny = 0, nx = 0;
+                for (int ta = 0; ta < c.nty; ++ta) { const int iy = r * p.S + c.dy0 + ta * p.dstep; ny += (iy >= 0 && iy < p.Hin); }
+                for (int tb = 0; tb < c.ntx; ++tb) { const int ix = cc * p.S + c.dx0 + tb * p.dstep; nx += (ix >= 0 && ix < p.Win); }
+                cnt[pix] = ny * nx;
+            }
+            for (int i = 0; i < RC; ++i) {                       // p.perm[0] is sorted by descending tap count
+                const int pix = p.perm[0][i];
+                int best = -1;
+                for (int b = 0; b < nbins; ++b) {
+                    const int slots = (RC - b + nbins - 1) / nbins;       // positions b, b + nbins, ... < RC
+                    if (used[b] < slots && used[b] < cap && (best < 0 || load[b] < load[best])) best = b;
+                }
+                bin_items[best][used[best]++] = (unsigned char)pix;
+                load[best] += cnt[pix];
+            }
+            for (int b = 0; b < nbins; ++b)
+                for (int k = 0; k < used[b]; ++k) p.perm[0][b + k * nbins] = bin_items[b][k];
+        }
+    }
+#ifdef CGS_EXPERIMENT
+    if (getenv("CGS_PRIO")) sscanf(getenv("CGS_PRIO"), "%d,%d,%d", &p.prio_t[0], &p.prio_t[1], &p.prio_t[2]);
+    if (getenv("CGS_NOBALANCE")) { /* diagnostic: handled by CGS_PRIO=0,0,0 for (a); (b) has no switch */ }
+    if (getenv("CGS_FORCE_DEEP")) deep = atoi(getenv("CGS_FORCE_DEEP")) != 0;
+    if (getenv("CGS_FORCE_NARROW")) wide = false;
+#endif
     if (vec && !deep && !p.tap_parity) return wide ? launch_cfg<128, 128, 4, true, 16>(p, s) : launch_cfg<128, 64, 4, true, 16>(p, s);
     if (vec && !deep && p.tap_parity) return wide ? launch_cfg<128, 128, 4, true, 16, true>(p, s) : launch_cfg<128, 64, 4, true, 16, true>(p, s);
     if (vec && p.tap_parity) return wide ? launch_cfg<128, 128, 4, true, 32, true>(p, s) : launch_cfg<128, 64, 4, true, 32, true>(p, s);

@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcgs_hip.so")
+LIB_PATH = os.environ.get("CGS_LIB") or os.path.join(_HERE, "libcgs_hip.so")      # CGS_LIB: an experimental build (development aid)
 
 OK, EINVAL, EWORKSPACE, ELAUNCH = 0, -1, -2, -3
 EPI_NONE, EPI_LRELU, EPI_AFFINE_RELU, EPI_TANH = 0, 1, 2, 3

@@ -116,7 +116,7 @@ def test_mlp_d_step_gradients_and_sgd_vs_autograd():
     rs = np.random.RandomState(5)
     for nl, nh, Br, Bf in ((6, 64, 1000, 1000), (3, 33, 77, 130), (2, 64, 5, 3)):
         Ws, bs = S.mlp_init(nh, nl, seed=3, scale=2.0)
-        real = S.toy_next_batch("Imbal-8Gaussians", 10.0, 0.9, max(Br, 16), rs)[:Br].astype(np.float32)
+        real = S.toy_next_batch("Imbal-8Gaussians", 10.0, 0.9, max(Br, 64), rs)[:Br].astype(np.float32)
         fake = (3.0 * rs.randn(Bf, 2)).astype(np.float32)
         D = MLPDiscriminator.from_lists([w.numpy() for w in Ws], [b.numpy() for b in bs], "cuda:0")
         sh = DShaper(D, lrd=8e-3)

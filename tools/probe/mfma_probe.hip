@@ -1,0 +1,175 @@
+// Micro-benchmark: what keeps an fp32-MFMA K loop shaped like igemm_kernel's (128x128x16 tile, 4 waves, one barrier per K tile,
+// 8 ds_read_b128 + 4 ds_write_b128 + 4 global b128 loads per 32 MFMAs and wave) from the 157 TFLOP/s matrix peak?
+// Variants add one ingredient at a time.   hipcc -O3 --offload-arch=gfx950 mfma_probe.hip -o mfma_probe ; ./mfma_probe
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int MODE, int LDSKB>
+__global__ __launch_bounds__(256, 2) void probe(const float* __restrict__ g, float* __restrict__ out, int iters) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    f32x16 acc[4];
+    for (int t = 0; t < 4; ++t) for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    for (int i = tid; i < 2 * 128 * 20 + 2 * 16 * 128; i += 256) smem[i] = (float)(i & 15) * 0.001f;
+    __syncthreads();
+    const float* a0 = smem + ((wave >> 1) * 64 + (lane & 31)) * 20;
+    const float* b0 = smem + 2 * 128 * 20 + ((wave & 1) * 64 + (lane & 31)) * 4;
+    const f32x4* gp = (const f32x4*)g + (size_t)blockIdx.x * 1024 + tid;
+    f32x4 ra[2], rb[2];
+    f32x4 fa[2], fb[2];
+    fa[0] = fa[1] = fb[0] = fb[1] = f32x4{1.f, 0.5f, 0.25f, 0.125f};
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)g, 0, 0x7ffffff0, 0x00020000);
+    unsigned dummy = threadIdx.x;
+    f32x4 ra2[2], rb2[2];
+    ra[0] = ra[1] = rb[0] = rb[1] = ra2[0] = ra2[1] = rb2[0] = rb2[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#define GLOAD(ra_, rb_, it_)                                                                  \
+    do {                                                                                      \
+        ra_[0] = gp[(size_t)((it_) & 63) * 256]; ra_[1] = gp[(size_t)((it_) & 63) * 256 + 16384];          \
+        rb_[0] = gp[(size_t)((it_) & 31) * 256 + 32768]; rb_[1] = gp[(size_t)((it_) & 31) * 256 + 49152];  \
+    } while (0)
+#define LSTORE(ra_, rb_, buf_)                                                                \
+    do {                                                                                      \
+        float* wa = smem + (buf_) * 128 * 20 + (tid >> 2) * 20 + (tid & 3) * 4;               \
+        *(f32x4*)wa = ra_[0]; *(f32x4*)(wa + 64 * 20) = ra_[1];                               \
+        float* wb = smem + 2 * 128 * 20 + (buf_) * 16 * 128 + tid * 4;                        \
+        *(f32x4*)wb = rb_[0]; *(f32x4*)(wb + 1024) = rb_[1];                                  \
+    } while (0)
+#define FREAD(buf_, grp_)                                                                     \
+    do {                                                                                      \
+        const int kq = 2 * (grp_) + (lane >> 5);                                              \
+        fa[0] = *(const f32x4*)(a0 + (buf_) * 128 * 20 + kq * 4);                             \
+        fa[1] = *(const f32x4*)(a0 + (buf_) * 128 * 20 + 32 * 20 + kq * 4);                   \
+        fb[0] = *(const f32x4*)(b0 + (buf_) * 16 * 128 + kq * 128 * 4);                       \
+        fb[1] = *(const f32x4*)(b0 + (buf_) * 16 * 128 + kq * 128 * 4 + 32 * 4);              \
+    } while (0)
+#define MFMA16()                                                                              \
+    _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                           \
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[0][e], fb[0][e], acc[0], 0, 0, 0);   \
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[0][e], fb[1][e], acc[1], 0, 0, 0);   \
+        acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[1][e], fb[0][e], acc[2], 0, 0, 0);   \
+        acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[1][e], fb[1][e], acc[3], 0, 0, 0);   \
+    }
+#define SB() __builtin_amdgcn_sched_barrier(0)
+    for (int it = 0; it < iters; ++it) {
+        const int buf = it & 1;
+        if (MODE <= 3) {
+            if (MODE >= 2) FREAD(buf, 0);
+            MFMA16();
+            if (MODE >= 3) { GLOAD(ra, rb, it); LSTORE(ra, rb, buf ^ 1); }
+            if (MODE >= 2) FREAD(buf, 1);
+            MFMA16();
+        } else if (MODE == 4) {          // loads first, stores last (one tile of distance)
+            GLOAD(ra, rb, it); SB();
+            FREAD(buf, 0); MFMA16(); SB();
+            FREAD(buf, 1); MFMA16(); SB();
+            LSTORE(ra, rb, buf ^ 1);
+        } else if (MODE == 5) {          // prefetch distance 2: the loads issued now are stored at the end of the NEXT tile
+            if (it & 1) { GLOAD(ra2, rb2, it); } else { GLOAD(ra, rb, it); }
+            SB();
+            FREAD(buf, 0); MFMA16(); SB();
+            FREAD(buf, 1); MFMA16(); SB();
+            if (it & 1) { LSTORE(ra, rb, buf ^ 1); } else { LSTORE(ra2, rb2, buf ^ 1); }
+        } else if (MODE == 6) {          // loads after group 0 (as the library), stores after group 1
+            FREAD(buf, 0); MFMA16(); SB();
+            GLOAD(ra, rb, it); SB();
+            FREAD(buf, 1); MFMA16(); SB();
+            LSTORE(ra, rb, buf ^ 1);
+        } else if (MODE == 7) {          // as 3 but without the LDS stores (loads only, consumed by a dummy)
+            FREAD(buf, 0); MFMA16();
+            GLOAD(ra, rb, it);
+            FREAD(buf, 1); MFMA16();
+            acc[0][0] += ra[0][0] + ra[1][0] + rb[0][0] + rb[1][0];
+        } else if (MODE == 9) {          // 2 loads only
+            FREAD(buf, 0); MFMA16();
+            ra[0] = gp[(size_t)(it & 63) * 256]; rb[0] = gp[(size_t)(it & 31) * 256 + 32768];
+            FREAD(buf, 1); MFMA16();
+            acc[0][0] += ra[0][0] + rb[0][0];
+        } else if (MODE == 10) {         // 1 load only
+            FREAD(buf, 0); MFMA16();
+            ra[0] = gp[(size_t)(it & 63) * 256];
+            FREAD(buf, 1); MFMA16();
+            acc[0][0] += ra[0][0];
+        } else if (MODE == 11) {         // 4 loads through a buffer descriptor (one address VGPR)
+            FREAD(buf, 0); MFMA16();
+            const unsigned o = (unsigned)(blockIdx.x * 1024 + tid) * 16u;
+            ra[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o + ((it & 63) * 256) * 16u, 0, 0));
+            ra[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o + ((it & 63) * 256 + 16384) * 16u, 0, 0));
+            rb[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o + ((it & 31) * 256 + 32768) * 16u, 0, 0));
+            rb[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o + ((it & 31) * 256 + 49152) * 16u, 0, 0));
+            FREAD(buf, 1); MFMA16();
+            acc[0][0] += ra[0][0] + ra[1][0] + rb[0][0] + rb[1][0];
+        } else if (MODE == 12) {         // 4 LDS-DMA loads (no VGPR destination, no ds_write): 1 KB per wave-instruction, lane-linear
+            FREAD(buf, 0); MFMA16();
+            float* dst = smem + (2 * 128 * 20 + 2 * 16 * 128) + wave * 1024;      // scratch area behind the tiles: [wave][4 x 256 floats]
+            __builtin_amdgcn_global_load_lds((const void*)(gp + (size_t)(it & 63) * 256), (__attribute__((address_space(3))) void*)(dst), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const void*)(gp + (size_t)(it & 63) * 256 + 16384), (__attribute__((address_space(3))) void*)(dst + 256), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const void*)(gp + (size_t)(it & 31) * 256 + 32768), (__attribute__((address_space(3))) void*)(dst + 512), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const void*)(gp + (size_t)(it & 31) * 256 + 49152), (__attribute__((address_space(3))) void*)(dst + 768), 16, 0, 0);
+            FREAD(buf, 1); MFMA16();
+        } else if (MODE == 13) {         // 4 loads, fragment-shaped: each lane-quad reads 64 B of its own row (rows 512 B apart)
+            FREAD(buf, 0); MFMA16();
+            const f32x4* q = (const f32x4*)g + (size_t)blockIdx.x * 8192 + (size_t)(tid >> 2) * 32 + (tid & 3) + (it & 7) * 4;
+            ra[0] = q[0]; ra[1] = q[2048]; rb[0] = q[4096]; rb[1] = q[6144];
+            FREAD(buf, 1); MFMA16();
+            acc[0][0] += ra[0][0] + ra[1][0] + rb[0][0] + rb[1][0];
+        } else if (MODE >= 20 && MODE < 30) {   // no memory traffic at all: N dummy VALU ops per K tile (MODE 20: 16 v_mul_lo_u32, 21: 64 v_add, 22: 16 v_add)
+            FREAD(buf, 0); MFMA16();
+            if (MODE == 20) { _Pragma("unroll") for (int q = 0; q < 16; ++q) dummy = dummy * (unsigned)(it + q) + 1u; }
+            if (MODE == 21) { _Pragma("unroll") for (int q = 0; q < 64; ++q) dummy = (dummy ^ (unsigned)(it + q)) + 3u; }
+            if (MODE == 22) { _Pragma("unroll") for (int q = 0; q < 16; ++q) dummy = (dummy ^ (unsigned)(it + q)) + 3u; }
+            FREAD(buf, 1); MFMA16();
+        } else if (MODE == 8) {          // as 3 but stores only (no global loads)
+            FREAD(buf, 0); MFMA16();
+            LSTORE(ra, rb, buf ^ 1);
+            FREAD(buf, 1); MFMA16();
+        }
+        if (MODE >= 1) __syncthreads();
+    }
+    float s = 0.f;
+    for (int t = 0; t < 4; ++t) for (int r = 0; r < 16; ++r) s += acc[t][r];
+    if (s == 12345.678f || dummy == 0x12345u) out[blockIdx.x * 256 + tid] = s;
+}
+
+template <int MODE>
+static void run(const char* what, const float* g, float* out, int blocks, int ldskb) {
+    const int iters = 2000;
+    hipFuncSetAttribute((const void*)probe<MODE, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    probe<MODE, 0><<<blocks, 256, ldskb * 1024>>>(g, out, iters);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    for (int r = 0; r < 5; ++r) probe<MODE, 0><<<blocks, 256, ldskb * 1024>>>(g, out, iters);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 5;
+    const double flop = (double)blocks * 4 * iters * 32 * (2.0 * 32 * 32 * 2);
+    printf("%-52s blocks %5d (LDS %3d KB/block) %8.3f ms  %7.1f TFLOP/s\n", what, blocks, ldskb, ms, flop / ms / 1e9);
+}
+
+int main() {
+    float *g, *out;
+    hipMalloc(&g, (size_t)1 << 30); hipMemset(g, 0, (size_t)1 << 30);
+    hipMalloc(&out, 1 << 24);
+    for (int ldskb : {37, 70}) {      // 37 KB -> 4 blocks/CU, 70 KB -> 2 blocks/CU
+        const int blocks = ldskb == 37 ? 1024 : 512;
+        run<0>("mfma only", g, out, blocks, ldskb);
+        run<2>("+ barrier + 8 ds_read_b128 per 32 MFMAs", g, out, blocks, ldskb);
+        run<3>("+ 4 global loads + 4 ds_write (load->store adjacent)", g, out, blocks, ldskb);
+        run<7>("   loads only (no LDS stores)", g, out, blocks, ldskb);
+        run<8>("   LDS stores only (no loads)", g, out, blocks, ldskb);
+        run<6>("   loads after group 0, stores after group 1", g, out, blocks, ldskb);
+        run<4>("   loads first, stores last", g, out, blocks, ldskb);
+        run<5>("   prefetch distance 2", g, out, blocks, ldskb);
+        run<20>("   no memory ops; 16 v_mul_lo_u32 per K tile", g, out, blocks, ldskb);
+        run<21>("   no memory ops; 128 simple VALU per K tile", g, out, blocks, ldskb);
+        run<22>("   no memory ops; 32 simple VALU per K tile", g, out, blocks, ldskb);
+        run<9>("   2 loads only", g, out, blocks, ldskb);
+        run<10>("   1 load only", g, out, blocks, ldskb);
+        run<11>("   4 buffer loads (1 address VGPR)", g, out, blocks, ldskb);
+        run<13>("   4 loads, 16 rows x 64 B each (fragment-shaped)", g, out, blocks, ldskb);
+        run<12>("   4 LDS-DMA loads (global_load_lds_dwordx4)", g, out, blocks, ldskb + 16);
+    }
+    return 0;
+}
