@@ -48,6 +48,7 @@ void cgs_geom_F(const CgsLayer& L, IgemmParams& p) {
     c.R = L.Hs; c.C = L.Ws; c.py = 0; c.px = 0; c.nty = L.kh; c.ntx = L.kw;
     c.dy0 = -cgs_same_pad_before(L.Hb, L.kh, L.sh); c.dx0 = -cgs_same_pad_before(L.Wb, L.kw, L.sw);
     c.ky0 = 0; c.kx0 = 0; c.K = L.kh * L.kw * L.Cb; c.w_off = 0;
+    p.vec = (p.Cred % BK) == 0 && c.nty <= 16 && c.ntx <= 16;
 }
 
 void cgs_geom_T(const CgsLayer& L, IgemmParams& p) {
@@ -70,6 +71,8 @@ void cgs_geom_T(const CgsLayer& L, IgemmParams& p) {
             c.K = c.nty * c.ntx * L.Cs; c.w_off = off;
             off += cgs_round_up(c.K, BK) * p.Np;
         }
+    p.vec = (p.Cred % BK) == 0;
+    for (int i = 0; i < p.nclasses; ++i) p.vec = p.vec && p.cls[i].nty <= 16 && p.cls[i].ntx <= 16;
     // heaviest class first: blocks are dispatched in blockIdx.y-major order, so the 9-tap class must not be the tail
     for (int i = 1; i < p.nclasses; ++i)
         for (int j = i; j > 0 && p.cls[j].K > p.cls[j - 1].K; --j) { IgemmClass t = p.cls[j]; p.cls[j] = p.cls[j - 1]; p.cls[j - 1] = t; }
@@ -96,7 +99,7 @@ __global__ void pack_weights_kernel(IgemmParams p, const float* __restrict__ w, 
         float v = 0.f;
         if (k < c.K && n < p.N) {
             int t, ci, ta, tb;
-            if ((p.Cred % BK) == 0) {      // K order (32-channel chunk, tap, channel in chunk): see igemm_kernel
+            if (p.vec) {      // K order (32-channel chunk, tap, channel in chunk): see igemm_kernel
                 const int ntaps = c.nty * c.ntx;
                 const int kt = k / BK, chunk = kt / ntaps;
                 t = kt - chunk * ntaps; ci = chunk * BK + (k - kt * BK);
@@ -425,6 +428,18 @@ __global__ __launch_bounds__(64 * NW, 2) void igemm_kernel(IgemmParams p) {
         const int kq = idx / BN, n = idx - kq * BN;
         b_voff[i] = (unsigned)(kq * p.Np + n0 + n) * 16u;
     }
+    // which taps of row i lie inside the image: bit ia (tap row, visiting order) and bit 16 + ib (tap column) -- the per-tile
+    // bounds check is then one v_and + one v_cmp against a scalar (VEC kernels have at most 16 taps per axis, see cgs_geom_*)
+    unsigned tapmask[AI];
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+        unsigned mk = 0;
+        for (int ia = 0; ia < c.nty; ++ia)
+            if ((unsigned)(a_iy[i] + cgs_tap_order(ia, c.nty, PAR) * p.dstep) < (unsigned)p.Hin) mk |= 1u << ia;
+        for (int ib = 0; ib < c.ntx; ++ib)
+            if ((unsigned)(a_ix[i] + cgs_tap_order(ib, c.ntx, PAR) * p.dstep) < (unsigned)p.Win) mk |= 1u << (16 + ib);
+        tapmask[i] = mk;
+    }
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)wsrc, 0, 0x7ffffff0, 0x00020000);
     const int b_tile_bytes = (BK / 4) * p.Np * 16;
     unsigned a_off[AI];
@@ -434,10 +449,9 @@ __global__ __launch_bounds__(64 * NW, 2) void igemm_kernel(IgemmParams p) {
         const int ta_ = cgs_tap_order((s_).ia, c.nty, PAR), tb_ = cgs_tap_order((s_).ib, c.ntx, PAR);           \
         const int dy_ = ta_ * p.dstep, dx_ = tb_ * p.dstep;                                                     \
         const unsigned soff_ = (unsigned)(((dy_ * p.Win + dx_) * p.Cred + (s_).chunk * 32 + (TBK == 16 ? (s_).sub * 16 : 0)) * 4); \
-        _Pragma("unroll") for (int i = 0; i < AI; ++i) {                                                        \
-            const bool ok = (unsigned)(a_iy[i] + dy_) < (unsigned)p.Hin && (unsigned)(a_ix[i] + dx_) < (unsigned)p.Win; \
-            a_off[i] = ok ? rowoff[i] + soff_ : 0xFFFFFFF0u;                                                    \
-        }                                                                                                       \
+        const unsigned need_ = (1u << (s_).ia) | (1u << (16 + (s_).ib));                                        \
+        _Pragma("unroll") for (int i = 0; i < AI; ++i)                                                          \
+            a_off[i] = (tapmask[i] & need_) == need_ ? rowoff[i] + soff_ : 0xFFFFFFF0u;                         \
     } while (0)
 #define ISSUE_TILE_V(s_)                                                                                        \
     do {                                                                                                        \
@@ -584,25 +598,45 @@ __global__ __launch_bounds__(64 * NW, 2) void igemm_kernel(IgemmParams p) {
             __builtin_amdgcn_sched_barrier(0);
         }
     } else if constexpr (VEC) {
-        for (int buf = 0; cur.kt < nk; buf ^= 1) {
+        // Two copies of the body, one per LDS buffer: the buffer offsets are then instruction immediates instead of a VALU add
+        // per address and tile.  The pair loop has ONE exit (at its top, on a two-tile look-ahead), an odd last tile runs in a
+        // third copy after it: with an exit between the two copies the compiler moves all 64 accumulator registers at it.
+#define TILE_BODY(BUF_, NXT_)                                                                                   \
+    {                                                                                                           \
+        PRIO_STEP(cur.kt);                                                                                      \
+        KIt ld = NXT_;                                  /* tile to prefetch (the current one again after the last) */ \
+        if ((NXT_).kt >= nk) ld = cur;                                                                          \
+        const float* a = As + (BUF_) * BM * LDA + (wm * (BM / 2) + j) * LDA;                                    \
+        const float* b = Bs + (BUF_) * BK * BN + (wn * (BN / WN) + j) * 4;                                      \
+        MFMA_GROUP(0);                                                                                          \
+        ADDR_TILE_V(ld);                                                                                        \
+        ISSUE_TILE_V(ld);                                                                                       \
+        _Pragma("unroll") for (int jj = 1; jj < NG - 1; ++jj) MFMA_GROUP(jj);                                   \
+        STORE_TILE((BUF_) ^ 1);                                                                                 \
+        if (NG > 1) MFMA_GROUP(NG - 1);                                                                         \
+        __syncthreads();                                                                                        \
+        cur = NXT_;                                                                                             \
+    }
+        KIt n1 = cur;
+        if (cur.kt < nk) n1 = kit_next(cur);
+        while (n1.kt < nk) {                             // at least two tiles left: cur (in buffer 0) and n1
+            const KIt n2 = kit_next(n1);
+            KIt n3 = n2;
+            if (n2.kt < nk) n3 = kit_next(n2);
+#ifdef CGS_DIAG_STAMPS
+            diag_tiles += 2;
+#endif
+            TILE_BODY(0, n1);
+            TILE_BODY(1, n2);
+            n1 = n3;
+        }
+        if (cur.kt < nk) {                               // an odd last tile
 #ifdef CGS_DIAG_STAMPS
             ++diag_tiles;
 #endif
-            PRIO_STEP(cur.kt);
-            const KIt nxt = kit_next(cur);
-            const KIt ld = nxt.kt < nk ? nxt : cur;      // tile to prefetch (the current one again after the last)
-            const float* a = As + buf * BM * LDA + (wm * (BM / 2) + j) * LDA;
-            const float* b = Bs + buf * BK * BN + (wn * (BN / WN) + j) * 4;
-            MFMA_GROUP(0);
-            ADDR_TILE_V(ld);
-            ISSUE_TILE_V(ld);
-#pragma unroll
-            for (int jj = 1; jj < NG - 1; ++jj) MFMA_GROUP(jj);
-            STORE_TILE(buf ^ 1);
-            if (NG > 1) MFMA_GROUP(NG - 1);
-            __syncthreads();
-            cur = nxt;
+            TILE_BODY(0, n1);
         }
+#undef TILE_BODY
     } else {
         for (int buf = 0; kt < nk; buf ^= 1) {
 #ifdef CGS_DIAG_STAMPS
@@ -868,7 +902,7 @@ int cgs_igemm_launch(const IgemmParams& p_in, void* slab, size_t slab_bytes, hip
     int maxRC = 0;
     for (int i = 0; i < p.nclasses; ++i) maxRC = p.cls[i].R * p.cls[i].C > maxRC ? p.cls[i].R * p.cls[i].C : maxRC;
     const size_t in_bytes = (size_t)p.B * p.Hin * p.Win * p.Cred * 4;
-    p.pix_major = (p.Cred % BK) == 0 && p.B >= 128 && maxRC <= 64 && maxRC > 1 && in_bytes <= (size_t)192 << 20;
+    p.pix_major = p.vec && p.B >= 128 && maxRC <= 64 && maxRC > 1 && in_bytes <= (size_t)192 << 20;
     p.lpt = p.pix_major && (p.B % 128) == 0;
     if (p.lpt)
         for (int ci = 0; ci < p.nclasses; ++ci) {
@@ -900,7 +934,7 @@ int cgs_igemm_launch(const IgemmParams& p_in, void* slab, size_t slab_bytes, hip
             }
         }
     }
-    const bool vec = (p.Cred % BK) == 0;
+    const bool vec = p.vec != 0;
     {   // multiply-accumulates this launch really issues: the algorithmic count minus the zero-padding taps whose K tiles the
         // kernel skips (pixel-major tiles whose 128 rows are one base pixel; exact, see igemm_kernel) -- for honest rooflines
         double macs = 0.0;
