@@ -8,6 +8,8 @@
 // staged once in LDS, and every A fragment of v_mfma_f32_32x32x2_f32 is one ds_read_b32 at
 //   patch[(2*oy+ky)*pitch + (2*ox+kx)*Cin + ci] = rowbase(pixel) + koff(k),  koff(k) = (k / (kw*Cin))*pitch + k % (kw*Cin)
 // (for a fixed ky the (kx,ci) run is contiguous in NHWC).  Output through the same LDS-transposed 16-byte epilogue.
+#include <stdlib.h>
+
 #include "cgs_internal.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -220,6 +222,288 @@ __global__ __launch_bounds__(256, 2) void conv_patch_kernel(PatchParams p, int t
 #undef STORE_PATCH
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Second form for the hot shapes (stride 2, kh = KH, a (kx, ci) run of R <= RP floats per tap row, e.g. 5x5x3: KH = 5, R = 15,
+// RP = 16).  The kernel above issues two ds_read_b32 and one address add per MFMA: it is bound by LDS-instruction issue and by
+// the vector ALU, which shares the SIMD's issue with the matrix pipe (tools/probe/mfma_probe.hip), not by the matrix pipe.
+// Here the reduction is re-ordered so that a lane reads CONSECUTIVE patch floats: every tap row is padded to RP elements and
+// split in two halves, lane-half h (the k index of v_mfma_f32_32x32x2_f32) takes half h, so the RP/2 MFMA steps of a tap row
+// consume RP/2 consecutive floats per lane = RP/4 ds_read_b64 (8-byte aligned: stride-2 pixels of 3 channels are 24 bytes
+// apart, the row pitch is even), and the lane's weight column sits in REGISTERS for the whole (persistent) block:
+// 0.5 LDS reads per MFMA instead of 2, no table look-ups.  Padding elements (run index >= R) carry zero weights AND are
+// zeroed on the A side, so a non-finite neighbour outside the receptive field cannot leak in.
+// ------------------------------------------------------------------------------------------------------------------
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__global__ void pack_patch2_weights_kernel(const float* __restrict__ w, float* __restrict__ wk, int KH, int RP, int R, int N, int Np) {
+    const int HALF = RP / 2, total = KH * RP * Np;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int n = i % Np, th = i / Np, h = th & 1, t = th >> 1;      // wk[(t * 2 + h) * Np + n]
+        const int ky = t / HALF, sidx = t - ky * HALF, e = h * HALF + sidx;
+        wk[i] = (e < R && n < N) ? w[((size_t)ky * R + e) * N + n] : 0.f;
+    }
+}
+
+// epilogue of conv_patch2_kernel for one tile: acc[tm][r] is output row (r & 3) + 8 * (r >> 2) + 4 * h of row tile tm (32 GEMM rows =
+// 2 tile rows of 16 pixels), channel j.  base = byte offset of (tile origin, this lane's channel, + 4 * h pixels); 32-bit offsets through a
+// buffer descriptor, the per-register part folds into the store's immediate offset.
+template <int EPI>
+__device__ __forceinline__ void patch2_store(const PatchParams& p, __amdgpu_buffer_rsrc_t out_rsrc, __amdgpu_buffer_rsrc_t aux_rsrc,
+                                             const f32x16 (&acc)[2], unsigned base, unsigned rowstride, float ea, float eb) {
+    const unsigned pixb = (unsigned)p.N * 4u;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2);                       // + 4 * h is in the lane base; row / 16 picks the tile row
+            const unsigned o = base + (unsigned)(2 * tm + row / TC) * rowstride + (unsigned)(row % TC) * pixb;
+            float aux = 0.f;
+            if (EPI >= CGS_EPI_RELU_BWD_AFFINE) aux = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(aux_rsrc, o, 0, 0));
+            const float y = epilogue_apply(acc[tm][r], EPI, ea, eb, aux);       // (the bias is already in the accumulator)
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y), out_rsrc, o, 0, 0);
+        }
+}
+
+// AUXP: the *_BWD epilogues read an aux tensor of the output's shape (the saved activation of the layer below).  Loading it in the
+// epilogue put a chain of global-load latencies into every tile (221 -> 262 us with one dword per register); here its 8 float4
+// per lane are PREFETCHED right after the tile's barrier, in the 16-byte-per-lane layout, and the accumulators are transposed to
+// that layout through a small LDS tile when the MFMAs are done.
+template <int KH, int RP, int R, int PLD, bool AUXP>     // R = kw * Cin floats per tap row (<= RP), PLD = patch floats per thread (ceil(PH * PW * Cin / 256))
+__global__ __launch_bounds__(256, AUXP ? 2 : 3) void conv_patch2_kernel(PatchParams p, int tiles_total, int tiles_per_block) {
+    constexpr int HALF = RP / 2, NQ = RP / 4, NS = KH * HALF;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int patch_f = p.PH * p.pitch;
+    float* Ps = smem;                                    // [2][PH][pitch]
+    constexpr int LDE = 32 + 4;
+    float* E = Ps + (size_t)2 * patch_f + (threadIdx.x >> 6) * 32 * LDE;     // AUXP: this wave's [32 rows][32 cols (+4)] staging tile
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, h = lane >> 5, j = lane & 31;
+    const int c4 = (lane & 7) * 4, rsub = lane >> 3;     // AUXP epilogue layout: 8 lanes x float4 per row, 8 rows per pass
+
+    const int tiles_x = p.Wout / TC, tiles_y = p.Hout / TR;
+    const int tiles_per_n = p.B * tiles_x * tiles_y;     // tile id = n-tile * tiles_per_n + (image, tile row, tile col): a block's run
+    const int t_begin = blockIdx.x * tiles_per_block;    // of tiles stays inside one n-tile except at a boundary (weights reloaded there)
+    const int t_end = t_begin + tiles_per_block < tiles_total ? t_begin + tiles_per_block : tiles_total;
+    if (t_begin >= t_end) return;
+
+    const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)p.in, 0, (int)((unsigned)p.B * (unsigned)p.Hin * (unsigned)p.Win * (unsigned)p.Cred * 4u), 0x00020000);
+    const unsigned out_bytes = (unsigned)p.B * (unsigned)p.Hout * (unsigned)p.Wout * (unsigned)p.N * 4u;
+    const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, (int)out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t aux_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.ep_aux ? p.ep_aux : p.out), 0, (int)out_bytes, 0x00020000);
+    const int rowf = p.PW * p.Cred;                      // valid floats per patch row
+    const int rowlen = p.Win * p.Cred;
+    // this thread's patch elements: (patch row, column) -> LDS offset and image offset relative to the tile's patch origin (loop invariant)
+    int l_pr[PLD], l_e[PLD], l_dst[PLD], l_src[PLD];
+    {
+        const float inv_rowf = 1.0f / (float)rowf;
+        const int total = p.PH * rowf;
+#pragma unroll
+        for (int u = 0; u < PLD; ++u) {
+            const int q = tid + 256 * u;
+            int pr = (int)((float)q * inv_rowf);
+            if (pr * rowf > q) --pr;
+            if ((pr + 1) * rowf <= q) ++pr;
+            l_pr[u] = q < total ? pr : -(1 << 20);       // far out of range: never loaded, never stored
+            l_e[u] = q - pr * rowf;
+            l_dst[u] = q < total ? pr * p.pitch + l_e[u] : -1;
+            l_src[u] = (pr * rowlen + l_e[u]) * 4;
+        }
+    }
+    // the pad floats behind a patch row's rowf valid ones are read by the widened runs: keep them finite (zero) in both buffers
+    for (int q = tid; q < 2 * p.PH * (p.pitch - rowf); q += 256) {
+        const int r = q / (p.pitch - rowf), cidx = q - r * (p.pitch - rowf);
+        Ps[(size_t)r * p.pitch + rowf + cidx] = 0.f;
+    }
+    float pv[PLD];
+#define TILE_DECODE(t_, b_, oy0_, ox0_, n0_)                                                       \
+    do {                                                                                           \
+        int r_ = (t_);                                                                             \
+        n0_ = (r_ / tiles_per_n) * PBN; r_ -= (r_ / tiles_per_n) * tiles_per_n;                    \
+        ox0_ = (r_ % tiles_x) * TC; r_ /= tiles_x;                                                 \
+        oy0_ = (r_ % tiles_y) * TR; b_ = r_ / tiles_y;                                             \
+    } while (0)
+#define LOAD_PATCH(b_, oy0_, ox0_)                                                                 \
+    do {                                                                                           \
+        const int iy0_ = p.S * (oy0_) - p.pt, col0_ = (p.S * (ox0_) - p.pl) * p.Cred;              \
+        const int org_ = (((b_) * p.Hin + iy0_) * rowlen + col0_) * 4;        /* scalar */          \
+        _Pragma("unroll") for (int u = 0; u < PLD; ++u) {                                          \
+            const bool ok = (unsigned)(iy0_ + l_pr[u]) < (unsigned)p.Hin && (unsigned)(col0_ + l_e[u]) < (unsigned)rowlen; \
+            const unsigned off = ok ? (unsigned)(org_ + l_src[u]) : 0xFFFFFFF0u;                   \
+            pv[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, off, 0, 0)); \
+        }                                                                                          \
+    } while (0)
+#define STORE_PATCH(buf_)                                                                          \
+    do {                                                                                           \
+        float* P_ = Ps + (size_t)(buf_) * patch_f;                                                 \
+        _Pragma("unroll") for (int u = 0; u < PLD; ++u)                                            \
+            if (l_dst[u] >= 0) P_[l_dst[u]] = pv[u];                                               \
+    } while (0)
+
+    int b, oy0, ox0, n0;
+    TILE_DECODE(t_begin, b, oy0, ox0, n0);
+    LOAD_PATCH(b, oy0, ox0);
+    STORE_PATCH(0);
+
+    int rowbase[2];                                      // this lane's two GEMM rows (pixels) inside the patch, + its half of the run
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) {
+        const int m = wm * 64 + tm * 32 + j;
+        rowbase[tm] = (p.S * (m / TC)) * p.pitch + (p.S * (m % TC)) * p.Cred + h * HALF;
+    }
+    int t = t_begin, it = 0;
+    while (t < t_end) {                                  // one pass per n-tile the block's run touches (normally one)
+        float bw[NS];                                    // this lane's weight column, all K steps: registers for the whole pass
+        {
+            const float* wcol = p.wk + (size_t)h * p.Np + n0 + wn * 32 + j;
+#pragma unroll
+            for (int q = 0; q < NS; ++q) bw[q] = wcol[(size_t)q * 2 * p.Np];
+        }
+        const int nj = n0 + wn * 32 + j;                 // this lane's output channel
+        float bias1 = 0.f, ea1 = 1.f, eb1 = 0.f;
+        if (nj < p.N) {
+            if (p.bias) bias1 = p.bias[nj];
+            if (p.epilogue == CGS_EPI_AFFINE_RELU) { ea1 = p.ep_a[nj]; eb1 = p.ep_b[nj]; }
+            if (p.epilogue == CGS_EPI_RELU_BWD_AFFINE) ea1 = p.ep_a[nj];
+        }
+        const unsigned rowstride = (unsigned)p.Wout * p.N * 4u;
+        // lane part of an output offset: channel, the + 4 * h pixel shift of the accumulator layout, the wave's 4 tile rows
+        const unsigned obase_l = (unsigned)(nj + 4 * h * p.N) * 4u + (unsigned)(wm * 4) * rowstride;
+        const int seg_n0 = n0;
+        for (; t < t_end && n0 == seg_n0; ++t, ++it) {
+#ifdef CGS_PATCH_STAMPS
+            unsigned long long st0 = __builtin_amdgcn_s_memtime();
+#endif
+            __syncthreads();                             // patch[it & 1] is in LDS; patch[(it+1) & 1] is free
+#ifdef CGS_PATCH_STAMPS
+            unsigned long long st1 = __builtin_amdgcn_s_memtime();
+#endif
+            int nb_ = b, noy0 = oy0, nox0 = ox0, nn0 = n0;
+            const bool more = t + 1 < t_end;
+            if (more) {
+                TILE_DECODE(t + 1, nb_, noy0, nox0, nn0);
+                LOAD_PATCH(nb_, noy0, nox0);
+            }
+            const float* P = Ps + (size_t)(it & 1) * patch_f;
+            const unsigned tile_off = (unsigned)(((b * p.Hout + oy0) * p.Wout + ox0) * p.N) * 4u;      // scalar
+            f32x4 auxv[2][4];
+            if constexpr (AUXP) {
+                const unsigned ab = tile_off + (unsigned)(n0 + wn * 32 + c4) * 4u + (unsigned)(wm * 4) * rowstride;
+#pragma unroll
+                for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int lrow = q * 8 + rsub;                       // row of the 32-row tile: pixel (lrow / 16, lrow % 16) of tile rows 2 tm, 2 tm + 1
+                        auxv[tm][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                            aux_rsrc, ab + (unsigned)(2 * tm + lrow / TC) * rowstride + (unsigned)(lrow % TC) * (unsigned)p.N * 4u, 0, 0));
+                    }
+            }
+#ifdef CGS_PATCH_STAMPS
+            unsigned long long st2 = __builtin_amdgcn_s_memtime();
+#endif
+            // the accumulators start at the bias: every plain VALU op of the epilogue costs matrix time on this SIMD (32 v_add per
+            // tile were worth 16 % of the kernel), the MFMA adds onto whatever is there for free
+            f32x16 acc[2];
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[tm][r] = bias1;
+#pragma unroll
+            for (int ky = 0; ky < KH; ++ky) {
+                f32x2 av[2][NQ];
+#pragma unroll
+                for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) av[tm][q] = *(const f32x2*)(P + rowbase[tm] + ky * p.pitch + 2 * q);
+#pragma unroll
+                for (int sidx = 0; sidx < HALF; ++sidx) {
+                    float a0 = av[0][sidx >> 1][sidx & 1], a1 = av[1][sidx >> 1][sidx & 1];
+                    if (sidx >= R - HALF) { a0 = h ? 0.f : a0; a1 = h ? 0.f : a1; }      // padding element of the run (compile-time sidx: one step per tap row)
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bw[ky * HALF + sidx], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bw[ky * HALF + sidx], acc[1], 0, 0, 0);
+                }
+            }
+#ifdef CGS_PATCH_STAMPS
+            unsigned long long st3 = __builtin_amdgcn_s_memtime();
+#endif
+            // the next patch goes to LDS BEFORE this tile's output stores are issued: its wait (vmcnt counts loads and stores in
+            // issue order) then covers only the patch loads and the previous tile's stores, both a whole MFMA phase old
+            if (more) STORE_PATCH((it + 1) & 1);
+#ifdef CGS_PATCH_STAMPS
+            unsigned long long st4 = __builtin_amdgcn_s_memtime();
+#endif
+            // epilogue straight from the accumulator registers: lane (h, j) holds channel j of 16 rows per row tile, so one
+            // buffer_store_dword writes two whole 128-byte channel runs (rows R and R + 4).  No LDS round trip, and every
+            // address is one of two per-lane bases (tile row 0 / 1 of the row tile) plus an instruction immediate.
+            // (The LDS-transposed 16-byte form took 7k cycles per tile here -- a chain of LDS latencies -- against 5k of MFMAs.)
+            if constexpr (AUXP) {
+                const unsigned ob = tile_off + (unsigned)(n0 + wn * 32 + c4) * 4u + (unsigned)(wm * 4) * rowstride;
+                const bool live = n0 + wn * 32 + c4 < p.N;
+                f32x4 ea4 = {1.f, 1.f, 1.f, 1.f};
+                if (live && p.epilogue == CGS_EPI_RELU_BWD_AFFINE) ea4 = *(const f32x4*)(p.ep_a + n0 + wn * 32 + c4);
+#pragma unroll
+                for (int tm = 0; tm < 2; ++tm) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) E[((r & 3) + 8 * (r >> 2) + 4 * h) * LDE + j] = acc[tm][r];
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int lrow = q * 8 + rsub;
+                        const f32x4 v = *(const f32x4*)(E + lrow * LDE + c4);
+                        f32x4 y;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float ax = auxv[tm][q][e];
+                            y[e] = p.epilogue == CGS_EPI_RELU_BWD_AFFINE ? (ax > 0.f ? v[e] * ea4[e] : 0.f)
+                                 : p.epilogue == CGS_EPI_LRELU_BWD ? (ax > 0.f ? v[e] : 0.2f * v[e]) : v[e] * (1.f - ax * ax);
+                        }
+                        if (live)
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, y), out_rsrc,
+                                                                   ob + (unsigned)(2 * tm + lrow / TC) * rowstride + (unsigned)(lrow % TC) * (unsigned)p.N * 4u, 0, 0);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                }
+            } else if (nj < p.N) {
+                switch (p.epilogue) {
+                    case CGS_EPI_NONE: patch2_store<CGS_EPI_NONE>(p, out_rsrc, aux_rsrc, acc, obase_l + tile_off, rowstride, ea1, eb1); break;
+                    case CGS_EPI_LRELU: patch2_store<CGS_EPI_LRELU>(p, out_rsrc, aux_rsrc, acc, obase_l + tile_off, rowstride, ea1, eb1); break;
+                    case CGS_EPI_AFFINE_RELU: patch2_store<CGS_EPI_AFFINE_RELU>(p, out_rsrc, aux_rsrc, acc, obase_l + tile_off, rowstride, ea1, eb1); break;
+                    case CGS_EPI_TANH: patch2_store<CGS_EPI_TANH>(p, out_rsrc, aux_rsrc, acc, obase_l + tile_off, rowstride, ea1, eb1); break;
+                    case CGS_EPI_RELU_BWD_AFFINE: patch2_store<CGS_EPI_RELU_BWD_AFFINE>(p, out_rsrc, aux_rsrc, acc, obase_l + tile_off, rowstride, ea1, eb1); break;
+                    case CGS_EPI_LRELU_BWD: patch2_store<CGS_EPI_LRELU_BWD>(p, out_rsrc, aux_rsrc, acc, obase_l + tile_off, rowstride, ea1, eb1); break;
+                    default: patch2_store<CGS_EPI_TANH_BWD>(p, out_rsrc, aux_rsrc, acc, obase_l + tile_off, rowstride, ea1, eb1); break;
+                }
+            }
+#ifdef CGS_PATCH_STAMPS
+            if (p.ep_b && lane == 0 && blockIdx.x < 64 && it < 16) {
+                unsigned long long* dbg = (unsigned long long*)p.ep_b + (((size_t)blockIdx.x * 4 + wave) * 16 + it) * 8;
+                dbg[0] = st0; dbg[1] = st1; dbg[2] = st2; dbg[3] = st3; dbg[4] = st4; dbg[5] = __builtin_amdgcn_s_memtime();
+            }
+#endif
+            b = nb_; oy0 = noy0; ox0 = nox0; n0 = nn0;
+        }
+    }
+#undef TILE_DECODE
+#undef LOAD_PATCH
+#undef STORE_PATCH
+}
+
+// which (KH, RP) instantiation of conv_patch2_kernel serves a layer (0 = none: the general kernel above)
+static int patch2_rp(const CgsLayer& L, bool dirT) {
+#ifdef CGS_EXPERIMENT
+    if (getenv("CGS_PATCH_V1")) return 0;
+#endif
+    if (dirT || L.sh != 2 || L.sw != 2) return 0;
+    if (((L.sw * L.Cb) & 1) != 0) return 0;                 // 8-byte aligned pixel starts
+    // the instantiated shape: 5 tap rows of 5 x 3 floats, a 19 x 35 x 3 patch (8 floats per thread)
+    if (L.kh == 5 && L.kw == 5 && L.Cb == 3 && (L.Hs % TR) == 0 && (L.Ws % TC) == 0) return 16;
+    return 0;
+}
+
 // dirT = false: the conv itself (big -> small, Cb <= 4 input channels, stride 1 or 2).
 // dirT = true : the backward-data of a STRIDE-1 conv whose output has <= 4 channels (small -> big at the same resolution):
 //               dx[i] = sum_ky dy[i + pt - ky] w[ky] = sum_ky' dy[i - (kh-1-pt) + ky'] w[kh-1-ky'] -- the same stride-1
@@ -234,6 +518,7 @@ static void patch_geom(const CgsLayer& L, bool dirT, PatchParams& p) {
     p.K = L.kh * L.kw * p.Cred; p.Kp = cgs_round_up(p.K, 2);
     p.PH = S * (TR - 1) + L.kh; p.PW = S * (TC - 1) + L.kw;
     p.pitch = p.PW * p.Cred + 1;
+    if (patch2_rp(L, dirT)) p.pitch = cgs_round_up(p.PW * p.Cred + 1, 16);      // even rows for ds_read_b64; 112 floats is conflict-free for 5x5x3
 }
 
 // <= 4 reduction channels, output tiles of 8 x 16 pixels, N % 4 == 0
@@ -250,6 +535,7 @@ int cgs_conv_patch_T_ok(const CgsLayer& L) {
 }
 
 size_t cgs_conv_patch_ws_floats(const CgsLayer& L, bool dirT) {
+    if (const int rp = patch2_rp(L, dirT)) return (size_t)L.kh * rp * cgs_round_up(L.Cs, PBN);
     return dirT ? (size_t)cgs_round_up(L.kh * L.kw * L.Cs, 2) * cgs_round_up(L.Cb, PBN)
                 : (size_t)cgs_round_up(L.kh * L.kw * L.Cb, 2) * cgs_round_up(L.Cs, PBN);
 }
@@ -278,6 +564,35 @@ int cgs_conv_patch_launch(const CgsLayer& L, bool dirT, int B, const float* in, 
     const size_t need = cgs_conv_patch_ws_floats(L, dirT) * sizeof(float);
     if (!ws || ws_bytes < need) return cgs_set_error(CGS_EWORKSPACE, "conv_patch: workspace %zu < %zu bytes", ws_bytes, need);
     if ((long)B * p.Hin * p.Win * p.Cred * 4 > 0x7fffffffL) return cgs_set_error(CGS_EINVAL, "conv_patch: input exceeds 2 GiB");
+    const int rp2 = patch2_rp(L, dirT);
+    if (rp2) {
+        if (!prepacked) {
+            hipLaunchKernelGGL(pack_patch2_weights_kernel, dim3(cgs_ceil_div(L.kh * rp2 * p.Np, 256)), dim3(256), 0, s, w, ws, L.kh, rp2,
+                               L.kw * p.Cred, p.N, p.Np);
+            CGS_CHECK_LAUNCH("pack_patch2_weights");
+        }
+        const bool auxp = epilogue >= CGS_EPI_RELU_BWD_AFFINE;
+        const size_t smem2 = ((size_t)2 * p.PH * p.pitch + (auxp ? (size_t)4 * 32 * 36 : 0)) * sizeof(float);
+        static bool done2 = false;
+        if (!done2) {
+            (void)hipFuncSetAttribute((const void*)conv_patch2_kernel<5, 16, 15, 8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+            (void)hipFuncSetAttribute((const void*)conv_patch2_kernel<5, 16, 15, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+            done2 = true;
+        }
+        if (smem2 > 96 * 1024 || p.PH * p.PW * p.Cred > 8 * 256) return cgs_set_error(CGS_EINVAL, "conv_patch: patch too large");
+        const long tiles2 = (long)B * (p.Hout / TR) * (p.Wout / TC) * (p.Np / PBN);
+        if (tiles2 == 0) return CGS_OK;
+        if (tiles2 > 0x7fffffffL) return cgs_set_error(CGS_EINVAL, "conv_patch: grid too large");
+        const long slots = auxp ? 512 : 768;          // persistent blocks: two (aux-prefetch form) or three per CU
+        long per2 = (tiles2 + slots - 1) / slots;
+        if (per2 < 4) per2 = tiles2 >= 4 * 256 ? 4 : 1;
+        const unsigned nblk2 = (unsigned)((tiles2 + per2 - 1) / per2);
+        if (auxp) hipLaunchKernelGGL((conv_patch2_kernel<5, 16, 15, 8, true>), dim3(nblk2), dim3(256), smem2, s, p, (int)tiles2, (int)per2);
+        else hipLaunchKernelGGL((conv_patch2_kernel<5, 16, 15, 8, false>), dim3(nblk2), dim3(256), smem2, s, p, (int)tiles2, (int)per2);
+        CGS_CHECK_LAUNCH("conv_patch2");
+        cgs_note_kernel(auxp ? "conv_patch2_kernel<5, 16, 15, 8, true>" : "conv_patch2_kernel<5, 16, 15, 8, false>");
+        return CGS_OK;
+    }
     if (!prepacked) {
         if (dirT)
             hipLaunchKernelGGL(pack_patch_weights_T_kernel, dim3(cgs_ceil_div(p.Kp * p.Np, 256)), dim3(256), 0, s, w, ws, L.kh, L.kw, L.Cb,

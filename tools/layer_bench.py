@@ -25,19 +25,48 @@ def timeit(fn, n=int(os.environ.get("LB_ITERS", "5"))):
     return e0.elapsed_time(e1) / n
 
 
+# LB_SLAB=1: carve every activation tensor from ONE big allocation at 2 MiB-aligned offsets (placement / page-size experiment)
+_slab = torch.empty(6 << 30, dtype=torch.uint8, device=d) if os.environ.get("LB_SLAB") else None
+_off = [0]
+
+
+def alloc(*shape):
+    if _slab is None:
+        return torch.empty(shape, device=d)
+    n = 4
+    for v in shape: n *= v
+    o = _off[0]; _off[0] = (o + n + (2 << 20) - 1) // (2 << 20) * (2 << 20)
+    return _slab[o:o + n].view(torch.float32).view(shape)
+
+
 tot = 0.0
 for H, Ci, Co in convs:
-    x = torch.randn(B, H, H, Ci, device=d); w = torch.randn(5, 5, Ci, Co, device=d) * 0.02; b = torch.zeros(Co, device=d)
-    y = K.conv2d_fwd(x, w, b); dy = torch.randn_like(y)
+    x = alloc(B, H, H, Ci).normal_(); w = torch.randn(5, 5, Ci, Co, device=d) * 0.02; b = torch.zeros(Co, device=d)
+    y = K.conv2d_fwd(x, w, b, out=alloc(B, H // 2, H // 2, Co)); dy = alloc(*y.shape).normal_()
     fl = 2.0 * B * (H // 2) ** 2 * Co * 25 * Ci
     t1 = timeit(lambda: K.conv2d_fwd(x, w, b, out=y)); t2 = timeit(lambda: K.conv2d_bwd_data(dy, w, (H, H), out=x))
     print(f"conv   {H:3d}x{H:<3d} {Ci:4d}->{Co:<4d} fwd {t1:8.3f} ms {fl/t1/1e9:7.1f} TF | bwd {t2:8.3f} ms {fl/t2/1e9:7.1f} TF")
     tot += t1 + t2
 for H, Ci, Co in deconvs:
-    x = torch.randn(B, H, H, Ci, device=d); w = torch.randn(5, 5, Co, Ci, device=d) * 0.02; b = torch.zeros(Co, device=d)
-    y = K.deconv2d_fwd(x, w, b, (2 * H, 2 * H)); dy = torch.randn_like(y)
+    x = alloc(B, H, H, Ci).normal_(); w = torch.randn(5, 5, Co, Ci, device=d) * 0.02; b = torch.zeros(Co, device=d)
+    y = K.deconv2d_fwd(x, w, b, (2 * H, 2 * H), out=alloc(B, 2 * H, 2 * H, Co)); dy = alloc(*y.shape).normal_()
     fl = 2.0 * B * H * H * Ci * 25 * Co
     t1 = timeit(lambda: K.deconv2d_fwd(x, w, b, (2 * H, 2 * H), out=y)); t2 = timeit(lambda: K.deconv2d_bwd_data(dy, w, (H, H), out=x))
     print(f"deconv {H:3d}x{H:<3d} {Ci:4d}->{Co:<4d} fwd {t1:8.3f} ms {fl/t1/1e9:7.1f} TF | bwd {t2:8.3f} ms {fl/t2/1e9:7.1f} TF")
     tot += t1 + t2
 print(f"sum fwd+bwd of all conv-family layers: {tot:.2f} ms for B={B}")
+if os.environ.get("LB_EPI"):
+    # the 3-channel layers with the epilogues the refinement engine really fuses into them
+    H = s
+    x = torch.randn(B, H, H, 3, device=d).tanh(); w = torch.randn(5, 5, 3, 64, device=d) * 0.02; b = torch.zeros(64, device=d)
+    y = K.conv2d_fwd(x, w, b, 2, 2, lib.EPI_LRELU); dy = torch.randn_like(y); dxs = torch.empty_like(x)
+    t1 = timeit(lambda: K.conv2d_fwd(x, w, b, 2, 2, lib.EPI_LRELU, out=y))
+    t2 = timeit(lambda: K.conv2d_bwd_data(dy, w, (H, H), out=dxs, epilogue=lib.EPI_TANH_BWD, ep_aux=x))
+    print(f"d_h0 conv {H}x{H} 3->64: fwd+lrelu {t1*1e3:7.1f} us ({lib.last_kernel()}) | bwd-data+tanh' {t2*1e3:7.1f} us")
+    H2 = s // 2
+    xg = torch.randn(B, H2, H2, 64, device=d).relu(); wg = torch.randn(5, 5, 3, 64, device=d) * 0.02; bg = torch.zeros(3, device=d)
+    a = torch.rand(64, device=d) + 0.5
+    img = K.deconv2d_fwd(xg, wg, bg, (H, H), 2, 2, lib.EPI_TANH); dimg = torch.randn_like(img); dxg = torch.empty_like(xg)
+    t3 = timeit(lambda: K.deconv2d_fwd(xg, wg, bg, (H, H), 2, 2, lib.EPI_TANH, out=img))
+    t4 = timeit(lambda: K.deconv2d_bwd_data(dimg, wg, (H2, H2), 2, 2, out=dxg, epilogue=lib.EPI_RELU_BWD_AFFINE, ep_a=a, ep_aux=xg))
+    print(f"g_h4 deconv {H2}x{H2} 64->3: fwd+tanh {t3*1e3:7.1f} us | bwd-data+relu'*a {t4*1e3:7.1f} us ({lib.last_kernel()})")
