@@ -155,15 +155,25 @@ __global__ __launch_bounds__(256) void convt_quad_mfma_kernel(QuadParams p) {
 // Persistent: a block copies the packed weights to LDS ONCE and walks a contiguous run of tiles (image-major: the tiles of an
 // image follow each other, so their halo rows are re-read from this CU's L1 / this XCD's L2 instead of from HBM); the patch
 // pipeline runs across tile boundaries (chunk 0 of the next tile is fetched under the last chunk's MFMAs of this one).
-template <int NPAD, int TW>   // NPAD = N (<= 4); TW = tile width in quads (32 or 16), tile height 256 / TW
+// tanh(x) = 1 - 2 / (exp(2x) + 1) on the hardware exp2 / rcp (5 VALU ops; ocml's tanhf is ~25, and every VALU op of this epilogue
+// costs matrix time on its SIMD): absolute error <= 2.4e-7 over the whole range (1 ulp of exp2 and rcp at results <= 1), +-1 at +-inf
+__device__ __forceinline__ float fast_tanh(float x) {
+    const float t = __builtin_amdgcn_exp2f(x * 2.885390081777927f);      // exp(2x); inf for large x -> rcp 0 -> 1, 0 for very negative x -> -1
+    return 1.f - 2.f * __builtin_amdgcn_rcpf(t + 1.f);
+}
+
+// NYX = 3: the 3 x 3 neighbourhood of a 5 x 5 (or 4 x 4) stride-2 layer at compile time -- every LDS fragment address is then the
+// lane's base plus an instruction immediate; NYX = 0: neighbourhood from the parameters.
+template <int NPAD, int TW, int NYX>   // NPAD = N (<= 4); TW = tile width in quads (32 or 16), tile height 256 / TW
 __global__ __launch_bounds__(256, 2) void convt_quad_lds_kernel(QuadParams p, int tiles_total, int tiles_per_block) {
     constexpr int TH = 256 / TW;
     constexpr int QR = TH / 4;                              // quad rows per wave (2 or 4)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, i = lane & 15;
-    const int K = p.ny * p.nx * p.Cs;
-    const int PH = TH + p.ny - 1, PW = TW + p.nx - 1;      // patch rows / cols (pixels)
+    const int ny = NYX ? NYX : p.ny, nx = NYX ? NYX : p.nx;
+    const int K = ny * nx * p.Cs;
+    const int PH = TH + ny - 1, PW = TW + nx - 1;          // patch rows / cols (pixels)
     const int patch_f4 = PH * PW * 4;                      // float4 per 16-channel patch
     float* Bs = smem;                                      // [K/4][16][4]
     float* Ps = smem + (size_t)K * 16;                     // [2][PH][PW][16]
@@ -179,31 +189,39 @@ __global__ __launch_bounds__(256, 2) void convt_quad_lds_kernel(QuadParams p, in
         (void*)p.in, 0, (int)((unsigned)p.B * (unsigned)p.Hs * (unsigned)p.Ws * (unsigned)p.Cs * 4u), 0x00020000);
     constexpr int PL = 6;                                  // float4 staged per thread: ceil(10*34*4 / 256), ceil(18*18*4 / 256)
     f32x4 st[PL];
-    int l_rel[PL];                                         // this thread's patch elements: (patch row << 16 | patch col << 2 | c4), -1 = none
+    int l_pr[PL], l_pc[PL];                                // this thread's patch elements (pixel row / col inside the patch), -2^20 = none
+    unsigned l_src[PL];                                    // ... and their byte offset relative to the patch origin pixel, chunk 0
 #pragma unroll
     for (int u = 0; u < PL; ++u) {
         const int q = tid + 256 * u;
         const int pixel = q >> 2;
         const int pr = pixel / PW, pc = pixel - pr * PW;
-        l_rel[u] = q < patch_f4 ? (pr << 16) | (pc << 2) | (q & 3) : -1;
+        l_pr[u] = q < patch_f4 ? pr : -(1 << 20); l_pc[u] = pc;
+        l_src[u] = (unsigned)(((pr * p.Ws + pc) * p.Cs + (q & 3) * 4) * 4);
     }
     const int nchunk = p.Cs >> 4;
+    unsigned okmask = 0;                                   // bit u: element u of the CURRENTLY LOADING tile lies inside the image
 #define TILE_DECODE(t_, b_, r0_, c0_)                                                                       \
     do {                                                                                                    \
         b_ = (t_) / tpi;                                                                                    \
         const int trem_ = (t_) - b_ * tpi;                                                                  \
         r0_ = (trem_ / tiles_x) * TH; c0_ = (trem_ - (trem_ / tiles_x) * tiles_x) * TW;                     \
     } while (0)
+    // validity of this thread's elements for the tile at (r0_, c0_): once per tile, not per chunk
+#define PATCH_VALID(r0_, c0_)                                                                              \
+    do {                                                                                                    \
+        okmask = 0;                                                                                         \
+        _Pragma("unroll") for (int u = 0; u < PL; ++u)                                                      \
+            if ((unsigned)((r0_) + l_pr[u] + p.dmin_y) < (unsigned)p.Hs && (unsigned)((c0_) + l_pc[u] + p.dmin_x) < (unsigned)p.Ws) okmask |= 1u << u; \
+    } while (0)
 #define LOAD_PATCH(b_, r0_, c0_, ch_)                                                                      \
-    _Pragma("unroll") for (int u = 0; u < PL; ++u) {                                                       \
-        unsigned off = 0xFFFFFFF0u;                                                                        \
-        if (l_rel[u] >= 0) {                                                                               \
-            const int iy = (r0_) + (l_rel[u] >> 16) + p.dmin_y, ix = (c0_) + ((l_rel[u] >> 2) & 0x3fff) + p.dmin_x; \
-            if ((unsigned)iy < (unsigned)p.Hs && (unsigned)ix < (unsigned)p.Ws)                            \
-                off = (unsigned)((((b_) * p.Hs + iy) * p.Ws + ix) * p.Cs + (ch_) * 16 + (l_rel[u] & 3) * 4) * 4u; \
-        }                                                                                                  \
-        st[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, off, 0, 0));      \
-    }
+    do {                                                                                                    \
+        const unsigned org_ = (unsigned)(((((b_) * p.Hs + (r0_) + p.dmin_y) * p.Ws + (c0_) + p.dmin_x) * p.Cs + (ch_) * 16) * 4);   /* scalar */ \
+        _Pragma("unroll") for (int u = 0; u < PL; ++u) {                                                    \
+            const unsigned off = (okmask >> u) & 1u ? org_ + l_src[u] : 0xFFFFFFF0u;                        \
+            st[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, off, 0, 0));   \
+        }                                                                                                   \
+    } while (0)
 #define STORE_PATCH(buf_)                                                                                  \
     _Pragma("unroll") for (int u = 0; u < PL; ++u) {                                                       \
         const int q = tid + 256 * u;                                                                       \
@@ -212,6 +230,7 @@ __global__ __launch_bounds__(256, 2) void convt_quad_lds_kernel(QuadParams p, in
 
     int b, r0, c0;
     TILE_DECODE(t_begin, b, r0, c0);
+    PATCH_VALID(r0, c0);
     LOAD_PATCH(b, r0, c0, 0);
     STORE_PATCH(0);
     __syncthreads();
@@ -232,12 +251,14 @@ __global__ __launch_bounds__(256, 2) void convt_quad_lds_kernel(QuadParams p, in
             const bool fetch = !last || more;                               // next chunk of this tile, or chunk 0 of the next tile
             if (fetch) {
                 if (!last) { LOAD_PATCH(b, r0, c0, ch + 1); }
-                else { LOAD_PATCH(nb, nr0, nc0, 0); }
+                else { PATCH_VALID(nr0, nc0); LOAD_PATCH(nb, nr0, nc0, 0); }
             }
             const float* P = Ps + (size_t)buf * patch_f4 * 4;
-            for (int a = 0; a < p.ny; ++a)
-                for (int bq = 0; bq < p.nx; ++bq) {
-                    const int it = (a * p.nx + bq) * nchunk + ch;          // k-quad group index of (neighbour, chunk)
+#pragma unroll
+            for (int a = 0; a < ny; ++a)
+#pragma unroll
+                for (int bq = 0; bq < nx; ++bq) {
+                    const int it = (a * nx + bq) * nchunk + ch;            // k-quad group index of (neighbour, chunk)
                     const f32x4 fb = *(const f32x4*)(Bs + ((size_t)(it * 4 + g) * 16 + i) * 4);
                     f32x4 fa[4];
 #pragma unroll
@@ -284,7 +305,7 @@ __global__ __launch_bounds__(256, 2) void convt_quad_lds_kernel(QuadParams p, in
             f32x4 v = *(const f32x4*)(E + yr * rowf + xq * 4);
             if (p.epilogue == CGS_EPI_TANH) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
+                for (int e = 0; e < 4; ++e) v[e] = fast_tanh(v[e]);
             } else if (p.epilogue == CGS_EPI_LRELU) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.2f * v[e]);
@@ -303,6 +324,7 @@ __global__ __launch_bounds__(256, 2) void convt_quad_lds_kernel(QuadParams p, in
         b = nb; r0 = nr0; c0 = nc0;
     }
 #undef TILE_DECODE
+#undef PATCH_VALID
 #undef LOAD_PATCH
 #undef STORE_PATCH
 }
@@ -358,6 +380,7 @@ int cgs_convt_quad_launch(const CgsLayer& L, int B, const float* in, const float
     // needs 16-byte aligned output rows
     if (p.ny <= 3 && p.nx <= 3 && ((2 * L.Ws * L.Cb) % 4) == 0 && ((32 * L.Cb) % 4) == 0) {
         const bool wide = (L.Ws % 32) == 0 && (L.Hs % 8) == 0;
+        const bool nyx3 = p.ny == 3 && p.nx == 3;
         const int TWr = wide ? 32 : 16, THr = 256 / TWr;
         const int PH = THr + p.ny - 1, PW = TWr + p.nx - 1;
         const size_t smem = need + (size_t)2 * PH * PW * 16 * sizeof(float);
@@ -367,19 +390,20 @@ int cgs_convt_quad_launch(const CgsLayer& L, int B, const float* in, const float
         long per = (tiles + 511) / 512;
         if (per < 4) per = tiles >= 4 * 256 ? 4 : 1;
         const long blocks = (tiles + per - 1) / per;
-#define QUAD_LDS_LAUNCH(NN, TT)                                                                                    \
+#define QUAD_LDS_LAUNCH(NN, TT, YX)                                                                                \
     {                                                                                                              \
         static bool done_ = false;                                                                                 \
         if (!done_) {                                                                                              \
-            hipError_t e = hipFuncSetAttribute((const void*)convt_quad_lds_kernel<NN, TT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            hipError_t e = hipFuncSetAttribute((const void*)convt_quad_lds_kernel<NN, TT, YX>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
             if (e != hipSuccess) return cgs_set_error(CGS_ELAUNCH, "convt_quad_lds smem attr: %s", hipGetErrorString(e)); \
             done_ = true;                                                                                          \
         }                                                                                                          \
-        hipLaunchKernelGGL((convt_quad_lds_kernel<NN, TT>), dim3((unsigned)blocks), dim3(256), smem, s, p, (int)tiles, (int)per); \
+        hipLaunchKernelGGL((convt_quad_lds_kernel<NN, TT, YX>), dim3((unsigned)blocks), dim3(256), smem, s, p, (int)tiles, (int)per); \
     }
 #define QUAD_LDS_CASE(NN)                                                                                          \
     case NN:                                                                                                       \
-        if (wide) QUAD_LDS_LAUNCH(NN, 32) else QUAD_LDS_LAUNCH(NN, 16)                                             \
+        if (wide && nyx3) QUAD_LDS_LAUNCH(NN, 32, 3) else if (wide) QUAD_LDS_LAUNCH(NN, 32, 0)                     \
+        else if (nyx3) QUAD_LDS_LAUNCH(NN, 16, 3) else QUAD_LDS_LAUNCH(NN, 16, 0)                                  \
         break;
         if (smem <= 160 * 1024 && (size_t)4 * 256 * L.Cb <= (size_t)2 * PH * PW * 16) {
             switch (L.Cb) {
@@ -390,7 +414,7 @@ int cgs_convt_quad_launch(const CgsLayer& L, int B, const float* in, const float
 #undef QUAD_LDS_LAUNCH
             CGS_CHECK_LAUNCH("convt_quad_lds");
             static thread_local char name[48];
-            snprintf(name, sizeof(name), "convt_quad_lds_kernel<%d, %d>", L.Cb, TWr);       // as rocprofv3 prints it
+            snprintf(name, sizeof(name), "convt_quad_lds_kernel<%d, %d, %d>", L.Cb, TWr, nyx3 ? 3 : 0);       // as rocprofv3 prints it
             cgs_note_kernel(name);
             return CGS_OK;
         }
