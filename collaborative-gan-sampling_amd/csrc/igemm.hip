@@ -214,6 +214,11 @@ __global__ __launch_bounds__(64 * NW, 2) void igemm_kernel(IgemmParams p) {
     const int m0 = mb * BM, n0 = nb * BN;
 
     const int tid = threadIdx.x;
+    // Plain VALU / memory instructions of a wave issue only in the gaps of the MFMA stream of the OTHER waves on its SIMD (the
+    // hardware arbitrates by priority, then age; in-kernel stamps: ~100 epilogue VALU ops take thousands of cycles next to a
+    // resident block in its K loop).  Prologue and epilogue therefore run at priority 3 and the K loop below them: the short
+    // phases finish at once and cost the matrix stream a few cycles per instruction.
+    __builtin_amdgcn_s_setprio(3);
 #ifdef CGS_DIAG_STAMPS      // diagnostic build only (tools/clock_probe.py): per-block timeline stamps into the workspace tail
     const bool stamp = p.slab != nullptr && p.splitk == 1 && tid == 0;
     unsigned long long sr_in = 0;
@@ -510,17 +515,18 @@ __global__ __launch_bounds__(64 * NW, 2) void igemm_kernel(IgemmParams p) {
     // or not) resident blocks the oldest runs ahead and finishes first, and the launch ends with one block per CU that
     // has most of its work left and nobody to hide its latencies.  Every block therefore starts at priority 3 and steps down as
     // it passes fixed fractions of its own K loop: leaders wait for the laggards at each step and all finish together.
-    int pt1 = 1 << 30, pt2 = 1 << 30, pt3 = 1 << 30;
+    int pt1 = 1 << 30, pt2 = 1 << 30;
     if (p.prio_t[0] > 0) {
         const int span = nk - kbeg;
-        pt1 = kbeg + ((span * p.prio_t[0]) >> 8); pt2 = kbeg + ((span * p.prio_t[1]) >> 8); pt3 = kbeg + ((span * p.prio_t[2]) >> 8);
-        __builtin_amdgcn_s_setprio(3);
+        pt1 = kbeg + ((span * p.prio_t[0]) >> 8); pt2 = kbeg + ((span * p.prio_t[1]) >> 8);
+        __builtin_amdgcn_s_setprio(2);               // steps 2 -> 1 -> 0 -> 0 (3 is kept for prologues / epilogues)
+    } else {
+        __builtin_amdgcn_s_setprio(0);
     }
 #define PRIO_STEP(kt_)                                                                                          \
     if ((kt_) >= pt1) {        /* (scalar compares; one s_setprio when a threshold is crossed) */               \
-        if ((kt_) >= pt3) { __builtin_amdgcn_s_setprio(0); pt1 = 1 << 30; }                                     \
-        else if ((kt_) >= pt2) { __builtin_amdgcn_s_setprio(1); pt1 = pt3; }                                    \
-        else { __builtin_amdgcn_s_setprio(2); pt1 = pt2; }                                                      \
+        if ((kt_) >= pt2) { __builtin_amdgcn_s_setprio(0); pt1 = 1 << 30; }                                     \
+        else { __builtin_amdgcn_s_setprio(1); pt1 = pt2; }                                                      \
     }
 
     // Software-pipelined across the barrier (the 32-deep VEC kernels: two blocks per CU, i.e. two waves per SIMD, which cannot
@@ -671,7 +677,7 @@ __global__ __launch_bounds__(64 * NW, 2) void igemm_kernel(IgemmParams p) {
 #undef LOAD_TILE
 #undef STORE_TILE
 #undef DECODE_ROW
-    if (p.prio_t[0] > 0) __builtin_amdgcn_s_setprio(3);      // retire quickly: the slot is what the next block (or kernel) is waiting for
+    __builtin_amdgcn_s_setprio(3);      // epilogue: retire quickly, the slot is what the next block (or kernel) is waiting for
     // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
     if (p.splitk > 1) {      // raw partial tile -> slab[class][split][m][Np]; bias / epilogue happen in the reduce kernel
         float* slab = p.slab + c.slab_off + (size_t)blockIdx.z * M * p.Np;
@@ -994,7 +1000,7 @@ int cgs_igemm_launch(const IgemmParams& p_in, void* slab, size_t slab_bytes, hip
         // (a) measured per layer at batch 1024: +2..4 % on every pixel-major layer (one or two rounds of 128x128 / 128x64 blocks),
         // -3 % on the transposed 128x64 layers with their 8192 short blocks (a fresh block at priority 3 starves the ones about
         // to finish), neutral elsewhere -> pixel-major launches only
-        if (vec && !deep && p.splitk == 1 && p.pix_major && total_blocks >= 256) { p.prio_t[0] = 64; p.prio_t[1] = 128; p.prio_t[2] = 192; }
+        if (vec && !deep && p.splitk == 1 && p.pix_major && total_blocks >= 256) { p.prio_t[0] = 85; p.prio_t[1] = 170; p.prio_t[2] = 0; }
         const int nblk_n = p.Np / bn_sel;
         if (one_round && p.lpt && p.nclasses == 1 && p.B / 128 == 8 && (32 % nblk_n) == 0) {
             const IgemmClass& c = p.cls[0];
