@@ -67,7 +67,7 @@ static int choose_family(const CgsLayer& L, bool dirT, int B, int epilogue, bool
 
 static int run_dir(const CgsLayer& L, bool dirT, int B, const float* in, const float* w, const float* bias, float* out,
                    int epilogue, const float* ep_a, const float* ep_b, const float* ep_aux, void* ws, size_t ws_bytes,
-                   int prepacked, hipStream_t s, const char* who) {
+                   int prepacked, hipStream_t s, const char* who, float* stat_part = nullptr) {
     cgs_note_flops(0.0);
     if (B <= 0) return cgs_set_error(CGS_EINVAL, "%s: B=%d", who, B);
     if (!in || !w || !out) return cgs_set_error(CGS_EINVAL, "%s: null tensor", who);
@@ -78,7 +78,9 @@ static int run_dir(const CgsLayer& L, bool dirT, int B, const float* in, const f
     if (dirT && (L.sh > 2 || L.sw > 2)) return cgs_set_error(CGS_EINVAL, "%s: transposed direction supports stride <= 2", who);
     const bool rest_al = !(((uintptr_t)out & 15) || ((uintptr_t)bias & 15) || ((uintptr_t)ep_a & 15) || ((uintptr_t)ep_b & 15) ||
                            ((uintptr_t)ep_aux & 15));
-    switch (choose_family(L, dirT, B, epilogue, ws != nullptr, ws_bytes, !((uintptr_t)in & 15), !((uintptr_t)ws & 15), rest_al)) {
+    const int fam = choose_family(L, dirT, B, epilogue, ws != nullptr, ws_bytes, !((uintptr_t)in & 15), !((uintptr_t)ws & 15), rest_al);
+    if (stat_part && fam != CGS_FAMILY_IGEMM) return cgs_set_error(CGS_EINVAL, "%s: fused statistics are an implicit-GEMM feature (see cgs_conv_stat_partials)", who);
+    switch (fam) {
         case CGS_FAMILY_QUAD:
             return cgs_convt_quad_launch(L, B, in, w, bias, out, epilogue, ep_a, ep_aux, (float*)ws, ws_bytes, prepacked, s);
         case CGS_FAMILY_SMALLN_T:
@@ -91,6 +93,7 @@ static int run_dir(const CgsLayer& L, bool dirT, int B, const float* in, const f
     }
     IgemmParams p;
     p.in = in; p.bias = bias; p.ep_a = ep_a; p.ep_b = ep_b; p.ep_aux = ep_aux; p.out = out; p.B = B; p.epilogue = epilogue;
+    p.stat_part = stat_part;
     if (dirT) cgs_geom_T(L, p); else cgs_geom_F(L, p);
     const size_t need = cgs_packed_floats(p) * sizeof(float);
     if (!ws || ws_bytes < need) return cgs_set_error(CGS_EWORKSPACE, "%s: workspace %zu < %zu bytes", who, ws_bytes, need);
@@ -107,6 +110,7 @@ static int run_dir(const CgsLayer& L, bool dirT, int B, const float* in, const f
     const size_t per = in_img > out_img ? in_img : out_img;
     long chunk = (long)(0x7fffffffUL / per);
     if (chunk < 1) return cgs_set_error(CGS_EINVAL, "%s: one image exceeds 2 GiB", who);
+    if (stat_part && chunk < B) return cgs_set_error(CGS_EINVAL, "%s: fused statistics need the batch in one launch", who);
     for (long b0 = 0; b0 < B; b0 += chunk) {
         p.B = (int)(B - b0 < chunk ? B - b0 : chunk);
         p.in = in + (size_t)b0 * (in_img / 4);
@@ -139,7 +143,7 @@ size_t cgs_conv_ws_bytes_for(int op, int B, int H, int W, int Cin, int Cout, int
     else { L.Hs = H; L.Ws = W; L.Cs = Cin; L.Hb = H * sh; L.Wb = W * sw; L.Cb = Cout; }   // bound: output = stride * input
     if (dirT && (sh > 2 || sw > 2)) return packed;
     IgemmParams p;
-    p.B = B;
+    p.B = B; p.stat_part = nullptr;
     if (dirT) cgs_geom_T(L, p); else cgs_geom_F(L, p);
     return packed + cgs_igemm_splitk_bytes(p);
 }
@@ -186,6 +190,31 @@ int cgs_conv2d_nhwc_fwd(const float* x, const float* w, const float* bias, float
     int rc = make_layer(L, kh, kw, sh, sw, H, W, Cin, cgs_ceil_div(H, sh > 0 ? sh : 1), cgs_ceil_div(W, sw > 0 ? sw : 1), Cout, "conv2d_nhwc_fwd");
     if (rc) return rc;
     return run_dir(L, false, B, x, w, bias, y, epilogue, ep_a, ep_b, nullptr, ws, ws_bytes, ws_prepacked, (hipStream_t)stream, "conv2d_nhwc_fwd");
+}
+
+int cgs_conv_stat_partials(int B, int H, int W, int Cin, int Cout, int kh, int kw, int sh, int sw, size_t ws_bytes) {
+    CgsLayer L;
+    if (make_layer(L, kh, kw, sh, sw, H, W, Cin, cgs_ceil_div(H, sh > 0 ? sh : 1), cgs_ceil_div(W, sw > 0 ? sw : 1), Cout, "conv_stat_partials")) return 0;
+    if (B <= 0 || (Cout & 3) || choose_family(L, false, B, CGS_EPI_NONE, ws_bytes > 0, ws_bytes, true, true, true) != CGS_FAMILY_IGEMM) return 0;
+    const size_t per = (size_t)(L.Hb * L.Wb * L.Cb > L.Hs * L.Ws * L.Cs ? L.Hb * L.Wb * L.Cb : L.Hs * L.Ws * L.Cs) * 4;
+    if ((size_t)B * per > 0x7fffffffUL) return 0;                    // the entry point would split the batch
+    const long M = (long)B * L.Hs * L.Ws;
+    return (int)(2 * ((M + 127) / 128));                             // one partial row per (128-row tile, wave row)
+}
+
+int cgs_conv2d_nhwc_fwd_stats(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int Cin,
+                              int Cout, int kh, int kw, int sh, int sw, void* ws, size_t ws_bytes, int ws_prepacked,
+                              float* stat_part, size_t stat_part_bytes, void* stream) {
+    CgsLayer L;
+    int rc = make_layer(L, kh, kw, sh, sw, H, W, Cin, cgs_ceil_div(H, sh > 0 ? sh : 1), cgs_ceil_div(W, sw > 0 ? sw : 1), Cout, "conv2d_nhwc_fwd_stats");
+    if (rc) return rc;
+    const int G = cgs_conv_stat_partials(B, H, W, Cin, Cout, kh, kw, sh, sw, ws_bytes);
+    if (G == 0) return cgs_set_error(CGS_EINVAL, "conv2d_nhwc_fwd_stats: not available for this call (cgs_conv_stat_partials == 0)");
+    if (!stat_part || stat_part_bytes < (size_t)G * 2 * Cout * sizeof(float))
+        return cgs_set_error(CGS_EWORKSPACE, "conv2d_nhwc_fwd_stats: partials buffer %zu < %zu bytes", stat_part_bytes, (size_t)G * 2 * Cout * sizeof(float));
+    if ((uintptr_t)stat_part & 15) return cgs_set_error(CGS_EINVAL, "conv2d_nhwc_fwd_stats: partials buffer must be 16-byte aligned");
+    return run_dir(L, false, B, x, w, bias, y, CGS_EPI_NONE, nullptr, nullptr, nullptr, ws, ws_bytes, ws_prepacked, (hipStream_t)stream,
+                   "conv2d_nhwc_fwd_stats", stat_part);
 }
 
 int cgs_conv2d_nhwc_bwd_data(const float* dy, const float* w, float* dx, int B, int H, int W, int Cin, int Cout, int kh,

@@ -198,6 +198,20 @@ int cgs_bn_train_lrelu_fwd(const float* x, const float* gamma, const float* beta
     return CGS_OK;
 }
 
+int cgs_bn_train_lrelu_fwd_from_partials(const float* x, const float* part, int G, const float* gamma, const float* beta, float eps,
+                                         float leak, float* y, float* mean, float* invstd, int M, int C, void* ws, size_t ws_bytes,
+                                         void* stream) {
+    if (M <= 0 || C <= 0 || (C & 3) || G <= 0 || !part) return cgs_set_error(CGS_EINVAL, "bn fwd from partials: M=%d C=%d G=%d", M, C, G);
+    if (ws_bytes < cgs_bn_ws_bytes(M, C)) return cgs_set_error(CGS_EWORKSPACE, "bn fwd: workspace %zu < %zu", ws_bytes, cgs_bn_ws_bytes(M, C));
+    hipStream_t s = (hipStream_t)stream;
+    float* stat = (float*)ws + (size_t)BN_MAX_BLOCKS * 2 * C;
+    hipLaunchKernelGGL(bn_finalize_kernel<0>, dim3(cgs_ceil_div(C, 16)), dim3(256), 0, s, part, G, M, C, gamma, beta, eps, stat, mean, invstd);
+    const size_t n4 = (size_t)M * C / 4;
+    hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3(ew_blocks(n4)), dim3(256), 0, s, x, stat, leak, y, n4, C, n4);
+    CGS_CHECK_LAUNCH("bn_train_lrelu_fwd_from_partials");
+    return CGS_OK;
+}
+
 __global__ void bn_restat_kernel(const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
                                  const float* __restrict__ beta, float* __restrict__ stat, int C) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;

@@ -73,6 +73,7 @@ struct IgemmParams {
     int tap_parity;      // VEC K order visits the taps even offsets first, then odd, per axis (stride-2 F direction)
     int xcd_map;         // block id -> (XCD, local index) decode: an m-tile's n-tiles run on one XCD (see igemm_kernel)
     int lpt;             // pixel-major only: m-tiles visit the pixels in perm[] order (most valid taps first)
+    float* stat_part;    // != null: per-(m-tile, wave row) column sums / sums of squares of the output, [2 * m-tiles][2][N] (fused batch-norm statistics)
     int vec;             // the 32-channel-chunk K order / 16-byte row gathers apply: Cred % 32 == 0 and at most 16 taps per axis
     int prio_t[3];       // progress thresholds (1/256 of the block's K tiles) at which a block steps its wave priority down; 0 = off
     int nclasses;

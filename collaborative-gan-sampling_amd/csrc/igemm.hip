@@ -139,9 +139,9 @@ int cgs_pack_weights(const IgemmParams& p, const CgsLayer& L, bool dirT, const f
 // Row pass of the wide epilogue for ONE epilogue mode (compile-time): branch-free inner loops and a compact
 // instruction footprint.  (With the mode as a run-time switch inside the unrolled loops the epilogue was ~21k lines
 // of ISA with 1.6k branches and took 20 us per block, 10 % of the block's life.)
-template <int EPI, int ROWS, int RPP, int LDE>
+template <int EPI, int ROWS, int RPP, int LDE, bool ST = false>
 __device__ __forceinline__ void epilogue_rows(const IgemmParams& p, const float* E, const int* rowpix_tile, int rsub, int c4,
-                                              int n, f32x4 bias, f32x4 ea, f32x4 eb) {
+                                              int n, f32x4 bias, f32x4 ea, f32x4 eb, f32x4* sa = nullptr, f32x4* sb = nullptr) {
 #pragma unroll
     for (int it = 0; it < ROWS / RPP; ++it) {
         const int lrow = it * RPP + rsub;
@@ -155,6 +155,10 @@ __device__ __forceinline__ void epilogue_rows(const IgemmParams& p, const float*
 #pragma unroll
         for (int e = 0; e < 4; ++e) y[e] = epilogue_apply(v[e] + bias[e], EPI, ea[e], eb[e], aux[e]);
         *(f32x4*)(p.out + o) = y;
+        if (ST) {        // fused batch-norm statistics: this lane's 4 channels, summed over its rows
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { (*sa)[e] += y[e]; (*sb)[e] = fmaf(y[e], y[e], (*sb)[e]); }
+        }
     }
 }
 
@@ -713,6 +717,7 @@ __global__ __launch_bounds__(64 * NW, 2) void igemm_kernel(IgemmParams p) {
             if (p.epilogue == CGS_EPI_AFFINE_RELU) { ea = *(const f32x4*)(p.ep_a + n); eb = *(const f32x4*)(p.ep_b + n); }
             if (p.epilogue == CGS_EPI_RELU_BWD_AFFINE) ea = *(const f32x4*)(p.ep_a + n);
         }
+        f32x4 st_a = {0.f, 0.f, 0.f, 0.f}, st_b = {0.f, 0.f, 0.f, 0.f};
         // all waves are past the loop's final barrier: the K-loop buffers are dead (rowpix lives behind the staging area)
 #pragma unroll
         for (int ph = 0; ph < EH; ++ph) {
@@ -729,6 +734,9 @@ __global__ __launch_bounds__(64 * NW, 2) void igemm_kernel(IgemmParams p) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             if (n < p.N) {
                 const int* rp = rowpix + wm * (BM / 2) + ph * ER;
+                if (p.stat_part) {        // (only with CGS_EPI_NONE: the statistics are those of the stored tensor)
+                    epilogue_rows<CGS_EPI_NONE, ER, RPP, LDE, true>(p, E, rp, rsub, c4, n, bias, ea, eb, &st_a, &st_b);
+                } else
                 switch (p.epilogue) {     // wave-uniform; each case is one compact branch-free row loop
                     case CGS_EPI_NONE: epilogue_rows<CGS_EPI_NONE, ER, RPP, LDE>(p, E, rp, rsub, c4, n, bias, ea, eb); break;
                     case CGS_EPI_LRELU: epilogue_rows<CGS_EPI_LRELU, ER, RPP, LDE>(p, E, rp, rsub, c4, n, bias, ea, eb); break;
@@ -743,6 +751,20 @@ __global__ __launch_bounds__(64 * NW, 2) void igemm_kernel(IgemmParams p) {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+        }
+        if (p.stat_part) {
+            // Fused batch-norm statistics (the producing conv leaves per-block column sums; bn_finalize adds them in a fixed order
+            // in double): the lanes that share a column group differ in their row sub-group -> xor-shuffle tree over it (fixed
+            // order: deterministic), then one partial row per (m-tile, wave row): [2 * tile + wm][sum | sum of squares][N]
+#pragma unroll
+            for (int off = LPR; off < 64; off <<= 1)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { st_a[e] += __shfl_xor(st_a[e], off); st_b[e] += __shfl_xor(st_b[e], off); }
+            if (rsub == 0 && n < p.N) {
+                float* dst = p.stat_part + ((size_t)((m0 / BM) * 2 + wm) * 2) * p.N + n;
+                *(f32x4*)dst = st_a;
+                *(f32x4*)(dst + p.N) = st_b;
             }
         }
 #ifdef CGS_DIAG_STAMPS
@@ -929,8 +951,10 @@ int cgs_igemm_launch(const IgemmParams& p_in, void* slab, size_t slab_bytes, hip
         }
     if ((long)p.B * p.Hout * p.Wout * p.N * 4 > 0x7fffffffL || (long)p.B * p.Hin * p.Win * p.Cred * 4 > 0x7fffffffL)
         return cgs_set_error(CGS_EINVAL, "igemm: a tensor of one launch exceeds 2 GiB (the caller splits the batch)");
+    if (p.stat_part && (p.nclasses != 1 || (p.N & 3) || p.epilogue != CGS_EPI_NONE))
+        return cgs_set_error(CGS_EINVAL, "igemm: fused statistics need the forward direction, N %% 4 == 0 and no epilogue");
     {   // split-K for under-filled grids, if the caller's workspace has room for the partial slabs
-        const size_t need = cgs_igemm_splitk_bytes(p);
+        const size_t need = p.stat_part ? 0 : cgs_igemm_splitk_bytes(p);      // (the statistics come out of the one-pass epilogue)
         if (need && slab && slab_bytes >= need) {
             p.splitk = choose_splitk(p); p.slab = (float*)slab;
             size_t off = 0;

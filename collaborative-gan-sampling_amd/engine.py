@@ -55,8 +55,22 @@ class _Conv(_Stage):
         self.out = torch.empty((B, _same_out(H, stride), _same_out(W, stride), w.shape[3]), dtype=torch.float32, device=dev)
         self.dx = torch.empty((B,) + tuple(in_shape), dtype=torch.float32, device=dev)
 
+    part = None          # [G, 2, Cout]: per-block column sums of the output for the batch norm that follows (fused statistics)
+
+    def want_stats(self, B):
+        """Called by the batch-norm stage right above: have this conv leave the statistics partials, if the library can."""
+        import os
+        if os.environ.get("CGS_NO_FUSED_BN_STATS"):       # (A/B switch for measurements)
+            return None
+        G = K.conv_stat_partials((B,) + tuple(self.dx.shape[1:]), tuple(self.w.shape), self.s, self.s) if self.epi == L.EPI_NONE else 0
+        if G > 0:
+            self.part = torch.empty((G, 2, self.w.shape[3]), dtype=torch.float32, device=self.out.device)
+        return self.part
+
     def fwd(self, x):
         self.x_in = x
+        if self.part is not None:
+            return K.conv2d_fwd_stats(x, self.w, self.b, self.part, self.s, self.s, out=self.out)
         return K.conv2d_fwd(x, self.w, self.b, self.s, self.s, self.epi, out=self.out)
 
     def bwd(self, dy):
@@ -119,10 +133,12 @@ class _BnTrainLrelu(_Stage):
 
     sync = None          # a BnSync: the batch is one shard of a logical batch spread over the ranks of a process group
     groups = 1           # > 1: the engine batch is ``groups`` logical batches back to back, each with its OWN statistics
+    part = None          # the producing conv's statistics partials (fused: no statistics pass over the tensor here)
 
     def set_groups(self, groups):
         """Statistics per group of rows: the instance-norm kernels with one 'sample' = one logical batch."""
         self.groups = int(groups)
+        self.part = None                 # (whole-batch partials do not apply; the producing conv keeps writing them, unused)
         C = self.out.shape[-1]
         self.mean = torch.empty((self.groups, C), dtype=torch.float32, device=self.out.device)
         self.invstd = torch.empty((self.groups, C), dtype=torch.float32, device=self.out.device)
@@ -136,7 +152,10 @@ class _BnTrainLrelu(_Stage):
             K.instnorm_lrelu_fwd(self._g(x), self.gamma, self.beta, self.leak, out=self._g(self.out), stats=(self.mean, self.invstd))
             return self.out
         if self.sync is None:
-            K.bn_train_lrelu_fwd(x, self.gamma, self.beta, self.leak, out=self.out, stats=(self.mean, self.invstd))
+            if self.part is not None:
+                K.bn_train_lrelu_fwd_from_partials(x, self.part, self.gamma, self.beta, self.leak, out=self.out, stats=(self.mean, self.invstd))
+            else:
+                K.bn_train_lrelu_fwd(x, self.gamma, self.beta, self.leak, out=self.out, stats=(self.mean, self.invstd))
             return self.out
         M = x.numel() // x.shape[-1]
         sums = self.sync.sums(x.shape[-1], x.device)
@@ -308,7 +327,10 @@ def compile_layers(layers, in_shape, P, scope, B, k, stride, bn_training, dev):
             s = f"{scope}/{Lr[1]}"
             if bn_training:
                 leak, used = (K.LEAK, 2) if kind(i + 1) == "lrelu" else (1.0, 1)
-                stages.append(_BnTrainLrelu(B, shape, P[s + "/gamma"], P[s + "/beta"], leak, dev))
+                bn_stage = _BnTrainLrelu(B, shape, P[s + "/gamma"], P[s + "/beta"], leak, dev)
+                if stages and isinstance(stages[-1], _Conv):      # statistics ride on the producing conv's epilogue
+                    bn_stage.part = stages[-1].want_stats(B)
+                stages.append(bn_stage)
                 i += used
             else:
                 if kind(i + 1) != "relu":
@@ -431,6 +453,17 @@ class RefineEngine:
                     if isinstance(st, _Residual):
                         walk(st.inner)
             walk(self.d.stages); walk(self.g_tail.stages)
+
+        # per-group / synchronised statistics do not use the fused whole-batch partials: switch them off in the producing convs too
+        def drop_partials(stages):
+            for below, st in zip([None] + stages[:-1], stages):
+                if isinstance(st, _BnTrainLrelu) and (st.groups > 1 or st.sync is not None):
+                    st.part = None
+                    if isinstance(below, _Conv):
+                        below.part = None
+                if isinstance(st, _Residual):
+                    drop_partials(st.inner)
+        drop_partials(self.d.stages); drop_partials(self.g_tail.stages)
 
     # -- pieces (sampling/collaborator.py:26-39) ------------------------------------------------
     def input_to_feature(self, z):

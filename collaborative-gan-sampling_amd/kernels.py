@@ -152,6 +152,47 @@ def conv2d_fwd(x, w, bias, sh=2, sw=2, epilogue=L.EPI_NONE, ep_a=None, ep_b=None
     return y
 
 
+def conv_stat_partials(x_shape, w_shape, sh=2, sw=2):
+    """Partial rows G that ``conv2d_fwd_stats`` writes for this call (0: the fused statistics are not available for it)."""
+    B, H, W, Cin = x_shape
+    kh, kw, _, Cout = w_shape
+    _, nbytes = WS.plan(L.CONV_FWD, B, H, W, Cin, 0, 0, Cout, kh, kw, sh, sw, L.EPI_NONE)
+    return int(L.load().cgs_conv_stat_partials(B, H, W, Cin, Cout, kh, kw, sh, sw, nbytes))
+
+
+def conv2d_fwd_stats(x, w, bias, part, sh=2, sw=2, out=None):
+    """conv2d_fwd (no epilogue) that also leaves the per-block column sums / sums of squares of its output in ``part``
+    [G, 2, Cout] for the batch norm that follows (``bn_train_lrelu_fwd_from_partials``)."""
+    _chk(x, "x"); _chk(w, "w"); _chk(part, "part")
+    B, H, W, Cin = x.shape
+    kh, kw, Cin2, Cout = w.shape
+    if Cin2 != Cin:
+        raise L.CgsError(f"conv2d: weight Cin {Cin2} != input channels {Cin}")
+    y = out if out is not None else torch.empty((B, same_out(H, sh), same_out(W, sw), Cout), dtype=torch.float32, device=x.device)
+    ws, pre = WS.get(w, L.CONV_FWD, kh, kw, sh, sw, Cin, Cout, (B, H, W), L.EPI_NONE, ptrs=(_ptr(x), _ptr(bias), _ptr(y), _ptr(part)))
+    Ho, Wo = y.shape[1], y.shape[2]
+    pr = _Prof(2.0 * B * Ho * Wo * Cout * kh * kw * Cin, f"conv_fwd {H}x{W} {Cin}->{Cout}") if PROFILE is not None else None
+    L.call("cgs_conv2d_nhwc_fwd_stats", _ptr(x), _ptr(w), _ptr(bias), _ptr(y), B, H, W, Cin, Cout, kh, kw, sh, sw,
+           _ptr(ws), ws.numel() * 4, pre, _ptr(part), part.numel() * 4, _stream())
+    if pr is not None:
+        pr.done()
+    return y
+
+
+def bn_train_lrelu_fwd_from_partials(x, part, gamma, beta, leak=LEAK, eps=BN_EPS, out=None, stats=None):
+    """bn_train_lrelu_fwd whose statistics pass is replaced by the partial sums of the producing conv."""
+    _chk(x, "x")
+    C = x.shape[-1]
+    M = x.numel() // C
+    y = out if out is not None else torch.empty_like(x)
+    mean, invstd = stats if stats is not None else (torch.empty(C, dtype=torch.float32, device=x.device),
+                                                    torch.empty(C, dtype=torch.float32, device=x.device))
+    ws = _bn_workspace(M, C, x.device)
+    L.call("cgs_bn_train_lrelu_fwd_from_partials", _ptr(x), _ptr(part), part.shape[0], _ptr(gamma), _ptr(beta), eps, leak, _ptr(y),
+           _ptr(mean), _ptr(invstd), M, C, _ptr(ws), ws.numel() * 4, _stream())
+    return y, mean, invstd
+
+
 def conv2d_bwd_data(dy, w, in_hw, sh=2, sw=2, out=None, epilogue=L.EPI_NONE, ep_a=None, ep_aux=None):
     """Input gradient of conv2d_fwd (Conv2DBackpropInput; sampling/collaborator.py:31).
     ``epilogue`` = one of the *_BWD modes folds the activation gradient of the layer below in."""

@@ -94,6 +94,17 @@ int cgs_conv2d_nhwc_fwd(const float* x, const float* w, const float* bias, float
                         int epilogue, const float* ep_a, const float* ep_b,
                         void* ws, size_t ws_bytes, int ws_prepacked, void* stream);
 
+/* The same conv (no fused epilogue) that also leaves per-block column sums of its OUTPUT -- sum and sum of squares per
+ * channel -- in stat_part[G][2][Cout], so the batch-statistics batch norm that follows it in D (nsgan/GAN.py:65 -> nsgan/ops.py:19-26)
+ * does not re-read the tensor for its statistics pass.  G = cgs_conv_stat_partials(...) (same B, H, W, ..., ws_bytes as the call);
+ * 0 = the fused form is not available for this call (another kernel family, Cout % 4 != 0, a batch the library would split):
+ * use cgs_conv2d_nhwc_fwd + cgs_bn_train_lrelu_fwd.  Deterministic (fixed reduction trees). */
+int cgs_conv_stat_partials(int B, int H, int W, int Cin, int Cout, int kh, int kw, int sh, int sw, size_t ws_bytes);
+int cgs_conv2d_nhwc_fwd_stats(const float* x, const float* w, const float* bias, float* y,
+                              int B, int H, int W, int Cin, int Cout, int kh, int kw, int sh, int sw,
+                              void* ws, size_t ws_bytes, int ws_prepacked,
+                              float* stat_part, size_t stat_part_bytes, void* stream);
+
 /* conv2d backward-data: dx[B,H,W,Cin] = d/dx of the conv above applied to dy[B,Ho,Wo,Cout].
  * Replaces the Conv2DBackpropInput node tf.gradients emits (sampling/collaborator.py:31).
  * epilogue: CGS_EPI_NONE or one of the *_BWD modes (ep_aux [B,H,W,Cin], ep_a [Cin]). */
@@ -133,6 +144,10 @@ size_t cgs_bn_ws_bytes(int M, int C);
 int cgs_bn_train_lrelu_fwd(const float* x, const float* gamma, const float* beta, float eps, float leak,
                            float* y, float* mean, float* invstd, int M, int C,
                            void* ws, size_t ws_bytes, void* stream);
+/*   fwd from the partial sums a cgs_conv2d_nhwc_fwd_stats call left (part[G][2][C]): statistics pass skipped. */
+int cgs_bn_train_lrelu_fwd_from_partials(const float* x, const float* part, int G, const float* gamma, const float* beta,
+                                         float eps, float leak, float* y, float* mean, float* invstd, int M, int C,
+                                         void* ws, size_t ws_bytes, void* stream);
 /*   bwd : dx = gamma*invstd*(dy' - mean(dy') - xhat*mean(dy'*xhat)), dy' = dy*lrelu'(bn(x)),
  *         the input gradient tf.gradients builds for the two ops (sampling/collaborator.py:31). */
 int cgs_bn_train_lrelu_bwd_data(const float* dy, const float* x, const float* gamma, const float* beta,

@@ -411,3 +411,41 @@ def test_many_block_grids_use_the_16_deep_variant(case):
         name = lib.last_kernel()
         close(got, x.grad, 2e-5)
         assert name == "igemm_kernel<128, 128, 4, true, 16, true>", name
+
+
+@pytest.mark.parametrize("B,H,Cin,Cout,k", [(64, 16, 32, 128, 5), (1024, 8, 64, 64, 5), (5, 6, 32, 64, 3), (130, 8, 32, 68, 4)])
+def test_conv_with_fused_bn_statistics(B, H, Cin, Cout, k):
+    """cgs_conv2d_nhwc_fwd_stats: the conv's output is unchanged, its per-block partial sums reduce to the per-channel sum and sum
+    of squares of that output, and cgs_bn_train_lrelu_fwd_from_partials gives the batch norm of the plain two-kernel path -- also on
+    pixel-major / balanced tile orders (B = 1024) and with ragged last tiles / channel counts off the 64 grid."""
+    from cgs_amd import kernels as K, lib
+    d = dev()
+    x, w, b = rnd((B, H, H, Cin), 1).to(d), rnd((k, k, Cin, Cout), 2, 0.05).to(d), rnd((Cout,), 3, 0.1).to(d)
+    G = K.conv_stat_partials(tuple(x.shape), tuple(w.shape), 2, 2)
+    assert G == 2 * ((B * (H // 2) ** 2 + 127) // 128)
+    part = torch.full((G, 2, Cout), float("nan"), device=d)
+    y = K.conv2d_fwd_stats(x, w, b, part, 2, 2)
+    assert lib.last_kernel().startswith("igemm_kernel")
+    y_plain = K.conv2d_fwd(x, w, b, 2, 2)
+    close(y, y_plain, 2e-6)          # (not bit-equal in general: small grids take the split-K path without the statistics)
+    close(y, R.conv2d(x.cpu(), w.cpu(), b.cpu(), 2, 2), 2e-5)
+    sums = part.double().sum(0)                                   # partial rows of tiles past M are never written: must not exist
+    assert torch.isfinite(sums).all()
+    flat = y.double().reshape(-1, Cout)
+    close(sums[0].float(), flat.sum(0).float(), 2e-5)
+    close(sums[1].float(), (flat * flat).sum(0).float(), 2e-5)
+    gamma, beta = (rnd((Cout,), 4, 0.2) + 1).to(d), rnd((Cout,), 5, 0.1).to(d)
+    got = K.bn_train_lrelu_fwd_from_partials(y, part, gamma, beta, 0.2)
+    want = K.bn_train_lrelu_fwd(y, gamma, beta, 0.2)
+    for a, c in zip(got, want):
+        close(a, c, 2e-6)
+    # determinism
+    part2 = torch.empty_like(part)
+    K.conv2d_fwd_stats(x, w, b, part2, 2, 2)
+    assert torch.equal(part, part2)
+
+
+def test_fused_statistics_not_offered_where_unsupported():
+    from cgs_amd import kernels as K
+    assert K.conv_stat_partials((8, 64, 64, 3), (5, 5, 3, 64), 2, 2) == 0       # the 3-channel patch kernel serves this conv
+    assert K.conv_stat_partials((8, 16, 16, 32), (5, 5, 32, 6), 2, 2) == 0      # Cout % 4 != 0
