@@ -259,12 +259,18 @@ def main():
     pools = [torch.empty((world * B * G,) + tuple(A["img"]), dtype=torch.float32, device=dev) if use_dist else None
              for _ in engines]                                           # one node-wide pool buffer per batch in flight
 
+    done_ev = []                                                        # one event per timed step, recorded on the step's stream (no host sync)
+
     def step(i):
         e, st = engines[i % len(engines)], streams[i % len(engines)]
         with torch.cuda.stream(st):
             img = e.refine_from_z(z[i], Ksteps, args.rate)[0]
             if use_dist:
                 dist.all_gather_into_tensor(pools[i % len(engines)], img)      # RCCL over xGMI: the refined sample pool
+            if i >= args.warmup - 1 and not os.environ.get("CGS_BENCH_NO_EVENTS"):
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record(st)
+                done_ev.append(ev)
         return img
 
     for i in range(args.warmup):
@@ -319,6 +325,10 @@ def main():
                        "hipgraph": bool(args.graph), "batches_in_flight": len(engines) * G, "fused_per_launch": G, "sync_bn": bool(args.sync_bn)},
             "algorithmic_tflops": round(value * flops_per_sample / 1e12, 2),
         }
+        ns = len(engines)
+        if len(done_ev) >= 3 * ns:   # SURVEY.md 8d "median of >= 10": median gap between a stream's consecutive step completions
+            gaps = sorted(a.elapsed_time(b) for a, b in zip(done_ev[:-ns], done_ev[ns:]))     # (GPU timestamps; the ns batches in flight
+            out["ms_per_step_median"] = round(gaps[len(gaps) // 2] / ns, 3)                    # finish together, so per stream, / ns)
         if prof:
             dom = max(prof.items(), key=lambda kv: sum(a.elapsed_time(b) for a, b in kv[1][1]))
             per = {}
