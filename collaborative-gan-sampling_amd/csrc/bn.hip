@@ -97,27 +97,30 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
 
 // MODE 0: -> stat = {mean, invstd, scale = gamma*invstd, shift = beta - mean*scale}; also mean/invstd outputs
 // MODE 1: -> stat2 = {mean(dy'), mean(dy'*xhat)}
-// Block = 16 channels x 16 slices of the G partials; each slice is summed in double in a fixed order and
-// the 16 slice sums are added in a fixed order -> deterministic, and G/16 loads deep instead of G.
+// Block = 8 channels x 32 slices of the G partials; each slice is summed in double in a fixed order and the 32 slice sums are
+// added in a fixed order -> deterministic, G/32 loads deep, C/8 blocks (the fused conv statistics bring G = 4096 partial rows for
+// the 16x16x128 layer: with 16 channels x 16 slices and C/16 = 8 blocks this kernel took 42 us there).
+#define BNF_CH 8
+#define BNF_SL 32
 template <int MODE>
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int G, int M, int C,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           float eps, float* __restrict__ stat, float* __restrict__ mean_out,
                                                           float* __restrict__ invstd_out) {
-    __shared__ double red[2][16][17];
+    __shared__ double red[2][BNF_SL][BNF_CH + 1];
     part += (size_t)blockIdx.y * G * 2 * C;
     stat += (size_t)blockIdx.y * (MODE == 0 ? 4 : 2) * C;
     if (MODE == 0) { mean_out += (size_t)blockIdx.y * C; invstd_out += (size_t)blockIdx.y * C; }
-    const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
-    const int c = blockIdx.x * 16 + cl;
+    const int cl = threadIdx.x % BNF_CH, sl = threadIdx.x / BNF_CH;
+    const int c = blockIdx.x * BNF_CH + cl;
     double a = 0.0, b = 0.0;
     if (c < C)
-        for (int g = sl; g < G; g += 16) { a += (double)part[((size_t)g * 2 + 0) * C + c]; b += (double)part[((size_t)g * 2 + 1) * C + c]; }
+        for (int g = sl; g < G; g += BNF_SL) { a += (double)part[((size_t)g * 2 + 0) * C + c]; b += (double)part[((size_t)g * 2 + 1) * C + c]; }
     red[0][sl][cl] = a; red[1][sl][cl] = b;
     __syncthreads();
     if (sl != 0 || c >= C) return;
     a = 0.0; b = 0.0;
-    for (int i = 0; i < 16; ++i) { a += red[0][i][cl]; b += red[1][i][cl]; }
+    for (int i = 0; i < BNF_SL; ++i) { a += red[0][i][cl]; b += red[1][i][cl]; }
     if (MODE == 0) {
         const double mean = a / M;
         double var = b / M - mean * mean;
@@ -191,7 +194,7 @@ int cgs_bn_train_lrelu_fwd(const float* x, const float* gamma, const float* beta
     float* part = (float*)ws;
     float* stat = part + (size_t)BN_MAX_BLOCKS * 2 * C;
     hipLaunchKernelGGL(bn_partial_kernel<0>, dim3(g.G), dim3(256), 0, s, x, nullptr, nullptr, leak, part, M, C, g.rows_per_block);
-    hipLaunchKernelGGL(bn_finalize_kernel<0>, dim3(cgs_ceil_div(C, 16)), dim3(256), 0, s, part, g.G, M, C, gamma, beta, eps, stat, mean, invstd);
+    hipLaunchKernelGGL(bn_finalize_kernel<0>, dim3(cgs_ceil_div(C, BNF_CH)), dim3(256), 0, s, part, g.G, M, C, gamma, beta, eps, stat, mean, invstd);
     const size_t n4 = (size_t)M * C / 4;
     hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3(ew_blocks(n4)), dim3(256), 0, s, x, stat, leak, y, n4, C, n4);
     CGS_CHECK_LAUNCH("bn_train_lrelu_fwd");
@@ -205,7 +208,7 @@ int cgs_bn_train_lrelu_fwd_from_partials(const float* x, const float* part, int 
     if (ws_bytes < cgs_bn_ws_bytes(M, C)) return cgs_set_error(CGS_EWORKSPACE, "bn fwd: workspace %zu < %zu", ws_bytes, cgs_bn_ws_bytes(M, C));
     hipStream_t s = (hipStream_t)stream;
     float* stat = (float*)ws + (size_t)BN_MAX_BLOCKS * 2 * C;
-    hipLaunchKernelGGL(bn_finalize_kernel<0>, dim3(cgs_ceil_div(C, 16)), dim3(256), 0, s, part, G, M, C, gamma, beta, eps, stat, mean, invstd);
+    hipLaunchKernelGGL(bn_finalize_kernel<0>, dim3(cgs_ceil_div(C, BNF_CH)), dim3(256), 0, s, part, G, M, C, gamma, beta, eps, stat, mean, invstd);
     const size_t n4 = (size_t)M * C / 4;
     hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3(ew_blocks(n4)), dim3(256), 0, s, x, stat, leak, y, n4, C, n4);
     CGS_CHECK_LAUNCH("bn_train_lrelu_fwd_from_partials");
@@ -233,7 +236,7 @@ int cgs_bn_train_lrelu_bwd_data(const float* dy, const float* x, const float* ga
     float* stat2 = stat + 4 * (size_t)C;                          // [2][C]
     hipLaunchKernelGGL(bn_restat_kernel, dim3(cgs_ceil_div(C, 128)), dim3(128), 0, s, mean, invstd, gamma, beta, stat, C);
     hipLaunchKernelGGL(bn_partial_kernel<1>, dim3(g.G), dim3(256), 0, s, x, dy, stat, leak, part, M, C, g.rows_per_block);
-    hipLaunchKernelGGL(bn_finalize_kernel<1>, dim3(cgs_ceil_div(C, 16)), dim3(256), 0, s, part, g.G, M, C, nullptr, nullptr, 0.f, stat2, nullptr, nullptr);
+    hipLaunchKernelGGL(bn_finalize_kernel<1>, dim3(cgs_ceil_div(C, BNF_CH)), dim3(256), 0, s, part, g.G, M, C, nullptr, nullptr, 0.f, stat2, nullptr, nullptr);
     const size_t n4 = (size_t)M * C / 4;
     hipLaunchKernelGGL(bn_apply_bwd_kernel, dim3(ew_blocks(n4)), dim3(256), 0, s, dy, x, stat, stat2, leak, dx, n4, C, n4);
     CGS_CHECK_LAUNCH("bn_train_lrelu_bwd_data");
@@ -398,7 +401,7 @@ int cgs_instnorm_lrelu_fwd(const float* x, const float* scale, const float* offs
     float* part = (float*)ws;
     float* stat = part + (size_t)B * g.G * 2 * C;
     hipLaunchKernelGGL(bn_partial_kernel<0>, dim3(g.G, B), dim3(256), 0, s, x, nullptr, nullptr, leak, part, HW, C, g.rows_per_block);
-    hipLaunchKernelGGL(bn_finalize_kernel<0>, dim3(cgs_ceil_div(C, 16), B), dim3(256), 0, s, part, g.G, HW, C, scale, offset, eps, stat, mean, invstd);
+    hipLaunchKernelGGL(bn_finalize_kernel<0>, dim3(cgs_ceil_div(C, BNF_CH), B), dim3(256), 0, s, part, g.G, HW, C, scale, offset, eps, stat, mean, invstd);
     const size_t n4 = (size_t)B * HW * C / 4, gn4 = (size_t)HW * C / 4;
     hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3(ew_blocks(n4)), dim3(256), 0, s, x, stat, leak, y, n4, C, gn4);
     CGS_CHECK_LAUNCH("instnorm_lrelu_fwd");
@@ -417,7 +420,7 @@ int cgs_instnorm_lrelu_bwd_data(const float* dy, const float* x, const float* sc
     float* stat2 = stat + (size_t)B * 4 * C;
     hipLaunchKernelGGL(bn_restat_kernel, dim3(cgs_ceil_div(C, 128), B), dim3(128), 0, s, mean, invstd, scale, offset, stat, C);
     hipLaunchKernelGGL(bn_partial_kernel<1>, dim3(g.G, B), dim3(256), 0, s, x, dy, stat, leak, part, HW, C, g.rows_per_block);
-    hipLaunchKernelGGL(bn_finalize_kernel<1>, dim3(cgs_ceil_div(C, 16), B), dim3(256), 0, s, part, g.G, HW, C, nullptr, nullptr, 0.f, stat2, nullptr, nullptr);
+    hipLaunchKernelGGL(bn_finalize_kernel<1>, dim3(cgs_ceil_div(C, BNF_CH), B), dim3(256), 0, s, part, g.G, HW, C, nullptr, nullptr, 0.f, stat2, nullptr, nullptr);
     const size_t n4 = (size_t)B * HW * C / 4, gn4 = (size_t)HW * C / 4;
     hipLaunchKernelGGL(bn_apply_bwd_kernel, dim3(ew_blocks(n4)), dim3(256), 0, s, dy, x, stat, stat2, leak, dx, n4, C, gn4);
     CGS_CHECK_LAUNCH("instnorm_lrelu_bwd_data");
