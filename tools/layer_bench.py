@@ -70,3 +70,21 @@ if os.environ.get("LB_EPI"):
     t3 = timeit(lambda: K.deconv2d_fwd(xg, wg, bg, (H, H), 2, 2, lib.EPI_TANH, out=img))
     t4 = timeit(lambda: K.deconv2d_bwd_data(dimg, wg, (H2, H2), 2, 2, out=dxg, epilogue=lib.EPI_RELU_BWD_AFFINE, ep_a=a, ep_aux=xg))
     print(f"g_h4 deconv {H2}x{H2} 64->3: fwd+tanh {t3*1e3:7.1f} us | bwd-data+relu'*a {t4*1e3:7.1f} us ({lib.last_kernel()})")
+if os.environ.get("LB_AUX"):
+    # the two implicit-GEMM layers whose backward-data carries an aux epilogue in the engine: with and without it
+    H = s // 2
+    w = torch.randn(5, 5, 64, 128, device=d) * 0.02
+    dy = torch.randn(B, H // 2, H // 2, 128, device=d); dx = torch.empty(B, H, H, 64, device=d); aux = torch.randn(B, H, H, 64, device=d)
+    t0 = timeit(lambda: K.conv2d_bwd_data(dy, w, (H, H), out=dx))
+    t1 = timeit(lambda: K.conv2d_bwd_data(dy, w, (H, H), out=dx, epilogue=lib.EPI_LRELU_BWD, ep_aux=aux))
+    print(f"d_h1 bwd-data 32x32 64<-128: plain {t0*1e3:7.1f} us | + lrelu' (aux) {t1*1e3:7.1f} us ({lib.last_kernel()})")
+    wg = torch.randn(5, 5, 64, 128, device=d) * 0.02          # g_h3: deconv 16x16x128 -> 32x32x64
+    dyg = torch.randn(B, H, H, 64, device=d); dxg = torch.empty(B, H // 2, H // 2, 128, device=d); auxg = torch.randn(B, H // 2, H // 2, 128, device=d)
+    a = torch.rand(128, device=d) + 0.5
+    t2 = timeit(lambda: K.deconv2d_bwd_data(dyg, wg, (H // 2, H // 2), 2, 2, out=dxg))
+    t3 = timeit(lambda: K.deconv2d_bwd_data(dyg, wg, (H // 2, H // 2), 2, 2, out=dxg, epilogue=lib.EPI_RELU_BWD_AFFINE, ep_a=a, ep_aux=auxg))
+    print(f"g_h3 bwd-data 16x16 128<-64: plain {t2*1e3:7.1f} us | + relu'*a (aux) {t3*1e3:7.1f} us ({lib.last_kernel()})")
+    xg = torch.randn(B, H // 2, H // 2, 128, device=d); bg = torch.zeros(64, device=d); yg = torch.empty(B, H, H, 64, device=d); cc = torch.zeros(64, device=d); a64 = torch.rand(64, device=d) + 0.5
+    t4 = timeit(lambda: K.deconv2d_fwd(xg, wg, bg, (H, H), 2, 2, out=yg))
+    t5 = timeit(lambda: K.deconv2d_fwd(xg, wg, bg, (H, H), 2, 2, lib.EPI_AFFINE_RELU, a64, cc, out=yg))
+    print(f"g_h3 fwd 16x16 128->64: plain {t4*1e3:7.1f} us | + bn-affine + relu {t5*1e3:7.1f} us")
