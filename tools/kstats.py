@@ -1,8 +1,6 @@
-#!/usr/bin/env python3
-"""Print the top rows of a rocprofv3 *_kernel_stats.csv (name, calls, average us, share).   python tools/kstats.py <csv> [n]"""
-import csv
-import sys
-
-rows = list(csv.DictReader(open(sys.argv[1])))
-for r in rows[:int(sys.argv[2]) if len(sys.argv) > 2 else 20]:
-    print(f"{r['Name'][:64]:64s} calls {int(r['Calls']):5d}  avg {float(r['AverageNs']) / 1e3:8.1f} us  {float(r['Percentage']):5.2f} %")
+"""Print the top rows of a rocprofv3 kernel_stats.csv:  python tools/kstats.py <dir or csv> [n]"""
+import csv, glob, os, sys
+p = sys.argv[1]
+f = p if p.endswith(".csv") else glob.glob(os.path.join(p, "**", "*kernel_stats.csv"), recursive=True)[0]
+for r in list(csv.DictReader(open(f)))[:int(sys.argv[2]) if len(sys.argv) > 2 else 16]:
+    print("%-80s calls=%6s avg=%9.1fus pct=%5.2f" % (r["Name"][:80], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["Percentage"])))
