@@ -78,7 +78,7 @@ struct IgemmParams {
     int prio_t[3];       // progress thresholds (1/256 of the block's K tiles) at which a block steps its wave priority down; 0 = off
     int nclasses;
     IgemmClass cls[CGS_MAX_CLASSES];
-    unsigned char perm[CGS_MAX_CLASSES][64];   // per class: base pixels sorted by descending valid-tap count
+    unsigned char perm[CGS_MAX_CLASSES][256];   // per class: base pixels sorted by descending valid-tap count
 };
 
 // i-th tap visited along one axis of an n-tap kernel: natural order, or evens then odds

@@ -925,17 +925,26 @@ int cgs_igemm_launch(const IgemmParams& p_in, void* slab, size_t slab_bytes, hip
 #ifdef CGS_DIAG_STAMPS
     if (getenv("CGS_STAMP") && slab && slab_bytes >= 64) p.slab = (float*)slab;
 #endif
-    // pixel-major row order pays when the base-pixel grid is small (many padded taps per pixel, and the whole
-    // input stays in the 256 MiB Infinity Cache for the cross-tile re-reads) and the batch fills whole tiles
+    // pixel-major row order (a tile = ONE base pixel of 128 images, so a tap that falls into the zero padding does so for the
+    // whole tile and is skipped) pays when the batch fills whole tiles and the pixel grid is small enough that the padding is a
+    // visible share of the taps: 28 % of the MACs at 4x4, 14 % at 8x8, 7 % at 16x16 (measured at batch 1024: 16x16 grids
+    // -3..-5.6 % per layer, also for the 268 MB input of the 32x32x64 forward layer, which no longer fits the Infinity Cache:
+    // the ~128 blocks an XCD runs at once are 128 pixels of the SAME image group, so the re-reads meet in its L2)
     int maxRC = 0;
     for (int i = 0; i < p.nclasses; ++i) maxRC = p.cls[i].R * p.cls[i].C > maxRC ? p.cls[i].R * p.cls[i].C : maxRC;
     const size_t in_bytes = (size_t)p.B * p.Hin * p.Win * p.Cred * 4;
-    p.pix_major = p.vec && p.B >= 128 && maxRC <= 64 && maxRC > 1 && in_bytes <= (size_t)192 << 20;
+    int pix_max = 256;
+    size_t pix_bytes = (size_t)384 << 20;
+#ifdef CGS_EXPERIMENT
+    if (getenv("CGS_PIXMAX")) pix_max = atoi(getenv("CGS_PIXMAX"));
+    if (getenv("CGS_PIXBYTES")) pix_bytes = (size_t)atoi(getenv("CGS_PIXBYTES")) << 20;
+#endif
+    p.pix_major = p.vec && p.B >= 128 && maxRC <= pix_max && maxRC > 1 && in_bytes <= pix_bytes;
     p.lpt = p.pix_major && (p.B % 128) == 0;
     if (p.lpt)
         for (int ci = 0; ci < p.nclasses; ++ci) {
             const IgemmClass& c = p.cls[ci];
-            int cnt[64];
+            int cnt[256];
             for (int pix = 0; pix < c.R * c.C; ++pix) {
                 const int r = pix / c.C, cc = pix - r * c.C;
                 int ny = 0, nx = 0;
@@ -990,7 +999,7 @@ int cgs_igemm_launch(const IgemmParams& p_in, void* slab, size_t slab_bytes, hip
         cgs_note_flops(2.0 * macs);
     }
     bool wide = (p.Np % 128) == 0;
-    if (wide && p.lpt) {      // uneven tiles need >= 2 rounds of blocks over the 512 block slots to balance: halve BN if short
+    if (wide && p.lpt && maxRC <= 64) {   // uneven tiles (9..25 valid taps on grids <= 8x8) need >= 2 rounds of blocks over the 512 block slots to balance: halve BN if short
         long blocks = 0;
         for (int i = 0; i < p.nclasses; ++i) blocks += ((long)p.B * p.cls[i].R * p.cls[i].C / 128) * (p.Np / 128);
         if (blocks < 1024) wide = false;
@@ -1029,8 +1038,8 @@ int cgs_igemm_launch(const IgemmParams& p_in, void* slab, size_t slab_bytes, hip
         if (one_round && p.lpt && p.nclasses == 1 && p.B / 128 == 8 && (32 % nblk_n) == 0) {
             const IgemmClass& c = p.cls[0];
             const int RC = c.R * c.C, nbins = 32 / nblk_n, cap = (RC + nbins - 1) / nbins;
-            int cnt[64], load[32] = {}, used[32] = {};
-            unsigned char bin_items[32][64];
+            int cnt[256], load[32] = {}, used[32] = {};
+            unsigned char bin_items[32][256];
             for (int pix = 0; pix < RC; ++pix) {
                 const int r = pix / c.C, cc = pix - r * c.C;
                 int ny = 0, nx = 0;
