@@ -72,6 +72,7 @@ struct IgemmParams {
     float* slab;         // [class][split][M_c][Np]
     int tap_parity;      // VEC K order visits the taps even offsets first, then odd, per axis (stride-2 F direction)
     int xcd_map;         // block id -> (XCD, local index) decode: an m-tile's n-tiles run on one XCD (see igemm_kernel)
+    int uni;             // uniform-tile K loop allowed (host policy, see cgs_igemm_launch)
     int lpt;             // pixel-major only: m-tiles visit the pixels in perm[] order (most valid taps first)
     float* stat_part;    // != null: per-(m-tile, wave row) column sums / sums of squares of the output, [2 * m-tiles][2][N] (fused batch-norm statistics)
     int vec;             // the 32-channel-chunk K order / 16-byte row gathers apply: Cred % 32 == 0 and at most 16 taps per axis

@@ -471,6 +471,31 @@ __global__ __launch_bounds__(64 * NW, 2) void igemm_kernel(IgemmParams p) {
             rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, b_voff[i], b_soff_, 0)); \
     } while (0)
 
+    // Uniform tiles (pixel-major, all BM rows are the same base pixel of BM different images, no ragged tail): the taps the
+    // iterator visits are inside the image for EVERY row, so no per-row bounds select is needed, and the tap / channel offset is
+    // the same for all rows -> it rides in the buffer load's SCALAR offset and the row part is a loop-invariant VGPR: the A
+    // addresses of a tile cost no vector-ALU instruction at all (9 VALU per tile in the general form above).  The row part is
+    // the image origin (>= 0: the hardware range check sees the VGPR offset), the scalar part the whole pixel offset.
+    const bool uni = VEC && p.uni && skip_ok && m0 + BM <= M;
+    unsigned rowoff_u[AI];
+#pragma unroll
+    for (int i = 0; i < AI; ++i) rowoff_u[i] = ((unsigned)a_base[i] * (unsigned)p.Cred + (unsigned)aq * 4u) * 4u;
+    unsigned a_soff = 0;
+#define ADDR_TILE_U(s_)                                                                                         \
+    do {                                                                                                        \
+        const int ta_ = cgs_tap_order((s_).ia, c.nty, PAR), tb_ = cgs_tap_order((s_).ib, c.ntx, PAR);           \
+        const int iy_ = u_iy + ta_ * p.dstep, ix_ = u_ix + tb_ * p.dstep;                                       \
+        a_soff = (unsigned)(((iy_ * p.Win + ix_) * p.Cred + (s_).chunk * 32 + (TBK == 16 ? (s_).sub * 16 : 0)) * 4); \
+    } while (0)
+#define ISSUE_TILE_U(s_)                                                                                        \
+    do {                                                                                                        \
+        _Pragma("unroll") for (int i = 0; i < AI; ++i)                                                          \
+            ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, rowoff_u[i], a_soff, 0)); \
+        const int b_soff_ = (s_).kt * b_tile_bytes;                                                             \
+        _Pragma("unroll") for (int i = 0; i < BI; ++i)                                                          \
+            rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, b_voff[i], b_soff_, 0)); \
+    } while (0)
+
     // prologue: first tile -> LDS buffer 0
     KIt cur;
     int kt;                                            // (generic-K path: plain tile index)
@@ -611,7 +636,7 @@ __global__ __launch_bounds__(64 * NW, 2) void igemm_kernel(IgemmParams p) {
         // Two copies of the body, one per LDS buffer: the buffer offsets are then instruction immediates instead of a VALU add
         // per address and tile.  The pair loop has ONE exit (at its top, on a two-tile look-ahead), an odd last tile runs in a
         // third copy after it: with an exit between the two copies the compiler moves all 64 accumulator registers at it.
-#define TILE_BODY(BUF_, NXT_)                                                                                   \
+#define TILE_BODY(BUF_, NXT_, ADDR_, ISSUE_)                                                                   \
     {                                                                                                           \
         PRIO_STEP(cur.kt);                                                                                      \
         KIt ld = NXT_;                                  /* tile to prefetch (the current one again after the last) */ \
@@ -619,33 +644,41 @@ __global__ __launch_bounds__(64 * NW, 2) void igemm_kernel(IgemmParams p) {
         const float* a = As + (BUF_) * BM * LDA + (wm * (BM / 2) + j) * LDA;                                    \
         const float* b = Bs + (BUF_) * BK * BN + (wn * (BN / WN) + j) * 4;                                      \
         MFMA_GROUP(0);                                                                                          \
-        ADDR_TILE_V(ld);                                                                                        \
-        ISSUE_TILE_V(ld);                                                                                       \
+        ADDR_(ld);                                                                                              \
+        ISSUE_(ld);                                                                                             \
         _Pragma("unroll") for (int jj = 1; jj < NG - 1; ++jj) MFMA_GROUP(jj);                                   \
         STORE_TILE((BUF_) ^ 1);                                                                                 \
         if (NG > 1) MFMA_GROUP(NG - 1);                                                                         \
         __syncthreads();                                                                                        \
         cur = NXT_;                                                                                             \
     }
-        KIt n1 = cur;
-        if (cur.kt < nk) n1 = kit_next(cur);
-        while (n1.kt < nk) {                             // at least two tiles left: cur (in buffer 0) and n1
-            const KIt n2 = kit_next(n1);
-            KIt n3 = n2;
-            if (n2.kt < nk) n3 = kit_next(n2);
 #ifdef CGS_DIAG_STAMPS
-            diag_tiles += 2;
+#define DIAG_TILES(n_) diag_tiles += (n_)
+#else
+#define DIAG_TILES(n_)
 #endif
-            TILE_BODY(0, n1);
-            TILE_BODY(1, n2);
-            n1 = n3;
-        }
-        if (cur.kt < nk) {                               // an odd last tile
-#ifdef CGS_DIAG_STAMPS
-            ++diag_tiles;
-#endif
-            TILE_BODY(0, n1);
-        }
+#define K_LOOP16(ADDR_, ISSUE_)                                                                                 \
+    {                                                                                                           \
+        KIt n1 = cur;                                                                                           \
+        if (cur.kt < nk) n1 = kit_next(cur);                                                                    \
+        while (n1.kt < nk) {                             /* at least two tiles left: cur (in buffer 0) and n1 */ \
+            const KIt n2 = kit_next(n1);                                                                        \
+            KIt n3 = n2;                                                                                        \
+            if (n2.kt < nk) n3 = kit_next(n2);                                                                  \
+            DIAG_TILES(2);                                                                                      \
+            TILE_BODY(0, n1, ADDR_, ISSUE_);                                                                    \
+            TILE_BODY(1, n2, ADDR_, ISSUE_);                                                                    \
+            n1 = n3;                                                                                            \
+        }                                                                                                       \
+        if (cur.kt < nk) {                               /* an odd last tile */                                 \
+            DIAG_TILES(1);                                                                                      \
+            TILE_BODY(0, n1, ADDR_, ISSUE_);                                                                    \
+        }                                                                                                       \
+    }
+        if (uni) K_LOOP16(ADDR_TILE_U, ISSUE_TILE_U)
+        else K_LOOP16(ADDR_TILE_V, ISSUE_TILE_V)
+#undef K_LOOP16
+#undef DIAG_TILES
 #undef TILE_BODY
     } else {
         for (int buf = 0; kt < nk; buf ^= 1) {
@@ -671,6 +704,8 @@ __global__ __launch_bounds__(64 * NW, 2) void igemm_kernel(IgemmParams p) {
 #undef MFMA_EXEC
 #undef ADDR_TILE_V
 #undef ISSUE_TILE_V
+#undef ADDR_TILE_U
+#undef ISSUE_TILE_U
 #undef PRIO_STEP
 #undef MFMA_GROUP
 
@@ -1061,6 +1096,10 @@ int cgs_igemm_launch(const IgemmParams& p_in, void* slab, size_t slab_bytes, hip
                 for (int k = 0; k < used[b]; ++k) p.perm[0][b + k * nbins] = bin_items[b][k];
         }
     }
+    p.uni = !(p.nclasses > 1 && wide && maxRC <= 64);
+#ifdef CGS_EXPERIMENT
+    if (getenv("CGS_UNI")) p.uni = atoi(getenv("CGS_UNI")) == 2 ? p.uni : atoi(getenv("CGS_UNI"));
+#endif
 #ifdef CGS_EXPERIMENT
     if (getenv("CGS_PRIO")) sscanf(getenv("CGS_PRIO"), "%d,%d,%d", &p.prio_t[0], &p.prio_t[1], &p.prio_t[2]);
     if (getenv("CGS_NOBALANCE")) { /* diagnostic: handled by CGS_PRIO=0,0,0 for (a); (b) has no switch */ }
