@@ -329,6 +329,264 @@ __global__ __launch_bounds__(256, 2) void convt_quad_lds_kernel(QuadParams p, in
 #undef STORE_PATCH
 }
 
+// ------------------------------------------------------------------------------------------------
+// "Rows" form (the fast path for kw * N <= 16, e.g. the 5x5 64 -> 3 layers of every DCGAN here): the quad form above spends
+// 48 % of its MFMA work on structural zeros (12 of 16 columns, 25 of 36 (neighbour, parity) pairs).  Here the vertical taps are
+// folded into K EXACTLY (an output row of parity py sums over the ky of that parity: 2 + 3 = kh row taps for a row PAIR, no
+// zero rows) and the horizontal taps become the GEMM's columns, (kx, n) = kw * N of 16:
+//
+//   Q[Y][c][(kx, n)] = sum_{ky = Y + pt - 2r, ci} in[b, r, c, ci] * w[ky][kx][n][ci]              (MFMA, 94 % useful for 5x5x3)
+//   out[b, Y, X, n]  = epi(bias[n] + sum_{kx = X + pl - 2c} Q[Y][c][(kx, n)])                     (<= 3 terms, from LDS)
+//
+// One wave owns one output row pair (2R, 2R+1) of one image: M = the Ws input pixels of a row (MT tiles of 16), its A fragments
+// come straight from global memory (each lane one float4 = 4 channels of its pixel; the row is read by the 3 row pairs that
+// use it, which run back to back in neighbouring waves -> L1/L2), the packed weights (kh * Cs * 16 floats, 20 KB) sit in LDS for
+// the whole persistent block, and the waves never synchronise with each other.  The horizontal gather runs through a per-wave
+// LDS staging tile with per-lane offsets computed once per block; the summation order is fixed (deterministic).
+// ------------------------------------------------------------------------------------------------
+struct RowsParams {
+    const float* in;     // [B,Hs,Ws,Cs]
+    const float* wp;     // packed [kh*Cs/4][16][4]: k = ky*Cs + ci, column = kx*N + n
+    const float* bias;   // [N] or null
+    const float* ep_a;   // [N] for RELU_BWD_AFFINE
+    const float* ep_aux; // [B,2Hs,2Ws,N] for the *_BWD epilogues
+    float* out;          // [B,2Hs,2Ws,N]
+    int B, Hs, Ws, Cs;
+    int kh, kw, pt, pl;
+    int dmin_y, ny;      // input rows R + dmin_y .. R + dmin_y + ny - 1 feed the output row pair (2R, 2R+1)
+    int epilogue;
+};
+
+// w[kh][kw][N][Cs] -> Wp[(ky*Cs + ci)/4][col = kx*N + n][(ky*Cs + ci)%4]
+__global__ void pack_rows_weights_kernel(const float* __restrict__ w, float* __restrict__ wp, int kh, int kw, int N, int Cs) {
+    const int total = kh * Cs * 16;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int e = i & 3, col = (i >> 2) & 15, k = (i >> 6) * 4 + e;
+        const int ky = k / Cs, ci = k - ky * Cs;
+        const int kx = col / N, n = col - kx * N;
+        wp[i] = kx < kw ? w[((size_t)(ky * kw + kx) * N + n) * Cs + ci] : 0.f;
+    }
+}
+
+// S5: the geometry of a 5x5 'SAME' layer with 64 input channels at compile time (kh = 5, pt = 1, rows R0-1 .. R0+2, 4 chunks): the 16
+// (row, chunk) steps of a task become straight-line code -- which row taps apply to a step is known, the loads of step s + 2
+// are in flight under the MFMAs of step s with exact vmcnt waits (with the generic form's uniform branches the compiler waits
+// for vmcnt(0) before every MFMA group, which serialises loads and matrix work: 133 us instead of 9x for dcgan64's g_h4)
+template <int N, int MT, bool S5>   // N output channels, MT 16-pixel tiles per input row (Ws <= 16 * MT)
+__global__ __launch_bounds__(512, 4) void convt_rows_kernel(RowsParams p, int tasks_total, int tasks_per_block) {
+    const int kh = S5 ? 5 : p.kh, pt = S5 ? 1 : p.pt, dmin_y = S5 ? -1 : p.dmin_y, ny = S5 ? 3 : p.ny;
+    constexpr int NWV = 8;                                  // waves per block
+    // staging of one output row pair: [2 rows][pixel -2 .. ROWS][SL floats]; the pixels < 0 and >= Ws and the columns >= 16 stay
+    // zero, so the gather needs no bounds: its three terms are the lane's base address + instruction immediates
+    constexpr int ROWS = MT * 16, SL = 20, SP = ROWS + 3;
+    constexpr int SW = 2 * SP * SL;
+    constexpr int NU = (2 * (2 * ROWS * N / 4) + 63) / 64;  // float4 of a row pair per lane
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // (tells the compiler it is wave-uniform: task indices, row offsets and descriptors stay in SGPRs)
+    const int g = lane >> 4, i = lane & 15;
+    float* Wl = smem;
+    float* S = smem + (size_t)kh * p.Cs * 16 + (size_t)wave * SW;
+    const int t_begin = blockIdx.x * tasks_per_block;
+    const int t_end = t_begin + tasks_per_block < tasks_total ? t_begin + tasks_per_block : tasks_total;
+    if (t_begin >= t_end) return;
+    for (int q = tid; q < kh * p.Cs * 4; q += 64 * NWV) ((f32x4*)Wl)[q] = ((const f32x4*)p.wp)[q];
+    for (int q = lane; q < SW; q += 64) S[q] = 0.f;
+    __syncthreads();
+
+    const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)p.in, 0, (int)((unsigned)p.B * (unsigned)p.Hs * (unsigned)p.Ws * (unsigned)p.Cs * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t null_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, 0, 0x00020000);
+    // loop-invariant per-lane part of the A addresses: pixel (16m + i), channels 4g.. (past the row -> out of range -> zeros)
+    unsigned coff[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) coff[m] = 16 * m + i < p.Ws ? (unsigned)(((16 * m + i) * p.Cs + 4 * g) * 4) : 0xFFFFFFF0u;
+    // gather plan of this lane: float4 q = lane + 64u of a row pair -> output row yr, floats 4xq..4xq+3 of that row; each float
+    // (X, n) sums Q[yr][c][(kx, n)] over kx = kx0, kx0 + 2, kx0 + 4 with kx0 = (X + pl) & 1 and 2c = X + pl - kx: one step in kx
+    // is one pixel down and 2N columns up, a constant stride, and every out-of-range term lands on a zero of the staging tile
+    // (c < 0 or >= Ws: zero pixels; kx >= kw: zero-weight column 15 or the never-written columns 16..19).  goff is the address
+    // of the LAST term (lowest address), the others are immediates.
+    const int f4_per_row = 2 * p.Ws * N / 4;
+    constexpr int GSTEP = SL - 2 * N;                       // floats from term kx + 2 to term kx
+    // (the plan depends on the lane only: it lives in LDS, one copy per block, and is read back per row pair -- its 18 values per
+    // lane would otherwise sit in VGPRs through the K loop)
+    int* Tg = (int*)(smem + (size_t)kh * p.Cs * 16 + (size_t)NWV * SW);       // [NU][64][4] staging offsets of the last term
+    float* Tb = (float*)(Tg + NU * 64 * 4);                                        // [NU][64][4] bias of each float
+    int* Tq = (int*)(Tb + NU * 64 * 4);                                            // [NU][64] float offset of the float4 inside the row pair's output, -1 = none
+    if (wave == 0) {
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int q = lane + 64 * u;
+            const int yr = q / f4_per_row, xq = q - yr * f4_per_row;
+            Tq[u * 64 + lane] = q < 2 * f4_per_row ? yr * (2 * p.Ws * N) + xq * 4 : -1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int f = xq * 4 + e;
+                const int X = f / N, n = f - X * N;
+                Tb[(u * 64 + lane) * 4 + e] = p.bias ? p.bias[n] : 0.f;
+                const int kx = ((X + p.pl) & 1) + 4;            // the last of the three terms
+                const int c = (X + p.pl - kx) >> 1;             // exact (even numerator); -2 <= c <= Ws for kw <= 6 (pl <= 2)
+                Tg[(u * 64 + lane) * 4 + e] = q < 2 * f4_per_row ? ((yr * SP + c + 2) * SL + kx * N + n) : 0;
+            }
+        }
+    }
+    __syncthreads();
+    const int nchunk = S5 ? 4 : p.Cs >> 4;
+    const int nrow = ny + 1;                              // input rows feeding TWO consecutive output row pairs
+    const int nit = S5 ? 16 : nrow * nchunk;
+    const size_t out_row = (size_t)2 * p.Ws * N;
+
+    // a task = two consecutive output row pairs (R0, R0 + 1) of one image: the 4 (ny + 1) input rows R0 + dmin_y .. are read once
+    // for both (a row pair alone needs 3: a third fewer loads), the packed weights of a row tap serve both M tiles
+    const int pairs_y = (p.Hs + 1) >> 1;
+    for (int t = t_begin + wave; t < t_end; t += NWV) {
+        const int b = t / pairs_y, R0 = (t - b * pairs_y) * 2;
+        f32x4 acc[4][MT];
+#pragma unroll
+        for (int y = 0; y < 4; ++y)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[y][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 a0[MT], a1[MT], a2[MT];
+#define ROWS_LOAD_A(dst, it_)                                                                              \
+    do {                                                                                                    \
+        const int d_ = (it_) / nchunk, j_ = (it_) - d_ * nchunk;                                            \
+        const int rr_ = R0 + dmin_y + d_;                                                                 \
+        /* a row outside the image reads through the EMPTY descriptor (num_records 0: every lane gets zeros): no branch */ \
+        const bool rok_ = (unsigned)rr_ < (unsigned)p.Hs;                                                   \
+        const unsigned sb_ = rok_ ? (unsigned)((((b * p.Hs + rr_) * p.Ws) * p.Cs + 16 * j_) * 4) : 0u;   /* scalar */ \
+        _Pragma("unroll") for (int m = 0; m < MT; ++m)                                                      \
+            dst[m] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rok_ ? in_rsrc : null_rsrc, coff[m], sb_, 0)); \
+    } while (0)
+#define ROWS_MFMA(a_, acc_, ky_, j_)                                                                        \
+    do {                                                                                                    \
+        const f32x4 fb = *(const f32x4*)(Wl + ((size_t)((((ky_) * p.Cs) >> 2) + 4 * (j_) + g) * 16 + i) * 4); \
+        _Pragma("unroll") for (int m = 0; m < MT; ++m) {                                                    \
+            acc_[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_[m].x, fb.x, acc_[m], 0, 0, 0);                \
+            acc_[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_[m].y, fb.y, acc_[m], 0, 0, 0);                \
+            acc_[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_[m].z, fb.z, acc_[m], 0, 0, 0);                \
+            acc_[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_[m].w, fb.w, acc_[m], 0, 0, 0);                \
+        }                                                                                                   \
+    } while (0)
+    // input row R0 + dmin_y + d feeds output row 2 R0 + y through the row tap ky = pt - 2 (dmin_y + d) + y (if that is a tap)
+#define ROWS_STEP(a_, it_)                                                                                  \
+    do {                                                                                                    \
+        const int d_ = (it_) / nchunk, j_ = (it_) - d_ * nchunk;                                            \
+        const int ky_ = pt - 2 * (dmin_y + d_);                                                         \
+        _Pragma("unroll") for (int y = 0; y < 4; ++y)                                                       \
+            if ((unsigned)(ky_ + y) < (unsigned)kh) ROWS_MFMA(a_, acc[y], ky_ + y, j_);                   \
+    } while (0)
+        // the aux values of the backward epilogues: the first row pair's are requested before the K loop, the second pair's
+        // before the first pair's gather
+        f32x4 aux[NU], aux_n[NU];
+        if (p.epilogue >= CGS_EPI_RELU_BWD_AFFINE) {
+            const size_t o0 = ((size_t)(b * 2 * p.Hs + 2 * R0)) * out_row;
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                const int gq0 = Tq[u * 64 + lane];
+                if (gq0 >= 0) aux[u] = *(const f32x4*)(p.ep_aux + o0 + gq0);
+            }
+        }
+        ROWS_LOAD_A(a0, 0);
+        if (1 < nit) ROWS_LOAD_A(a1, 1);
+#pragma unroll
+        for (int it = 0; it < (S5 ? 16 : nit); it += 3) {   // two steps of loads in flight under each step's MFMAs
+            // (sched_barrier: left alone, the scheduler hoists the straight-line form's fragment reads and loads far ahead and spills)
+            if (it + 2 < nit) ROWS_LOAD_A(a2, it + 2);
+            if (S5) __builtin_amdgcn_sched_barrier(0);
+            ROWS_STEP(a0, it);
+            if (S5) __builtin_amdgcn_sched_barrier(0);
+            if (it + 1 < nit) {
+                if (it + 3 < nit) ROWS_LOAD_A(a0, it + 3);
+                if (S5) __builtin_amdgcn_sched_barrier(0);
+                ROWS_STEP(a1, it + 1);
+                if (S5) __builtin_amdgcn_sched_barrier(0);
+            }
+            if (it + 2 < nit) {
+                if (it + 4 < nit) ROWS_LOAD_A(a1, it + 4);
+                if (S5) __builtin_amdgcn_sched_barrier(0);
+                ROWS_STEP(a2, it + 2);
+                if (S5) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#undef ROWS_LOAD_A
+#undef ROWS_MFMA
+#undef ROWS_STEP
+#pragma unroll
+        for (int hp = 0; hp < 2; ++hp) {                    // the two row pairs, one after the other through the staging tile
+            if (R0 + hp >= p.Hs) break;
+            const size_t o_pair = ((size_t)(b * 2 * p.Hs + 2 * (R0 + hp))) * out_row;
+            int gq[NU];
+#pragma unroll
+            for (int u = 0; u < NU; ++u) gq[u] = Tq[u * 64 + lane];
+            if (p.epilogue >= CGS_EPI_RELU_BWD_AFFINE) {
+                if (hp == 0) {
+                    if (R0 + 1 < p.Hs) {
+#pragma unroll
+                        for (int u = 0; u < NU; ++u)
+                            if (gq[u] >= 0) aux_n[u] = *(const f32x4*)(p.ep_aux + o_pair + 2 * out_row + gq[u]);
+                    }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < NU; ++u) aux[u] = aux_n[u];
+                }
+            }
+            // Q -> staging (C/D layout of 16x16x4: column = lane & 15, row = (lane >> 4) * 4 + reg); the previous reads of the tile
+            // are complete (LDS operations of one wave finish in order; the fences only pin the compiler)
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    S[(2 + 16 * m + 4 * g + r) * SL + i] = acc[2 * hp][m][r];
+                    S[(SP + 2 + 16 * m + 4 * g + r) * SL + i] = acc[2 * hp + 1][m][r];
+                }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                if (gq[u] < 0) continue;
+                f32x4 v;
+                const int4 go = *(const int4*)(Tg + (u * 64 + lane) * 4);
+                const f32x4 gb = *(const f32x4*)(Tb + (u * 64 + lane) * 4);
+                const int goff[4] = {go.x, go.y, go.z, go.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float* q_ = S + goff[e];
+                    v[e] = ((gb[e] + q_[2 * GSTEP]) + q_[GSTEP]) + q_[0];             // kx0, kx0 + 2, kx0 + 4: a fixed order
+                }
+                if (p.epilogue == CGS_EPI_TANH) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fast_tanh(v[e]);
+                } else if (p.epilogue == CGS_EPI_LRELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.2f * v[e]);
+                } else if (p.epilogue >= CGS_EPI_RELU_BWD_AFFINE) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float y = aux[u][e];
+                        if (p.epilogue == CGS_EPI_TANH_BWD) v[e] *= (1.f - y * y);
+                        else if (p.epilogue == CGS_EPI_LRELU_BWD) v[e] = y > 0.f ? v[e] : 0.2f * v[e];
+                        else v[e] = y > 0.f ? v[e] * p.ep_a[(gq[u] + e) % N] : 0.f;
+                    }
+                }
+                *(f32x4*)(p.out + o_pair + gq[u]) = v;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    }
+}
+
+// geometry-only eligibility (the packed layout differs from the quad form's, and a cached packed workspace is keyed by the
+// family and the geometry): kw * N columns fit one MFMA tile, whole float4 output rows, weights + staging fit the LDS
+static int rows_mt(const CgsLayer& L) {
+    if (!(L.Cb == 1 || L.Cb == 3) || L.kw * L.Cb > 16 || L.kw > 6 || (L.Cs % 16) != 0 || ((2 * L.Ws * L.Cb) % 4) != 0) return 0;
+    if ((size_t)L.kh * L.Cs * 16 * sizeof(float) > 64 * 1024) return 0;
+    if (L.Ws > 32) return 0;                   // (four pixel tiles x four output rows of accumulators do not fit 128 VGPRs)
+    return L.Ws <= 16 ? 1 : 2;
+}
+
 static void quad_range(int k, int pad, int& lo, int& hi) {
     lo = 1 << 20; hi = -(1 << 20);
     for (int par = 0; par < 2; ++par)
@@ -365,6 +623,54 @@ int cgs_convt_quad_launch(const CgsLayer& L, int B, const float* in, const float
     quad_range(L.kw, pl, p.dmin_x, hx);
     p.ny = hy - p.dmin_y + 1; p.nx = hx - p.dmin_x + 1;
     if ((long)B * L.Hs * L.Ws * L.Cs * 4 > 0x7fffffffL) return cgs_set_error(CGS_EINVAL, "convt_quad: input exceeds 2 GiB (split the batch)");
+    if (const int mt = rows_mt(L)) {
+        RowsParams r;
+        r.in = in; r.wp = ws; r.bias = bias; r.out = out; r.ep_a = ep_a; r.ep_aux = ep_aux;
+        r.B = B; r.Hs = L.Hs; r.Ws = L.Ws; r.Cs = L.Cs; r.kh = L.kh; r.kw = L.kw; r.pt = pt; r.pl = pl;
+        r.dmin_y = p.dmin_y; r.ny = p.ny; r.epilogue = epilogue;
+        const size_t wfl = (size_t)L.kh * L.Cs * 16;
+        if (!ws || ws_bytes < wfl * sizeof(float)) return cgs_set_error(CGS_EWORKSPACE, "convt_rows: workspace %zu < %zu bytes", ws_bytes, wfl * sizeof(float));
+        if (!prepacked) {
+            hipLaunchKernelGGL(pack_rows_weights_kernel, dim3((unsigned)((wfl + 255) / 256)), dim3(256), 0, s, w, ws, L.kh, L.kw, L.Cb, L.Cs);
+            CGS_CHECK_LAUNCH("pack_rows_weights");
+        }
+        const long tasks = (long)B * ((L.Hs + 1) / 2);      // two output row pairs per task
+        if (tasks == 0) return CGS_OK;
+        // persistent blocks of 8 independent waves, two per CU; a block's waves walk neighbouring row pairs of a contiguous run
+        long blocks = (tasks + 7) / 8;
+        if (blocks > 512) blocks = 512;
+        long per = (tasks + blocks - 1) / blocks;
+        per = (per + 7) / 8 * 8;
+        blocks = (tasks + per - 1) / per;
+        const int nu = (2 * (2 * mt * 16 * L.Cb / 4) + 63) / 64;
+        const size_t smem = (wfl + (size_t)8 * (2 * (mt * 16 + 3) * 20) + (size_t)nu * 64 * 9) * sizeof(float);
+#define ROWS_LAUNCH(NN, MM, SS)                                                                                      \
+    {                                                                                                              \
+        static bool done_[64] = {};                                                                                \
+        int dv_ = 0;                                                                                               \
+        (void)hipGetDevice(&dv_);                                                                                  \
+        dv_ &= 63;                                                                                                 \
+        if (!done_[dv_]) {                                                                                         \
+            hipError_t e = hipFuncSetAttribute((const void*)convt_rows_kernel<NN, MM, SS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            if (e != hipSuccess) return cgs_set_error(CGS_ELAUNCH, "convt_rows smem attr: %s", hipGetErrorString(e)); \
+            done_[dv_] = true;                                                                                     \
+        }                                                                                                          \
+        hipLaunchKernelGGL((convt_rows_kernel<NN, MM, SS>), dim3((unsigned)blocks), dim3(512), smem, s, r, (int)tasks, (int)per); \
+    }
+        const bool s5 = L.kh == 5 && L.Cs == 64 && pt == 1 && p.dmin_y == -1 && p.ny == 3;
+        if (L.Cb == 3) {
+            if (mt == 1) { if (s5) ROWS_LAUNCH(3, 1, true) else ROWS_LAUNCH(3, 1, false) }
+            else { if (s5) ROWS_LAUNCH(3, 2, true) else ROWS_LAUNCH(3, 2, false) }
+        } else {
+            if (mt == 1) ROWS_LAUNCH(1, 1, false) else ROWS_LAUNCH(1, 2, false)
+        }
+#undef ROWS_LAUNCH
+        CGS_CHECK_LAUNCH("convt_rows");
+        static thread_local char name[48];
+        snprintf(name, sizeof(name), "convt_rows_kernel<%d, %d, %s>", L.Cb, mt, (s5 && L.Cb == 3) ? "true" : "false");       // as rocprofv3 prints it
+        cgs_note_kernel(name);
+        return CGS_OK;
+    }
     const size_t K = (size_t)p.ny * p.nx * L.Cs;
     const size_t need = K * 16 * sizeof(float);
     if (!ws || ws_bytes < need) return cgs_set_error(CGS_EWORKSPACE, "convt_quad: workspace %zu < %zu bytes", ws_bytes, need);

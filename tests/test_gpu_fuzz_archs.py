@@ -87,6 +87,31 @@ def close(got, want, tol, what, floor=1e-6):
     assert err <= max(tol * ref, floor), f"{what}: max|delta|={err:.3e} vs max|ref|={ref:.3e}"
 
 
+def kink_margins(name, P, f0):
+    """Per sample: how close the oracle's forward pass (G tail + D) comes to a relu / lrelu kink, as min |pre-activation| over
+    the largest |pre-activation| of that tensor.  A sample whose margin is within the forward rounding error can legitimately
+    take the other slope in a second arithmetic, and its WHOLE gradient then differs (seed 1002: an instance-norm output of
+    3.3e-7 in one of 8 samples)."""
+    from oracle import ops_ref as R
+    margins = []
+    relu0, lrelu0 = torch.relu, R.lrelu
+
+    def tap(fn):
+        def f(x, *a, **k):
+            if x.dim() >= 2:
+                flat = x.detach().reshape(x.shape[0], -1).abs().double()
+                margins.append(flat.min(dim=1).values / (flat.max() + 1e-30))
+            return fn(x, *a, **k)
+        return f
+    torch.relu, R.lrelu = tap(relu0), tap(lrelu0)
+    try:
+        with torch.no_grad():
+            N.discriminator(name, P, N.feature_to_data(name, P, f0))
+    finally:
+        torch.relu, R.lrelu = relu0, lrelu0
+    return torch.stack(margins).min(dim=0).values if margins else torch.ones(f0.shape[0], dtype=torch.float64)
+
+
 @pytest.mark.parametrize("seed", [1000 + SEED + i for i in range(N_ARCHS)])
 @pytest.mark.parametrize("use_graph", [False, True], ids=["eager", "hipgraph"])
 def test_random_topology_matches_oracle(seed, use_graph):
@@ -113,15 +138,26 @@ def test_random_topology_matches_oracle(seed, use_graph):
         # a pre-activation within rounding of a relu / lrelu kink can take the other slope in the two arithmetics: require the
         # bulk of the gradient entries to agree tightly instead of the maximum
         g, go = grad.cpu().double(), grad_o.double()
+        keep = torch.ones(B, dtype=torch.bool)       # samples whose refinement is compared below (all but the kink-excused ones)
         if go.abs().max().item() < 1e-12:          # degenerate draw (e.g. instance norm over a 1x1 map): the gradient is exactly 0
             assert g.abs().max().item() < 1e-6, f"grad should vanish, max {g.abs().max().item():.3e}"
         else:
             rel = (g - go).abs() / go.abs().max()
-            assert (rel < 2e-3).double().mean().item() > 0.95 and rel.max().item() < 0.3, f"grad: max rel {rel.max().item():.3e}"
+            if not ((rel < 2e-3).double().mean().item() > 0.95 and rel.max().item() < 0.3):
+                # per sample: every sample must meet the criterion unless the oracle itself sits on a kink there (margin below
+                # 1e-4 of the tensor's scale -- forward differences of 1e-5 are normal behind an instance norm over a 3x3 map),
+                # and at most a quarter of the batch may be excused that way
+                per = rel.reshape(B, -1)
+                ok = ((per < 2e-3).double().mean(dim=1) > 0.95) & (per.max(dim=1).values < 0.3)
+                margin = kink_margins(name, P, f0_ref)
+                excused = (~ok) & (margin < 1e-4)
+                assert bool((ok | excused).all()) and int(excused.sum()) <= max(1, B // 4), \
+                    f"grad: max rel {rel.max().item():.3e}; failing samples {(~ok).nonzero().flatten().tolist()}, kink margins {margin.tolist()}"
+                keep = ~excused
         want = S.collaborative_refine(f0_ref, gt, dd, Ksteps, 0.1)
         img, dl, ol, os_, of = eng.refine(f0, Ksteps, 0.1)
         close(dl, want[1], 2e-4, "default logit")
-        close(img, want[0], 5e-2, "images")          # two steps downstream of the kink effect above; a wrong kernel is off by O(1)
+        close(img.cpu()[keep], want[0][keep], 5e-2, "images")   # two steps downstream of the kink effect above; a wrong kernel is off by O(1)
     finally:
         N.ARCHS.pop(name, None)
         nets.ARCHS.pop(name, None)

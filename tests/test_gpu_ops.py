@@ -156,6 +156,39 @@ def test_deconv2d_bwd_data(B, H, W, Cin, Ho, Wo, Cout, k, s):
     close(got, x.grad, 2e-5)
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,name", [
+    (37, 32, 32, 64, 3, 5, "convt_rows_kernel<3, 2, true>"),      # dcgan64 g_h4 / d_h0 backward-data; row pairs not a multiple of the 8 waves
+    (9, 16, 16, 64, 3, 5, "convt_rows_kernel<3, 1, true>"),       # dcgan32 g_h4: the straight-line 5x5x64 form, one pixel tile, odd image count
+    (300, 16, 16, 32, 3, 5, "convt_rows_kernel<3, 1, false>"),     # dcgan32; 4800 row pairs over 512 persistent blocks
+    (5, 14, 14, 64, 1, 4, "convt_rows_kernel<1, 1, false>"),       # mnist g_dc4 (4x4 kernel, one channel, 14 of 16 pixels per tile)
+    (3, 20, 12, 32, 3, 5, "convt_rows_kernel<3, 1, false>"),       # ragged width, non-square
+    (2, 9, 24, 16, 3, 3, "convt_rows_kernel<3, 2, false>"),        # 3x3 kernel, 24 of 32 pixels
+    (2, 7, 24, 16, 1, 5, "convt_rows_kernel<1, 2, false>"),        # one channel, odd number of row pairs
+    (2, 6, 48, 16, 1, 5, "convt_quad_lds_kernel<1, 16, 3>"),  # wider than 32 pixels -> quad form
+    (2, 8, 40, 16, 3, 5, "convt_quad_lds_kernel<3, 16, 3>"),  # wider than the rows form takes with 3 channels -> quad form
+])
+def test_rows_form_of_small_channel_transposed_conv(B, H, W, Cin, Cout, k, name):
+    """kw * N <= 16: vertical taps folded into K, horizontal taps as GEMM columns + a <= 3-term gather (convt_rows_kernel), forward
+    with bias + tanh and as a conv's backward-data with the tanh gradient folded in -- against the oracle operators."""
+    from cgs_amd import kernels as K, lib
+    d = dev()
+    x, w, b = rnd((B, H, W, Cin), 1), rnd((k, k, Cout, Cin), 2, 0.05), rnd((Cout,), 3, 0.1)
+    got = K.deconv2d_fwd(x.to(d), w.to(d), b.to(d), (2 * H, 2 * W), 2, 2, lib.EPI_TANH)
+    assert lib.last_kernel() == name, lib.last_kernel()
+    close(got, torch.tanh(R.deconv2d(x, w, b, (B, 2 * H, 2 * W, Cout), 2, 2)), 2e-5)
+    got = K.deconv2d_fwd(x.to(d), w.to(d), None, (2 * H, 2 * W), 2, 2)
+    close(got, R.deconv2d(x, w, torch.zeros(Cout), (B, 2 * H, 2 * W, Cout), 2, 2), 2e-5)
+    # conv [k,k,Cout(big side),Cin] backward-data: dy [B,H,W,Cin] -> dx [B,2H,2W,Cout], times tanh'(aux)
+    wc = rnd((k, k, Cout, Cin), 4, 0.05)
+    xb = rnd((B, 2 * H, 2 * W, Cout), 5).requires_grad_(True)
+    dy = rnd((B, H, W, Cin), 6)
+    (R.conv2d(xb, wc, torch.zeros(Cin), 2, 2) * dy).sum().backward()
+    aux = rnd((B, 2 * H, 2 * W, Cout), 7, 0.5)
+    got = K.conv2d_bwd_data(dy.to(d), wc.to(d), (2 * H, 2 * W), 2, 2, epilogue=lib.EPI_TANH_BWD, ep_aux=aux.to(d))
+    assert lib.last_kernel() == name, lib.last_kernel()
+    close(got, xb.grad * (1 - aux * aux), 2e-5)
+
+
 @pytest.mark.parametrize("mode", ["relu_affine", "lrelu", "tanh"])
 @pytest.mark.parametrize("case", [(3, 16, 16, 64, 128, 5, 2), (3, 32, 32, 3, 64, 5, 2), (5, 28, 28, 1, 64, 4, 2), (2, 7, 9, 32, 40, 5, 2),
                                   (2, 64, 64, 3, 64, 5, 2)])
