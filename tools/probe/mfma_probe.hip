@@ -109,6 +109,17 @@ __global__ __launch_bounds__(256, 2) void probe(const float* __restrict__ g, flo
             __builtin_amdgcn_global_load_lds((const void*)(gp + (size_t)(it & 31) * 256 + 32768), (__attribute__((address_space(3))) void*)(dst + 512), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((const void*)(gp + (size_t)(it & 31) * 256 + 49152), (__attribute__((address_space(3))) void*)(dst + 768), 16, 0, 0);
             FREAD(buf, 1); MFMA16();
+        } else if (MODE == 14) {         // 4 buffer LDS-DMA loads straight into the other tile buffer (what a DMA-fed K loop would issue)
+            FREAD(buf, 0); MFMA16();
+            const unsigned o = (unsigned)(blockIdx.x * 1024 + tid) * 16u;
+            float* da = smem + (buf ^ 1) * 128 * 20 + wave * 256;
+            float* db = smem + 2 * 128 * 20 + (buf ^ 1) * 16 * 128 + wave * 256;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)da, 16, o, ((it & 63) * 256) * 16u, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(da + 1024), 16, o, ((it & 63) * 256 + 16384) * 16u, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)db, 16, o, ((it & 31) * 256 + 32768) * 16u, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(db + 1024), 16, o, ((it & 31) * 256 + 49152) * 16u, 0, 0);
+            FREAD(buf, 1); MFMA16();
+            __builtin_amdgcn_s_waitcnt(0x0f70);      // vmcnt(0): the DMA data must be in LDS before the barrier
         } else if (MODE == 13) {         // 4 loads, fragment-shaped: each lane-quad reads 64 B of its own row (rows 512 B apart)
             FREAD(buf, 0); MFMA16();
             const f32x4* q = (const f32x4*)g + (size_t)blockIdx.x * 8192 + (size_t)(tid >> 2) * 32 + (tid & 3) + (it & 7) * 4;
@@ -170,6 +181,7 @@ int main() {
         run<11>("   4 buffer loads (1 address VGPR)", g, out, blocks, ldskb);
         run<13>("   4 loads, 16 rows x 64 B each (fragment-shaped)", g, out, blocks, ldskb);
         run<12>("   4 LDS-DMA loads (global_load_lds_dwordx4)", g, out, blocks, ldskb + 16);
+        run<14>("   4 buffer LDS-DMA loads into the tile buffers", g, out, blocks, ldskb);
     }
     return 0;
 }

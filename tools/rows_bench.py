@@ -25,3 +25,13 @@ for rep in range(2):
     for name, epi in (("none", lib.EPI_NONE), ("tanh'", lib.EPI_TANH_BWD), ("lrelu'", lib.EPI_LRELU_BWD)):
         t = timeit(lambda: K.conv2d_bwd_data(x, w, (2 * H, 2 * H), 2, 2, out=y, epilogue=epi, ep_aux=aux if epi != lib.EPI_NONE else None))
         print(f"bwd {name:6s} {t:7.1f} us  {lib.last_kernel()}")
+
+# the 3 -> 64 forward-direction twin (d_h0 forward, g_h4 backward-data): conv_patch2_kernel
+xi = torch.randn(B, 2 * H, 2 * H, 3, device=d).tanh(); wc = torch.randn(5, 5, 3, 64, device=d) * 0.02; bc = torch.zeros(64, device=d)
+yo = torch.empty(B, H, H, 64, device=d); auxo = torch.randn(B, H, H, 64, device=d); a64 = torch.rand(64, device=d) + 0.5
+for rep in range(2):
+    for name, epi in (("none", lib.EPI_NONE), ("lrelu", lib.EPI_LRELU)):
+        t = timeit(lambda: K.conv2d_fwd(xi, wc, bc, 2, 2, epi, out=yo))
+        print(f"F fwd {name:8s} {t:7.1f} us  {lib.last_kernel()}")
+    t = timeit(lambda: K.deconv2d_bwd_data(xi, wc, (H, H), 2, 2, out=yo, epilogue=lib.EPI_RELU_BWD_AFFINE, ep_a=a64, ep_aux=auxo))
+    print(f"F bwd relu'*a   {t:7.1f} us  {lib.last_kernel()}")
