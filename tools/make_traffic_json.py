@@ -14,7 +14,7 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KEEP = ("igemm_kernel", "convt_quad", "conv_patch", "conv_smalln", "convt_smalln")
+KEEP = ("igemm_kernel", "convt_quad", "convt_rows", "conv_patch", "conv_smalln", "convt_smalln")
 
 
 def short(name):
