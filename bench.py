@@ -8,6 +8,9 @@ per GPU, K = 20 (the configuration the 10k samples/s target is quoted on; it fit
 Inputs (z batches) and weights are resident in HBM before the timed region.  Two steps are in flight per GPU
 (--streams), and for the small configurations several logical batches share one launch, each with its own
 batch-norm statistics (--fuse; dcgan32 4 x 256, mnist 16 x 64): the work and the results of a step are unchanged.
+The K-step program of a step is replayed as a hipGraph (the launch-bound inner loop: ~1300 dependent launches per step;
+--no-graph launches them one by one); the per-kernel HIP-event timing behind `roofline` then comes from one extra step
+launched eagerly on one stream right after the timed region (the same kernels with the same arguments).
 
 N > 1: one process per GPU (torch.distributed, backend nccl = RCCL), independent z-batches per rank
 (seed 2019+rank, weak scaling), and ONE RCCL all-gather per step of the refined images into the
@@ -151,7 +154,7 @@ def other_configs(dev, skip):
             continue
         A = nets.ARCHS[arch]
         P = nets.init_params(arch, dev, seed=2019)
-        engines = [RefineEngine(arch, P, B * G, dev, bn_groups=G) for _ in range(2)]
+        engines = [RefineEngine(arch, P, B * G, dev, use_graph=True, bn_groups=G) for _ in range(2)]
         streams = [torch.cuda.Stream(dev) for _ in engines]
         z = torch.from_numpy(np.random.RandomState(2019).uniform(-1, 1, (steps + 2, B * G) + nets.g_input_shape(A)).astype(np.float32)).to(dev)
 
@@ -202,7 +205,10 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: 1024 dcgan64, 256 dcgan32, 64 mnist)")
     ap.add_argument("--refine-steps", type=int, default=0, help="K (default: 20; 50 for mnist)")
     ap.add_argument("--rate", type=float, default=0.1)
-    ap.add_argument("--graph", action="store_true", help="replay the K-step program as a hipGraph")
+    ap.add_argument("--graph", dest="graph", action="store_true", default=None,
+                    help="replay the K-step program as a hipGraph (the default for the refinement archs: +1.3 %% on the dcgan64 headline, the "
+                         "launch gaps between the ~1300 dependent kernels of a step otherwise only partly hide behind the other batch in flight)")
+    ap.add_argument("--no-graph", dest="graph", action="store_false", help="launch every kernel eagerly")
     ap.add_argument("--streams", type=int, default=0,
                     help="(default 2; 8 for synthetic2d) z-batches in flight per GPU, one engine + HIP stream each: the tail / small kernels of one "
                          "batch overlap the big kernels of the other (measured: 1 -> 5040, 2 -> 5500, 3 -> 5460 samples/s)")
@@ -249,6 +255,8 @@ def main():
     if args.sync_bn and not use_dist:
         raise SystemExit("--sync-bn needs the torch.distributed launch (python -m torch.distributed.run ... bench.py)")
     G = args.fuse if args.fuse > 0 else {"dcgan32": 4, "mnist": 16}.get(args.arch, 1) if not args.sync_bn else 1
+    if args.graph is None:
+        args.graph = not args.sync_bn                                    # (synchronised batch norm has a collective inside the program)
     engines = [RefineEngine(args.arch, P, B * G, dev, use_graph=args.graph, sync_bn=True if args.sync_bn else None, bn_groups=G)
                for _ in range(args.streams if args.streams > 0 else 2)]
     streams = [torch.cuda.Stream(dev) for _ in engines] if len(engines) > 1 else [torch.cuda.current_stream(dev)]
@@ -293,18 +301,25 @@ def main():
     dt = time.perf_counter() - t0
     prof, K.PROFILE = K.PROFILE, None
     prof_ms, prof_note = dt * 1e3, "HIP events around every launch inside the timed region"
-    if rank == 0 and not args.graph and not live_profile:
+    if rank == 0 and not live_profile:
         # several batches in flight: kernels of different streams overlap, so a per-launch duration taken inside the
-        # timed region would include the other stream's work.  Time ONE more step alone on one stream instead.
+        # timed region would include the other stream's work; and a replayed hipGraph has no per-launch host hook.
+        # Time ONE more step alone on one stream instead, launched eagerly (the same kernels with the same arguments).
+        prof_eng = engines[0] if not args.graph else RefineEngine(args.arch, P, B * G, dev, use_graph=False,
+                                                                  sync_bn=True if args.sync_bn else None, bn_groups=G)
+        if args.graph:                                                   # (untimed first pass: packs weights, sizes workspaces)
+            with torch.cuda.stream(streams[0]):
+                prof_eng.refine_from_z(z[args.warmup], Ksteps, args.rate)
+            torch.cuda.synchronize(dev)
         K.PROFILE = {}
         K.PROFILE_BY_LAYER = args.by_layer
         tp = time.perf_counter()
         with torch.cuda.stream(streams[0]):
-            engines[0].refine_from_z(z[args.warmup], Ksteps, args.rate)
+            prof_eng.refine_from_z(z[args.warmup], Ksteps, args.rate)
         torch.cuda.synchronize(dev)
         prof_ms = (time.perf_counter() - tp) * 1e3
         prof, K.PROFILE = K.PROFILE, None
-        prof_note = "HIP events around every launch of one extra single-stream step right after the timed region"
+        prof_note = "HIP events around every launch of one extra single-stream step right after the timed region" + (" (launched eagerly; the timed region replays hipGraphs)" if args.graph else "")
     if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
