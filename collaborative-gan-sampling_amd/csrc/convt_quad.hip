@@ -338,11 +338,13 @@ __global__ __launch_bounds__(256, 2) void convt_quad_lds_kernel(QuadParams p, in
 //   Q[Y][c][(kx, n)] = sum_{ky = Y + pt - 2r, ci} in[b, r, c, ci] * w[ky][kx][n][ci]              (MFMA, 94 % useful for 5x5x3)
 //   out[b, Y, X, n]  = epi(bias[n] + sum_{kx = X + pl - 2c} Q[Y][c][(kx, n)])                     (<= 3 terms, from LDS)
 //
-// One wave owns one output row pair (2R, 2R+1) of one image: M = the Ws input pixels of a row (MT tiles of 16), its A fragments
-// come straight from global memory (each lane one float4 = 4 channels of its pixel; the row is read by the 3 row pairs that
-// use it, which run back to back in neighbouring waves -> L1/L2), the packed weights (kh * Cs * 16 floats, 20 KB) sit in LDS for
-// the whole persistent block, and the waves never synchronise with each other.  The horizontal gather runs through a per-wave
-// LDS staging tile with per-lane offsets computed once per block; the summation order is fixed (deterministic).
+// One wave owns TWO consecutive output row pairs (rows 2R0 .. 2R0+3) of one image: M = the Ws input pixels of a row (MT tiles of
+// 16), its A fragments come straight from global memory (each lane one float4 = 4 channels of its pixel; the ny + 1 = 4 input rows
+// are read once for both pairs, and again by the neighbouring task that shares two of them -> L1/L2), the packed weights
+// (kh * Cs * 16 floats, 20 KB) sit in LDS for the whole persistent block, and the waves never synchronise with each other.  The
+// horizontal gather runs through a per-wave LDS staging tile with a per-lane plan kept in an LDS table; the summation order is
+// fixed (deterministic).  Reference semantics: tf.nn.conv2d_transpose 'SAME' (nsgan/ops.py:48-67) and the conv's
+// Conv2DBackpropInput (sampling/collaborator.py:31).
 // ------------------------------------------------------------------------------------------------
 struct RowsParams {
     const float* in;     // [B,Hs,Ws,Cs]

@@ -235,12 +235,22 @@ __global__ __launch_bounds__(64 * NW, 2) void igemm_kernel(IgemmParams p) {
     // GEMM row m -> (image b, base pixel r, cc).  Image-major: m = b*RC + pixel (rows of a tile are neighbouring
     // pixels: their taps overlap, L1/L2 reuse).  Pixel-major: m = pixel*B + b (rows of a tile are the SAME pixel of
     // 128 images: a tap that falls in the zero padding does so for the whole tile and is skipped, below).
+    // One-pixel tiles (pixel-major and every row of the tile inside one base pixel -- all tiles of an lpt launch): the pixel is a
+    // property of the BLOCK, so its decode is two scalar divisions once instead of two vector divisions per row and thread (the
+    // prologue ran ~500 VALU instructions per thread, half of them these; it runs at priority 3 in front of the other blocks' MFMAs)
+    const int mlast_ = m0 + BM - 1 < M ? m0 + BM - 1 : M - 1;
+    const bool one_pix = p.pix_major && (m0 / p.B) == (mlast_ / p.B);
+    const int t_pix = one_pix ? m0 / p.B : 0;
+    const int t_b0 = m0 - t_pix * p.B, t_r = t_pix / c.C, t_cc = t_pix - (t_pix / c.C) * c.C;
 #define DECODE_ROW(m_, b_, r_, cc_)                                        \
     do {                                                                   \
-        int rem_;                                                          \
-        if (p.pix_major) { rem_ = (m_) / p.B; b_ = (m_) - rem_ * p.B; }    \
-        else { b_ = (m_) / RC; rem_ = (m_) - b_ * RC; }                    \
-        r_ = rem_ / c.C; cc_ = rem_ - r_ * c.C;                            \
+        if (one_pix) { b_ = t_b0 + ((m_) - m0); r_ = t_r; cc_ = t_cc; }    \
+        else {                                                             \
+            int rem_;                                                      \
+            if (p.pix_major) { rem_ = (m_) / p.B; b_ = (m_) - rem_ * p.B; } \
+            else { b_ = (m_) / RC; rem_ = (m_) - b_ * RC; }                \
+            r_ = rem_ / c.C; cc_ = rem_ - r_ * c.C;                        \
+        }                                                                  \
     } while (0)
 
     if (tid < BM) {
@@ -280,17 +290,8 @@ __global__ __launch_bounds__(64 * NW, 2) void igemm_kernel(IgemmParams p) {
 
     // zero-tap skipping (pixel-major, VEC): if every row of this tile is the same base pixel, a tap outside the
     // image contributes exact zeros for all rows -> its Cred/32 K-chunks are not loaded or multiplied at all.
-    bool skip_ok = false;
-    int u_iy = 0, u_ix = 0;
-    if (VEC && p.pix_major) {
-        const int mlast = (m0 + BM - 1 < M ? m0 + BM - 1 : M - 1);
-        const int pf = m0 / p.B, pl = mlast / p.B;
-        if (pf == pl) {
-            skip_ok = true;
-            const int r = pf / c.C, cc = pf - r * c.C;
-            u_iy = r * p.S + c.dy0; u_ix = cc * p.S + c.dx0;
-        }
-    }
+    const bool skip_ok = VEC && one_pix;
+    const int u_iy = t_r * p.S + c.dy0, u_ix = t_cc * p.S + c.dx0;      // (used only with skip_ok)
     // VEC K order: K tile kt = chunk * ntaps + tap, i.e. the taps are the INNER loop of each 32-channel chunk.
     // The 25 (9/6/6/4) taps of a tile re-read one input patch; with the taps inner only a 32-channel slice of the
     // patch is live at a time, so the working set of an XCD's resident blocks fits its 4 MiB L2 and the tap
@@ -440,14 +441,24 @@ __global__ __launch_bounds__(64 * NW, 2) void igemm_kernel(IgemmParams p) {
     // which taps of row i lie inside the image: bit ia (tap row, visiting order) and bit 16 + ib (tap column) -- the per-tile
     // bounds check is then one v_and + one v_cmp against a scalar (VEC kernels have at most 16 taps per axis, see cgs_geom_*)
     unsigned tapmask[AI];
-#pragma unroll
-    for (int i = 0; i < AI; ++i) {
+    if (one_pix) {       // the same mask for every row of the tile: built once on the scalar unit (rows past M: no tap)
         unsigned mk = 0;
         for (int ia = 0; ia < c.nty; ++ia)
-            if ((unsigned)(a_iy[i] + cgs_tap_order(ia, c.nty, PAR) * p.dstep) < (unsigned)p.Hin) mk |= 1u << ia;
+            if ((unsigned)(u_iy + cgs_tap_order(ia, c.nty, PAR) * p.dstep) < (unsigned)p.Hin) mk |= 1u << ia;
         for (int ib = 0; ib < c.ntx; ++ib)
-            if ((unsigned)(a_ix[i] + cgs_tap_order(ib, c.ntx, PAR) * p.dstep) < (unsigned)p.Win) mk |= 1u << (16 + ib);
-        tapmask[i] = mk;
+            if ((unsigned)(u_ix + cgs_tap_order(ib, c.ntx, PAR) * p.dstep) < (unsigned)p.Win) mk |= 1u << (16 + ib);
+#pragma unroll
+        for (int i = 0; i < AI; ++i) tapmask[i] = m0 + ar + AR * i < M ? mk : 0u;
+    } else {
+#pragma unroll
+        for (int i = 0; i < AI; ++i) {
+            unsigned mk = 0;
+            for (int ia = 0; ia < c.nty; ++ia)
+                if ((unsigned)(a_iy[i] + cgs_tap_order(ia, c.nty, PAR) * p.dstep) < (unsigned)p.Hin) mk |= 1u << ia;
+            for (int ib = 0; ib < c.ntx; ++ib)
+                if ((unsigned)(a_ix[i] + cgs_tap_order(ib, c.ntx, PAR) * p.dstep) < (unsigned)p.Win) mk |= 1u << (16 + ib);
+            tapmask[i] = mk;
+        }
     }
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)wsrc, 0, 0x7ffffff0, 0x00020000);
     const int b_tile_bytes = (BK / 4) * p.Np * 16;
