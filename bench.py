@@ -198,7 +198,7 @@ def self_launch(n_gpus):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=0, help="timed steps (default 4; 256 for synthetic2d, whose step is 0.05 ms)")
+    ap.add_argument("--steps", type=int, default=0, help="timed steps (default 12: ms_per_step_median is then the median of 11 completion gaps; 256 for synthetic2d, whose step is 0.05 ms)")
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--arch", default="dcgan64", choices=["mnist", "dcgan32", "dcgan64", "synthetic2d", "cyclegan256"],
                     help="synthetic2d = BASELINE config 1 (2-D MLP GAN, batch 512, K=10, ladam) on the fused device refiner")
@@ -224,7 +224,7 @@ def main():
     ap.add_argument("--by-layer", action="store_true", help="key the per-kernel timing records by layer shape too (diagnostic)")
     args = ap.parse_args()
     if args.steps <= 0:
-        args.steps = 256 if args.arch == "synthetic2d" else 4
+        args.steps = 256 if args.arch == "synthetic2d" else 12
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC for RCCL; must be set before HIP initialises
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
