@@ -256,7 +256,10 @@ def main():
         raise SystemExit("--sync-bn needs the torch.distributed launch (python -m torch.distributed.run ... bench.py)")
     G = args.fuse if args.fuse > 0 else {"dcgan32": 4, "mnist": 16}.get(args.arch, 1) if not args.sync_bn else 1
     if args.graph is None:
-        args.graph = not args.sync_bn                                    # (synchronised batch norm has a collective inside the program)
+        # default: replay graphs on the single-GPU run; launch eagerly under the multi-process launch, where graph capture next to
+        # RCCL's threads could not be exercised on hardware here (--graph turns it on there too), and with synchronised batch norm,
+        # which has a collective inside the program
+        args.graph = (not use_dist or world == 1) and not args.sync_bn
     engines = [RefineEngine(args.arch, P, B * G, dev, use_graph=args.graph, sync_bn=True if args.sync_bn else None, bn_groups=G)
                for _ in range(args.streams if args.streams > 0 else 2)]
     streams = [torch.cuda.Stream(dev) for _ in engines] if len(engines) > 1 else [torch.cuda.current_stream(dev)]

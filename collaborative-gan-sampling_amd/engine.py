@@ -553,7 +553,9 @@ class RefineEngine:
                         self.theta.copy_(feature0)
                     torch.cuda.synchronize(self.dev)
                     g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, stream=self._gstream):
+                    # (thread-local capture: other threads of the process -- RCCL proxies, the distributed watchdog, a second engine's
+                    # host thread -- may make HIP calls meanwhile without invalidating this capture)
+                    with torch.cuda.graph(g, stream=self._gstream, capture_error_mode="thread_local"):
                         self._program(steps, rate, alpha, prob, vmin, vmax)
                     cur.wait_stream(self._gstream)
                     self._graphs[key] = g
