@@ -14,10 +14,15 @@ launched eagerly on one stream right after the timed region (the same kernels wi
 
 N > 1: one process per GPU (torch.distributed, backend nccl = RCCL), independent z-batches per rank
 (seed 2019+rank, weak scaling), and ONE RCCL all-gather per step of the refined images into the
-node-wide sample pool -- inside the timed region.
+node-wide sample pool -- inside the timed region, and timed by itself with HIP events (`dist.gather_ms_per_step`).
+The `dist` object of the line says what the collective layer really saw: backend, dist.get_world_size(), the number of
+distinct ranks an all-gather of rank ids returned, pool bytes, per-rank throughput.
+`--backend gloo --share-gpu` is the debug transport: all ranks on device 0, the pool staged through the host -- the whole
+N-rank control flow (self-launch, rank-offset seeds, gather, MAX-reduce, one JSON line) on a 1-GPU box.
 
     python bench.py --gpus 1 --steps 3 --warmup 1
     python -m torch.distributed.run --nproc-per-node 8 ... bench.py --gpus 8 --steps 3 --warmup 1
+    python bench.py --gpus 2 --backend gloo --share-gpu --arch mnist --steps 2 --warmup 1      (1-GPU box)
 """
 import argparse
 import json
@@ -32,60 +37,136 @@ import numpy as np
 import torch
 
 PEAK_FP32_MATRIX_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+PEAK_HBM_GBPS = 8000.0              # same guide: HBM3E ~ 8 TB/s
 # HBM-side bytes per launch from rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in separate runs of this same
 # command, FETCH_SIZE doubled per the gfx950 correction of the guide); collected offline, see profiles/README.md
 TRAFFIC_JSON = os.path.join(ROOT, "profiles", "traffic.json")
 
 
-def measured_traffic(kernel):
-    """HBM bytes per launch of ``kernel`` from the committed PMC passes -- or None when profiles/traffic.json was collected
-    on other kernel sources than the ones this run executes (a stale number is worse than none)."""
+# HBM-bound multi-kernel entry points -> the kernels one call launches (rocprofv3 names; the last one runs once per call)
+HBM_OPS = {
+    "bn_train_lrelu_fwd_from_partials": ["bn_slice_sums_kernel", "bn_finalize_slices_kernel", "bn_apply_fwd_kernel"],
+    "bn_train_lrelu_bwd_data": ["bn_partial_kernel<1>", "bn_finalize_kernel<1>", "bn_restat_kernel", "bn_apply_bwd_kernel"],
+    "refine_update": ["refine_update_kernel"],
+}
+THREE_CHANNEL = ("convt_rows_kernel", "conv_patch2_kernel", "conv_patch_kernel", "convt_quad")
+
+
+def _traffic_table():
+    """profiles/traffic.json -- or {} when it was collected on other kernel sources than the ones this run executes (a stale
+    number is worse than none), or when CGS_LIB points the run at some other build of the library."""
     try:
         from cgs_amd.lib import source_hash
+        if os.environ.get("CGS_LIB"):
+            return {}
         with open(TRAFFIC_JSON) as f:
             t = json.load(f)
-        if t.get("_source_sha256") != source_hash():
-            return None
-        return t.get(kernel, {}).get("hbm_bytes_per_launch_corrected")
+        return t if t.get("_source_sha256") == source_hash() else {}
     except (OSError, ValueError):
-        return None
+        return {}
 
 
-def cpu_baseline(arch, refine_steps, rate, budget_batch=64):
+def measured_traffic(name, table=None):
+    """HBM bytes per launch of a kernel (or per call of an HBM_OPS entry point: its kernels' bytes summed) from the committed
+    PMC passes; None when unknown."""
+    t = _traffic_table() if table is None else table
+    if name in HBM_OPS:
+        ks = HBM_OPS[name]
+        if not all(k in t for k in ks):
+            return None
+        calls = t[ks[-1]]["launches"]
+        return int(sum(t[k]["hbm_bytes_per_launch_corrected"] * t[k]["launches"] for k in ks) / max(1, calls))
+    return t.get(name, {}).get("hbm_bytes_per_launch_corrected")
+
+
+def profile_records(prof, prof_ms, step_ms, timing_note, with_traffic, prof_steps=1):
+    """The per-kernel HIP-event records of one profiled step -> (roofline, kernels, hbm, executed flops of the step).
+
+    roofline: the dominant kernel.  ``achieved`` / ``frac`` count what is ISSUED to the matrix cores: the implicit-GEMM
+    kernels skip the K tiles of taps that fall into the zero padding (exact -- they only add zeros), so the dense count of
+    SURVEY.md 8(d) (``nominal`` / ``nominal_frac``) bills 7-28 % work that no exact implementation has to do and can exceed
+    the machine's peak; frac <= 1 by construction.
+    hbm: the HBM-bound launches (3-channel conv kernels, batch-norm passes, the momentum update): algorithmic bytes (every
+    operand once) / launch time against the 8 TB/s peak, and the PMC-measured bytes over the algorithmic ones."""
+    table = _traffic_table() if with_traffic else {}
+    per, hbm, ex_total = {}, {}, 0.0
+    for name, (fl, evs, ex, nb) in prof.items():
+        ms = sum(a.elapsed_time(b) for a, b in evs)
+        ex_total += ex
+        n = len(evs)
+        if fl > 0 and name not in ("linear_out1_fwd", "linear_out1_bwd"):
+            per[name] = {"launches": n, "avg_us": round(1e3 * ms / n, 2), "tflops": round(ex / ms / 1e9, 2),
+                         "nominal_tflops": round(fl / ms / 1e9, 2), "share_of_step": round(ms / prof_ms, 3)}
+        if fl == 0 or name.startswith(THREE_CHANNEL) or name.startswith("linear_out1"):
+            gbps = nb / ms / 1e6
+            tr = measured_traffic(name, table)
+            hbm[name] = {"launches": n, "avg_us": round(1e3 * ms / n, 2), "algorithmic_bytes": int(nb / n),
+                         "achieved": round(gbps, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(gbps / PEAK_HBM_GBPS, 4),
+                         "traffic": tr, "traffic_over_algorithmic": round(tr / (nb / n), 3) if tr else None,
+                         "share_of_step": round(ms / prof_ms, 3)}
+    mf = {k: v for k, v in prof.items() if v[0] > 0}
+    name, (fl, evs, ex, nb) = max(mf.items(), key=lambda kv: sum(a.elapsed_time(b) for a, b in kv[1][1]))
+    ms = sum(a.elapsed_time(b) for a, b in evs)
+    n = len(evs)
+    tr = measured_traffic(name, table)
+    roof = {"kernel": name, "bound": "mfma", "achieved": round(ex / ms / 1e9, 2), "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(ex / ms / 1e9 / PEAK_FP32_MATRIX_TFLOPS, 4),
+            "nominal": round(fl / ms / 1e9, 2), "nominal_frac": round(fl / ms / 1e9 / PEAK_FP32_MATRIX_TFLOPS, 4),
+            "traffic": tr, "algorithmic_bytes": int(nb / n), "traffic_over_algorithmic": round(tr / (nb / n), 3) if tr else None,
+            "launches": n, "avg_launch_us": round(1e3 * ms / n, 2), "share_of_step": round(ms / prof_ms, 3), "timing": timing_note,
+            "flop_per_launch": round(ex / n, 0), "nominal_flop_per_launch": round(fl / n, 0),
+            "step_executed_tflops": round(ex_total / prof_steps / step_ms / 1e9, 2),
+            "step_executed_frac": round(ex_total / prof_steps / step_ms / 1e9 / PEAK_FP32_MATRIX_TFLOPS, 4),
+            "note": "achieved/frac = flops issued to the matrix cores / launch time (padding taps the kernel skips exactly are not "
+                    "counted, so frac <= 1); nominal* = the dense count of SURVEY 8(d), padding taps included; step_executed_* = all "
+                    "contraction launches of one step / the measured ms_per_step"}
+    return roof, per, hbm, ex_total / prof_steps
+
+
+_CPU_THREADS = [None]          # the calibrated thread count of the headline's cpu_baseline, reused for the other configs
+
+
+def cpu_baseline(arch, refine_steps, rate, seconds=15.0, max_batch=512):
     """The CPU oracle (torch-CPU fp32 restatement of collaborator.build_refiner) timed on the host cores
     on a bounded sample of the same workload (same net, same K, a smaller batch: work is linear in B)."""
     from oracle import nets_ref as N
     from oracle import sampling_ref as S
     P = N.init_params(arch, 2019, True)
-    zdim = N.ARCHS[arch]["z_dim"]
+    A = N.ARCHS[arch]
+    in_shape = tuple(A["g_in"]) if A.get("g_in") else (A["z_dim"],)
     gt, dd = (lambda f: N.feature_to_data(arch, P, f)), (lambda x: N.discriminator(arch, P, x))
 
     def run(B, K):
-        z = torch.from_numpy(np.random.RandomState(0).uniform(-1, 1, (B, zdim)).astype(np.float32))
+        z = torch.from_numpy(np.random.RandomState(0).uniform(-1, 1, (B,) + in_shape).astype(np.float32))
         with torch.no_grad():
             f0 = N.input_to_feature(arch, P, z)
         t = time.time()
         S.collaborative_refine(f0, gt, dd, K, rate)
         return time.time() - t
-    run(4, 1)                                  # warm the thread pool / allocator
+    unit = 2 if arch == "cyclegan256" else 32                  # pilot batch
+    run(min(4, unit), 1)                                       # warm the thread pool / allocator
     # more threads is not faster on these layer sizes (8 cores beat 128 on the first boxes measured): calibrate the
-    # thread count on a small run and time the sample with the best one
+    # thread count once (on the headline's net) on a small run and time the samples with the best one
     ncpu = os.cpu_count() or 1
-    best_n, best_t = torch.get_num_threads(), None
-    for n in sorted({c for c in (8, 16, 32, 64, ncpu) if c <= ncpu}):
-        torch.set_num_threads(n)
-        run(8, 1)
-        t = run(32, 1) / 4.0               # (per 8 samples; a 32-sample run is long enough to rank the thread counts reliably)
-        if best_t is None or t < best_t:
-            best_n, best_t = n, t
+    if _CPU_THREADS[0] is None:
+        best_n, best_t = torch.get_num_threads(), None
+        for n in sorted({c for c in (8, 16, 32, 64, ncpu) if c <= ncpu}):
+            torch.set_num_threads(n)
+            run(8 if unit > 8 else unit, 1)
+            t = run(unit, 1)               # (a 32-sample run is long enough to rank the thread counts reliably)
+            if best_t is None or t < best_t:
+                best_n, best_t = n, t
+        _CPU_THREADS[0] = best_n
+    best_n = _CPU_THREADS[0]
     torch.set_num_threads(best_n)
-    # size the sample for ~15 s of CPU work from a 32-sample pilot at the full K
-    pilot = run(32, refine_steps)
-    budget_batch = int(min(512, max(budget_batch, 32 * round(15.0 / pilot))))
-    dt = run(budget_batch, refine_steps)
-    return {"value": round(budget_batch / dt, 3), "unit": "samples/s", "cores": best_n, "kind": "port",
-            "sample": f"oracle.collaborative_refine (torch-CPU fp32), {arch}, batch {budget_batch}, K={refine_steps}, "
-                      f"{dt:.1f} s wall, {best_n} of {ncpu} host threads (fastest of a 8/16/32/64/all calibration)"}
+    # size the sample for ~`seconds` of CPU work from a pilot at the full K
+    pilot = run(unit, refine_steps)
+    batch = int(min(max_batch, max(unit, unit * round(seconds / pilot))))
+    dt = run(batch, refine_steps) if batch != unit else pilot
+    return {"value": round(batch / dt, 3), "unit": "samples/s", "cores": best_n, "kind": "port",
+            "sample": f"oracle.collaborative_refine (torch-CPU fp32), {arch}, batch {batch}, K={refine_steps}, "
+                      f"{dt:.1f} s wall, {best_n} of {ncpu} host threads (fastest of a 8/16/32/64/all calibration; a reported "
+                      f"baseline that moves 10-20 % from run to run with the box's other tenants, never a target)"}
 
 
 def run_synthetic2d(dev, rank, B, Ksteps, rate, steps, warmup, n_streams):
@@ -143,9 +224,29 @@ def bench_synthetic2d(args, dev, rank, world):
         print(json.dumps(out), flush=True)
 
 
-def other_configs(dev, skip):
-    """samples/s of the other single-GPU configurations ("always report MNIST"; BASELINE configs[0], [1]) at
-    their bench.py defaults, timed AFTER and OUTSIDE the headline's timed region: a handful of steps each, value only."""
+def profile_one_step(arch, P, B, G, Ksteps, rate, z1, dev, stream, by_layer=False, sync_bn=None, engine=None):
+    """One step launched eagerly on ONE stream with HIP events around every launch (kernels.PROFILE): what `roofline`,
+    `kernels` and `hbm` are computed from when the timed region overlaps streams or replays hipGraphs."""
+    from cgs_amd import kernels as K
+    from cgs_amd.engine import RefineEngine
+    eng = engine if engine is not None else RefineEngine(arch, P, B * G, dev, use_graph=False, sync_bn=sync_bn, bn_groups=G)
+    with torch.cuda.stream(stream):
+        eng.refine_from_z(z1, Ksteps, rate)                             # (untimed first pass: packs weights, sizes workspaces)
+    torch.cuda.synchronize(dev)
+    K.PROFILE, K.PROFILE_BY_LAYER = {}, by_layer
+    tp = time.perf_counter()
+    with torch.cuda.stream(stream):
+        eng.refine_from_z(z1, Ksteps, rate)
+    torch.cuda.synchronize(dev)
+    ms = (time.perf_counter() - tp) * 1e3
+    prof, K.PROFILE = K.PROFILE, None
+    return prof, ms
+
+
+def other_configs(dev, skip, want_cpu):
+    """The other single-GPU configurations ("always report MNIST"; BASELINE configs[0], [1]) at their bench.py
+    defaults, timed AFTER and OUTSIDE the headline's timed region: a handful of steps each, with their own `roofline`
+    (one extra eager single-stream step, as for the headline) and a short `cpu_baseline`."""
     from cgs_amd import nets
     from cgs_amd.engine import RefineEngine
     out = {}
@@ -169,14 +270,22 @@ def other_configs(dev, skip):
         torch.cuda.synchronize(dev)
         dt = time.perf_counter() - t0
         out[arch] = {"samples_per_s": round(B * G * steps / dt, 1), "batch": B, "refine_steps": Ksteps, "fused_per_launch": G,
-                     "batches_in_flight": 2 * G, "steps": steps,
+                     "batches_in_flight": 2 * G, "steps": steps, "hipgraph": True,
                      "algorithmic_tflops": round(B * G * steps / dt * nets.refine_flops_per_sample(arch, Ksteps) / 1e12, 2)}
-        del engines, z, P
+        del engines
+        prof, prof_ms = profile_one_step(arch, P, B, G, Ksteps, 0.1, z[0], dev, streams[0])
+        roof, _, hbm, _ = profile_records(prof, prof_ms, 1e3 * dt / steps, "one extra eager single-stream step", False)
+        roof.pop("note"); roof.pop("traffic"); roof.pop("traffic_over_algorithmic")
+        out[arch]["roofline"] = roof
+        out[arch]["hbm"] = {k: {f: v[f] for f in ("avg_us", "achieved", "frac", "share_of_step")} for k, v in hbm.items()}
+        if want_cpu:
+            out[arch]["cpu_baseline"] = cpu_baseline(arch, Ksteps, 0.1, seconds=4.0, max_batch=128)
+        del z, P
         torch.cuda.empty_cache()
     if skip != "synthetic2d":
         dt, _ = run_synthetic2d(dev, 0, 512, 10, 0.1, 256, 16, 8)
         out["synthetic2d"] = {"samples_per_s": round(512 * 256 / dt, 1), "batch": 512, "refine_steps": 10, "method": "ladam",
-                              "batches_in_flight": 8, "steps": 256}
+                              "batches_in_flight": 8, "steps": 256, "roofline": None}
     return out
 
 
@@ -206,8 +315,10 @@ def main():
     ap.add_argument("--refine-steps", type=int, default=0, help="K (default: 20; 50 for mnist)")
     ap.add_argument("--rate", type=float, default=0.1)
     ap.add_argument("--graph", dest="graph", action="store_true", default=None,
-                    help="replay the K-step program as a hipGraph (the default for the refinement archs: +1.3 %% on the dcgan64 headline, the "
-                         "launch gaps between the ~1300 dependent kernels of a step otherwise only partly hide behind the other batch in flight)")
+                    help="replay the K-step program as a hipGraph (the default, at every world size: +1.3 %% on the dcgan64 headline, +14 %% on "
+                         "mnist -- the launch gaps between the ~1300 dependent kernels of a step otherwise only partly hide behind the other "
+                         "batch in flight).  By default a failed capture falls back to eager launches in the same process and the line says so "
+                         "(config.hipgraph false + config.hipgraph_fallback); with --graph given explicitly a failed capture is an error")
     ap.add_argument("--no-graph", dest="graph", action="store_false", help="launch every kernel eagerly")
     ap.add_argument("--streams", type=int, default=0,
                     help="(default 2; 8 for synthetic2d) z-batches in flight per GPU, one engine + HIP stream each: the tail / small kernels of one "
@@ -218,6 +329,12 @@ def main():
     ap.add_argument("--sync-bn", action="store_true",
                     help="treat the N ranks' batches as ONE logical batch of N*B samples: all-reduce D's batch-norm sums "
                          "(needs the torch.distributed launch; eager only)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend: nccl = RCCL over xGMI (the product path); gloo = debug transport, the pool is staged "
+                         "through the host (what a 1-GPU box can run at world size 2 together with --share-gpu)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="every rank uses device 0 (debug: the N-rank control flow on a 1-GPU box; RCCL refuses two ranks on one device, so "
+                         "this needs --backend gloo)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the mnist / dcgan32 / synthetic2d samples/s that are measured after the headline's timed region")
@@ -225,25 +342,35 @@ def main():
     args = ap.parse_args()
     if args.steps <= 0:
         args.steps = 256 if args.arch == "synthetic2d" else 12
+    if args.share_gpu and args.backend == "nccl" and args.gpus > 1:
+        raise SystemExit("--share-gpu puts every rank on device 0, which RCCL refuses: add --backend gloo")
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC for RCCL; must be set before HIP initialises
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return self_launch(args.gpus)
-    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
-    local = int(os.environ.get("LOCAL_RANK", 0))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    env_world = int(os.environ.get("WORLD_SIZE", 1))
+    if env_world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={env_world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    local = 0 if args.share_gpu else int(os.environ.get("LOCAL_RANK", 0))
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (there is no CPU path to benchmark)"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     use_dist = "RANK" in os.environ and "MASTER_ADDR" in os.environ      # launched by torch.distributed.run (any world size)
+    rank, world = 0, 1
     if use_dist:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
+        rank, world = dist.get_rank(), dist.get_world_size()             # what the process group says, not the environment
+        if world != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but the process group has {world} ranks")
 
     if args.arch == "synthetic2d":
         return bench_synthetic2d(args, dev, rank, world)
 
+    from cgs_amd import dist as D
     from cgs_amd import kernels as K
     from cgs_amd import nets
     from cgs_amd.engine import RefineEngine
@@ -255,29 +382,67 @@ def main():
     if args.sync_bn and not use_dist:
         raise SystemExit("--sync-bn needs the torch.distributed launch (python -m torch.distributed.run ... bench.py)")
     G = args.fuse if args.fuse > 0 else {"dcgan32": 4, "mnist": 16}.get(args.arch, 1) if not args.sync_bn else 1
+    graph_forced = args.graph is True
     if args.graph is None:
-        # default: replay graphs on the single-GPU run; launch eagerly under the multi-process launch, where graph capture next to
-        # RCCL's threads could not be exercised on hardware here (--graph turns it on there too), and with synchronised batch norm,
-        # which has a collective inside the program
-        args.graph = (not use_dist or world == 1) and not args.sync_bn
-    engines = [RefineEngine(args.arch, P, B * G, dev, use_graph=args.graph, sync_bn=True if args.sync_bn else None, bn_groups=G)
-               for _ in range(args.streams if args.streams > 0 else 2)]
-    streams = [torch.cuda.Stream(dev) for _ in engines] if len(engines) > 1 else [torch.cuda.current_stream(dev)]
-    eng = engines[0]
+        # default: replay graphs at every world size (the engine captures in thread-local mode on its own side stream, so RCCL's
+        # proxy / watchdog threads may make HIP calls meanwhile); eager only with synchronised batch norm, which has a
+        # collective inside the program
+        args.graph = not args.sync_bn
+    n_flight = args.streams if args.streams > 0 else 2
+    sync = True if args.sync_bn else None
+
+    def build_engines(use_graph):
+        return [RefineEngine(args.arch, P, B * G, dev, use_graph=use_graph, sync_bn=sync, bn_groups=G) for _ in range(n_flight)]
+
+    streams = [torch.cuda.Stream(dev) for _ in range(n_flight)] if n_flight > 1 else [torch.cuda.current_stream(dev)]
     n_batches = args.steps + args.warmup                                # a step = one engine call = G logical batches
-    rs = np.random.RandomState(2019 + rank)                            # rank-offset seed: disjoint z shards
+    rs = np.random.RandomState(D.rank_seed(rank))                       # rank-offset seed (2019 + rank): disjoint z shards
     z = torch.from_numpy(rs.uniform(-1, 1, (n_batches, B * G) + nets.g_input_shape(A)).astype(np.float32)).to(dev)   # z, or source images
     pools = [torch.empty((world * B * G,) + tuple(A["img"]), dtype=torch.float32, device=dev) if use_dist else None
-             for _ in engines]                                           # one node-wide pool buffer per batch in flight
+             for _ in range(n_flight)]                                   # one node-wide pool buffer per batch in flight
 
-    done_ev = []                                                        # one event per timed step, recorded on the step's stream (no host sync)
+    # -- prepare: every engine's first call (packs weights, sizes workspaces, captures its hipGraph).  No collective in here, so
+    # a rank whose capture fails can fall back to eager launches by itself without unbalancing the ranks' gather counts.
+    graph_fallback = None
+
+    def prepare(engs):
+        for e, st in zip(engs, streams):
+            with torch.cuda.stream(st):
+                e.refine_from_z(z[0], Ksteps, args.rate)
+        torch.cuda.synchronize(dev)
+    engines = build_engines(args.graph)
+    try:
+        prepare(engines)
+    except Exception as ex:                                              # noqa: BLE001 (any capture failure: HIP, RCCL threads, allocator)
+        if not args.graph or graph_forced:
+            raise
+        graph_fallback = f"{type(ex).__name__}: {str(ex)[:300]}"
+        print(f"[bench rank {rank}] hipGraph capture failed, launching eagerly instead: {graph_fallback}", file=sys.stderr, flush=True)
+        args.graph = False
+        try:
+            torch.cuda.synchronize(dev)
+        except Exception:                                                # noqa: BLE001
+            pass
+        del engines
+        engines = build_engines(False)
+        prepare(engines)
+    eng = engines[0]
+
+    done_ev, gather_ev = [], []                                         # per timed step: completion event; (before, after) the gather
 
     def step(i):
-        e, st = engines[i % len(engines)], streams[i % len(engines)]
+        j = i % n_flight
+        e, st = engines[j], streams[j]
+        timed = i >= args.warmup
         with torch.cuda.stream(st):
             img = e.refine_from_z(z[i], Ksteps, args.rate)[0]
             if use_dist:
-                dist.all_gather_into_tensor(pools[i % len(engines)], img)      # RCCL over xGMI: the refined sample pool
+                if timed:
+                    g0 = torch.cuda.Event(enable_timing=True); g0.record(st)
+                D.gather_pool(img, out=pools[j])                          # RCCL over xGMI: the refined sample pool
+                if timed:
+                    g1 = torch.cuda.Event(enable_timing=True); g1.record(st)
+                    gather_ev.append((g0, g1))
             if i >= args.warmup - 1 and not os.environ.get("CGS_BENCH_NO_EVENTS"):
                 ev = torch.cuda.Event(enable_timing=True)
                 ev.record(st)
@@ -290,14 +455,16 @@ def main():
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize(dev)
-    live_profile = rank == 0 and not args.graph and len(engines) == 1
+    live_profile = rank == 0 and not args.graph and n_flight == 1
     if live_profile:                      # one batch in flight: per-launch HIP events inside the timed region
         K.PROFILE = {}
         K.PROFILE_BY_LAYER = args.by_layer
     t0 = time.perf_counter()
+    last_img = None
     for i in range(args.warmup, n_batches):
-        step(i)
+        last_img = step(i)
     torch.cuda.synchronize(dev)
+    dt_own = time.perf_counter() - t0                                   # this rank's own work, before it waits for the others
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize(dev)
@@ -308,29 +475,34 @@ def main():
         # several batches in flight: kernels of different streams overlap, so a per-launch duration taken inside the
         # timed region would include the other stream's work; and a replayed hipGraph has no per-launch host hook.
         # Time ONE more step alone on one stream instead, launched eagerly (the same kernels with the same arguments).
-        prof_eng = engines[0] if not args.graph else RefineEngine(args.arch, P, B * G, dev, use_graph=False,
-                                                                  sync_bn=True if args.sync_bn else None, bn_groups=G)
-        if args.graph:                                                   # (untimed first pass: packs weights, sizes workspaces)
-            with torch.cuda.stream(streams[0]):
-                prof_eng.refine_from_z(z[args.warmup], Ksteps, args.rate)
-            torch.cuda.synchronize(dev)
-        K.PROFILE = {}
-        K.PROFILE_BY_LAYER = args.by_layer
-        tp = time.perf_counter()
-        with torch.cuda.stream(streams[0]):
-            prof_eng.refine_from_z(z[args.warmup], Ksteps, args.rate)
-        torch.cuda.synchronize(dev)
-        prof_ms = (time.perf_counter() - tp) * 1e3
-        prof, K.PROFILE = K.PROFILE, None
+        prof, prof_ms = profile_one_step(args.arch, P, B, G, Ksteps, args.rate, z[args.warmup], dev, streams[0], args.by_layer, sync,
+                                         engine=None if args.graph else engines[0])
         prof_note = "HIP events around every launch of one extra single-stream step right after the timed region" + (" (launched eagerly; the timed region replays hipGraphs)" if args.graph else "")
+    dist_rec = None
     if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        # what the collective layer really saw (all ranks take part in these two small all-gathers)
+        own_sum = float(last_img.double().sum().item()) if last_img is not None else 0.0
+        rows = D.all_gather_floats([rank, dt_own, dt, 1.0 if args.graph else 0.0, own_sum], device=dev)
+        dt = float(rows[:, 2].max())                                    # MAX over ranks of the barrier-to-barrier time
+        if rank == 0:
+            jl = (n_batches - 1) % n_flight
+            pool_sums = pools[jl].view(world, -1).double().sum(dim=1).cpu().numpy() if n_batches > 0 else np.zeros(world)
+            per_rank = B * G * args.steps / rows[:, 1]
+            dist_rec = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "ranks_seen": len({int(r) for r in rows[:, 0]}),
+                        "devices": "shared cuda:0 (debug)" if args.share_gpu else "one per rank",
+                        "pool_bytes": int(pools[0].numel() * 4), "gathers_per_step": 1,
+                        "gather_ms_per_step": round(sum(a.elapsed_time(b) for a, b in gather_ev) / max(1, len(gather_ev)), 4),
+                        "gather": "all_gather_into_tensor on the step's stream, HIP events around it" + ("" if args.backend == "nccl" else " (gloo: staged through the host)"),
+                        "per_rank_samples_per_s": [round(float(per_rank.min()), 1), round(float(per_rank.max()), 1)],
+                        "hipgraph_ranks": int(rows[:, 3].sum()),
+                        # rank r's rows of the last pool are rank r's own images (disjoint z shards -> distinct sums)
+                        "pool_rows_match_ranks": bool(np.allclose(pool_sums, rows[:, 4], rtol=1e-9, atol=1e-6)),
+                        "pool_rank_sums_distinct": len({round(float(v), 3) for v in pool_sums}) == world}
 
     if rank == 0:
         value = world * B * G * args.steps / dt
         flops_per_sample = nets.refine_flops_per_sample(args.arch, Ksteps)
+        all_graph = bool(args.graph) if dist_rec is None else dist_rec["hipgraph_ranks"] == world
         out = {
             "metric": f"refined samples/sec @ {Ksteps} refinement steps", "value": round(value, 2), "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
@@ -340,39 +512,27 @@ def main():
                                    f"K={Ksteps}, momentum rate {args.rate}, refine at feature "
                                    f"{list(A['feature'])}, random-init weights, z~U(-1,1) seed 2019+rank",
                        "global_batch": world * B * G, "refine_steps": Ksteps, "parallelism": f"z-shards x{world} + RCCL all-gather of the pool" if world > 1 else "single GPU",
-                       "hipgraph": bool(args.graph), "batches_in_flight": len(engines) * G, "fused_per_launch": G, "sync_bn": bool(args.sync_bn)},
+                       "hipgraph": all_graph, "batches_in_flight": n_flight * G, "fused_per_launch": G, "sync_bn": bool(args.sync_bn)},
             "algorithmic_tflops": round(value * flops_per_sample / 1e12, 2),
         }
-        ns = len(engines)
+        if graph_fallback:
+            out["config"]["hipgraph_fallback"] = graph_fallback
+        if dist_rec is not None:
+            out["dist"] = dist_rec
+        ns = n_flight
         if len(done_ev) >= 3 * ns:   # SURVEY.md 8d "median of >= 10": median gap between a stream's consecutive step completions
             gaps = sorted(a.elapsed_time(b) for a, b in zip(done_ev[:-ns], done_ev[ns:]))     # (GPU timestamps; the ns batches in flight
             out["ms_per_step_median"] = round(gaps[len(gaps) // 2] / ns, 3)                    # finish together, so per stream, / ns)
         if prof:
-            dom = max(prof.items(), key=lambda kv: sum(a.elapsed_time(b) for a, b in kv[1][1]))
-            per = {}
-            for name, (fl, evs, ex) in prof.items():
-                ms = sum(a.elapsed_time(b) for a, b in evs)
-                per[name] = {"launches": len(evs), "avg_us": round(1e3 * ms / len(evs), 2), "tflops": round(fl / ms / 1e9, 2),
-                             "executed_tflops": round(ex / ms / 1e9, 2), "share_of_step": round(ms / prof_ms, 3)}
-            name, (fl, evs, ex) = dom
-            ms = sum(a.elapsed_time(b) for a, b in evs)
-            ach = fl / ms / 1e9
-            # "achieved" divides the ALGORITHMIC flop count (zero-padding taps included, the contract's definition) by the
-            # launch time; "executed_frac" counts only what the kernel issues to the matrix cores: it skips the K tiles of
-            # taps that fall into the padding on the <= 16x16 grids (exact: they add zeros), 7-28 % of those layers
-            out["roofline"] = {"kernel": name, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MATRIX_TFLOPS,
-                               "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MATRIX_TFLOPS, 4),
-                               "executed": round(ex / ms / 1e9, 2), "executed_frac": round(ex / ms / 1e9 / PEAK_FP32_MATRIX_TFLOPS, 4),
-                               "traffic": measured_traffic(name) if args.arch == "dcgan64" and B == 1024 else None,
-                               "launches": len(evs), "avg_launch_us": round(1e3 * ms / len(evs), 2), "timing": prof_note,
-                               "flop_per_launch_avg": round(fl / len(evs), 0), "executed_flop_per_launch_avg": round(ex / len(evs), 0),
-                               "note": "achieved/frac = ALGORITHMIC flops (zero-padding taps included) / launch time, so it can pass 1.0: the kernel "
-                                       "skips the K tiles of padding taps (exact); executed/executed_frac = what is issued to the matrix cores"}
-            out["kernels"] = per
+            out["roofline"], out["kernels"], out["hbm"], ex_step = profile_records(
+                prof, prof_ms, 1e3 * dt / args.steps, prof_note, args.arch == "dcgan64" and B == 1024 and G == 1,
+                prof_steps=args.steps if live_profile else 1)
+            out["executed_tflops"] = round(world * ex_step / (1e3 * dt / args.steps) / 1e9, 2)      # whole job, padding taps not counted
+        cpu = cpu_baseline(args.arch, Ksteps, args.rate) if world == 1 and not args.no_cpu_baseline else None   # (calibrates the host thread count)
         if world == 1 and not args.no_other_configs:
-            out["other_configs"] = other_configs(dev, args.arch)
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.arch, Ksteps, args.rate)
+            out["other_configs"] = other_configs(dev, args.arch, not args.no_cpu_baseline)
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()

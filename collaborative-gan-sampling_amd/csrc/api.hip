@@ -12,6 +12,7 @@ static thread_local double g_last_flops = 0.0;
 
 void cgs_note_kernel(const char* name) { g_last_kernel = name; }
 void cgs_note_flops(double f) { g_last_flops = f; }
+void cgs_add_flops(double f) { g_last_flops += f; }      // per launch: a call that splits its batch (run_dir) sums its chunks
 
 int cgs_set_error(int code, const char* fmt, ...) {
     va_list ap;

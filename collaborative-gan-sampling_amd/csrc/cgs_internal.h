@@ -9,6 +9,7 @@
 int cgs_set_error(int code, const char* fmt, ...);
 void cgs_note_kernel(const char* name);   // remembered per thread, read back by cgs_last_kernel()
 void cgs_note_flops(double executed);     // ... by cgs_last_executed_flops()
+void cgs_add_flops(double executed);      // (accumulating form: one entry point may launch several batch chunks)
 
 #define CGS_CHECK_LAUNCH(name)                                                        \
     do {                                                                              \
@@ -119,6 +120,23 @@ __device__ __forceinline__ float epilogue_apply(float v, int mode, float a, floa
     }
 }
 #endif
+
+
+// hipFuncAttributeMaxDynamicSharedMemorySize belongs to the DEVICE's code object: set it once per device (a process may drive
+// several GPUs) and report a failure instead of letting the launch that follows fail with an unrelated message.
+// CGS_SMEM_ATTR(bytes, "who", kernel<template, args>) -- the kernel last, so its commas need no parentheses.
+#define CGS_SMEM_ATTR(bytes, who, ...)                                                                                  \
+    do {                                                                                                                \
+        static bool smem_done_[64] = {};                                                                                \
+        int smem_dev_ = 0;                                                                                              \
+        (void)hipGetDevice(&smem_dev_);                                                                                 \
+        smem_dev_ &= 63;                                                                                                \
+        if (!smem_done_[smem_dev_]) {                                                                                   \
+            hipError_t smem_e_ = hipFuncSetAttribute((const void*)(__VA_ARGS__), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)); \
+            if (smem_e_ != hipSuccess) return cgs_set_error(CGS_ELAUNCH, "%s: MaxDynamicSharedMemorySize: %s", who, hipGetErrorString(smem_e_)); \
+            smem_done_[smem_dev_] = true;                                                                               \
+        }                                                                                                               \
+    } while (0)
 
 bool cgs_convt_quad_fits(const CgsLayer& L);
 int cgs_conv_smalln_f_ok(const CgsLayer& L, int B, int epilogue);

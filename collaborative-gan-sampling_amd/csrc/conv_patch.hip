@@ -582,12 +582,8 @@ int cgs_conv_patch_launch(const CgsLayer& L, bool dirT, int B, const float* in, 
         }
         const bool auxp = epilogue >= CGS_EPI_RELU_BWD_AFFINE;
         const size_t smem2 = ((size_t)2 * p.PH * p.pitch + (auxp ? (size_t)4 * 32 * 36 : 0)) * sizeof(float);
-        static bool done2 = false;
-        if (!done2) {
-            (void)hipFuncSetAttribute((const void*)conv_patch2_kernel<5, 16, 15, 8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-            (void)hipFuncSetAttribute((const void*)conv_patch2_kernel<5, 16, 15, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-            done2 = true;
-        }
+        CGS_SMEM_ATTR(96 * 1024, "conv_patch2", conv_patch2_kernel<5, 16, 15, 8, false>);
+        CGS_SMEM_ATTR(96 * 1024, "conv_patch2 (aux)", conv_patch2_kernel<5, 16, 15, 8, true>);
         if (smem2 > 96 * 1024 || p.PH * p.PW * p.Cred > 8 * 256) return cgs_set_error(CGS_EINVAL, "conv_patch: patch too large");
         const long tiles2 = (long)B * (p.Hout / TR) * (p.Wout / TC) * (p.Np / PBN);
         if (tiles2 == 0) return CGS_OK;
@@ -611,11 +607,7 @@ int cgs_conv_patch_launch(const CgsLayer& L, bool dirT, int B, const float* in, 
         CGS_CHECK_LAUNCH("pack_patch_weights");
     }
     const size_t smem = ((size_t)p.Kp * PBN + (size_t)2 * p.PH * p.pitch + p.Kp + (size_t)4 * 64 * 36) * sizeof(float);
-    static bool done = false;
-    if (!done) {
-        (void)hipFuncSetAttribute((const void*)conv_patch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        done = true;
-    }
+    CGS_SMEM_ATTR(96 * 1024, "conv_patch", conv_patch_kernel);
     if (smem > 96 * 1024 || p.PH * p.PW * p.Cred > 10 * 256) return cgs_set_error(CGS_EINVAL, "conv_patch: patch too large");
     const long tiles = (long)B * (p.Hout / TR) * (p.Wout / TC) * (p.Np / PBN);
     if (tiles == 0) return CGS_OK;

@@ -700,12 +700,7 @@ int cgs_convt_quad_launch(const CgsLayer& L, int B, const float* in, const float
         const long blocks = (tiles + per - 1) / per;
 #define QUAD_LDS_LAUNCH(NN, TT, YX)                                                                                \
     {                                                                                                              \
-        static bool done_ = false;                                                                                 \
-        if (!done_) {                                                                                              \
-            hipError_t e = hipFuncSetAttribute((const void*)convt_quad_lds_kernel<NN, TT, YX>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-            if (e != hipSuccess) return cgs_set_error(CGS_ELAUNCH, "convt_quad_lds smem attr: %s", hipGetErrorString(e)); \
-            done_ = true;                                                                                          \
-        }                                                                                                          \
+        CGS_SMEM_ATTR(160 * 1024, "convt_quad_lds", convt_quad_lds_kernel<NN, TT, YX>);                            \
         hipLaunchKernelGGL((convt_quad_lds_kernel<NN, TT, YX>), dim3((unsigned)blocks), dim3(256), smem, s, p, (int)tiles, (int)per); \
     }
 #define QUAD_LDS_CASE(NN)                                                                                          \

@@ -1042,7 +1042,7 @@ int cgs_igemm_launch(const IgemmParams& p_in, void* slab, size_t slab_bytes, hip
                 macs += (double)(ml - m0 + 1) * p.N * p.Cred * taps;
             }
         }
-        cgs_note_flops(2.0 * macs);
+        cgs_add_flops(2.0 * macs);
     }
     bool wide = (p.Np % 128) == 0;
     if (wide && p.lpt && maxRC <= 64) {   // uneven tiles (9..25 valid taps on grids <= 8x8) need >= 2 rounds of blocks over the 512 block slots to balance: halve BN if short

@@ -310,7 +310,7 @@ int cgs_mlp2d_sigmoid_saliency(const float* const* w, const float* const* b, int
     if (rc) return rc;
     if (B <= 0 || !x || !sigmoid) return cgs_set_error(CGS_EINVAL, "mlp2d_sigmoid_saliency: bad argument");
     const size_t smem = mlp_smem(nlayers);
-    (void)hipFuncSetAttribute((const void*)mlp_saliency_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    CGS_SMEM_ATTR(160 * 1024, "mlp2d_sigmoid_saliency", mlp_saliency_kernel);
     int blocks = (B + 15) / 16; if (blocks > 256) blocks = 256;
     hipLaunchKernelGGL(mlp_saliency_kernel, dim3(blocks), dim3(1024), smem, (hipStream_t)stream, p, x, sigmoid, saliency, B, inv_batch);
     CGS_CHECK_LAUNCH("mlp2d_sigmoid_saliency");
@@ -325,7 +325,7 @@ static int refine2d_launch(const float* const* w, const float* const* b, int nla
     if (rc) return rc;
     if (B <= 0 || steps < 0 || method < 0 || method > 2 || !x || !best_x || !best_step) return cgs_set_error(CGS_EINVAL, "refine2d: bad argument");
     const size_t smem = mlp_smem(nlayers);
-    (void)hipFuncSetAttribute((const void*)refine2d_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    CGS_SMEM_ATTR(160 * 1024, "refine2d", refine2d_kernel);
     int blocks = (B + 15) / 16; if (blocks > 256) blocks = 256;
     hipLaunchKernelGGL(refine2d_kernel, dim3(blocks), dim3(1024), smem, (hipStream_t)stream, p, x, mean_host, mean_dev, inv_batch, steps, rate,
                        method, best_x, best_step, traj, B);
@@ -365,7 +365,7 @@ int cgs_mlp2d_d_step(float* const* w, float* const* b, int nlayers, int nhidden,
     float* dlast = deltas + (size_t)Bt * (nlayers - 1) * 64;
     float* bce = dlast + Bt;
     const size_t smem = mlp_smem(nlayers);
-    (void)hipFuncSetAttribute((const void*)mlp_train_fwdbwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    CGS_SMEM_ATTR(160 * 1024, "mlp2d_d_step", mlp_train_fwdbwd_kernel);
     for (int part = 0; part < 2; ++part) {      // real rows (target 1) then refined rows (target 0); each loss term is a MEAN
         const int B = part ? B_fake : B_real;
         int blocks = (B + 15) / 16; if (blocks > 256) blocks = 256;

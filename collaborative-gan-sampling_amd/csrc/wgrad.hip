@@ -190,12 +190,8 @@ static int wgrad_run(WgradParams& p, float* dw, int accumulate, void* ws, size_t
     if (!ws || ws_bytes < need) return cgs_set_error(CGS_EWORKSPACE, "%s: workspace %zu < %zu bytes", who, ws_bytes, need);
     p.slab = (float*)ws;
     constexpr size_t smem = (size_t)4 * WK * WLD * sizeof(float);
-    static bool done = false;
-    if (!done) {
-        (void)hipFuncSetAttribute((const void*)wgrad_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        (void)hipFuncSetAttribute((const void*)wgrad_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        done = true;
-    }
+    CGS_SMEM_ATTR(smem, who, wgrad_kernel<true>);
+    CGS_SMEM_ATTR(smem, who, wgrad_kernel<false>);
     const dim3 grid(cgs_ceil_div(p.Kc, WT), cgs_ceil_div(p.Cs, WT), p.splits);
     // VEC: a thread's 4 consecutive rows (tap, cb..cb+3) never straddle a tap when Cb % 4 == 0 -> one 16-byte load
     if ((p.Cb & 3) == 0)

@@ -34,17 +34,43 @@ def batch_owner(global_batch_index, world_size):
     return global_batch_index % world_size, global_batch_index // world_size
 
 
-def gather_pool(local, group=None):
+def gather_pool(local, group=None, out=None, skip_trivial=False):
     """All-gather ``local`` [B, ...] from every rank into [W*B, ...], rank-major (rank r occupies rows r*B:(r+1)*B).
-    One collective; with world size 1 (or no process group) it is the identity."""
+    One collective per pool.  Without a process group it is the identity; with one it ALWAYS runs the collective, world size
+    1 included (the RCCL path a 1-GPU box can exercise is this very function) unless ``skip_trivial``.  "nccl" (= RCCL over
+    xGMI) gathers the device tensors in place on the current stream; any other backend (gloo: the debug transport of
+    ``bench.py --backend gloo --share-gpu`` and the CPU tests) cannot all-gather device tensors and is staged through the host.
+    ``out``: a preallocated pool buffer (bench.py keeps one per batch in flight)."""
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return local
     W = dist.get_world_size(group)
+    if W == 1 and skip_trivial:
+        return local
     local = local.contiguous()
-    pool = torch.empty((W * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(pool, local, group=group)
+    shape = (W * local.shape[0],) + tuple(local.shape[1:])
+    pool = out if out is not None else torch.empty(shape, dtype=local.dtype, device=local.device)
+    if tuple(pool.shape) != shape:
+        raise ValueError(f"gather_pool: pool buffer {tuple(pool.shape)} != {shape}")
+    if local.is_cuda and dist.get_backend(group) != "nccl":
+        host = torch.empty(shape, dtype=local.dtype)
+        dist.all_gather_into_tensor(host, local.cpu(), group=group)
+        pool.copy_(host)
+    else:
+        dist.all_gather_into_tensor(pool, local, group=group)
     return pool
+
+
+def all_gather_floats(values, device=None, group=None):
+    """[W, len(values)] float64 numpy array: every rank's ``values`` (timing / bookkeeping scalars of bench.py).  Device
+    tensors under "nccl", host tensors otherwise."""
+    import torch.distributed as dist
+    W = dist.get_world_size(group)
+    on_dev = dist.get_backend(group) == "nccl"
+    t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=device if on_dev else None)
+    out = torch.empty(W * t.numel(), dtype=torch.float64, device=t.device)        # (flat: gloo checks the concatenated shape)
+    dist.all_gather_into_tensor(out, t, group=group)
+    return out.view(W, t.numel()).cpu().numpy()
 
 
 def refine_pool(refine_fn, z_local, group=None):

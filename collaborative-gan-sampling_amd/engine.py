@@ -286,8 +286,10 @@ class _Unary(_Stage):
         return K.lrelu_bwd(dy, self.out, 0.0, out=dy)
 
 
-def compile_layers(layers, in_shape, P, scope, B, k, stride, bn_training, dev):
-    """Layer list -> stage tape with peephole fusion.  Returns (stages, out_shape)."""
+def compile_layers(layers, in_shape, P, scope, B, k, stride, bn_training, dev, folds=None):
+    """Layer list -> stage tape with peephole fusion.  Returns (stages, out_shape).
+    ``folds`` collects (a, c, gamma, beta, moving_mean, moving_variance) of every folded inference bn: values DERIVED from
+    the parameters, which the engine refreshes in place when the parameters are restored / updated under it."""
     stages, shape, i = [], tuple(in_shape), 0
     n = len(layers)
 
@@ -296,7 +298,11 @@ def compile_layers(layers, in_shape, P, scope, B, k, stride, bn_training, dev):
 
     def fold(name):
         s = f"{scope}/{name}"
-        return K.bn_fold(P[s + "/gamma"], P[s + "/beta"], P[s + "/moving_mean"], P[s + "/moving_variance"])
+        src = (P[s + "/gamma"], P[s + "/beta"], P[s + "/moving_mean"], P[s + "/moving_variance"])
+        a, c = K.bn_fold(*src)
+        if folds is not None:
+            folds.append((a, c) + src)
+        return a, c
 
     while i < n:
         Lr = layers[i]
@@ -342,7 +348,7 @@ def compile_layers(layers, in_shape, P, scope, B, k, stride, bn_training, dev):
             leak, used = (K.LEAK, 2) if kind(i + 1) == "lrelu" else (0.0, 2) if kind(i + 1) == "relu" else (1.0, 1)
             stages.append(_InstNormAct(B, shape, P[sc + "/scale"], P[sc + "/offset"], leak, dev)); i += used
         elif t == "res":
-            inner, ishape = compile_layers(Lr[1], shape, P, scope, B, k, stride, bn_training, dev)
+            inner, ishape = compile_layers(Lr[1], shape, P, scope, B, k, stride, bn_training, dev, folds)
             assert tuple(ishape) == tuple(shape)
             stages.append(_Residual(B, shape, inner, dev)); i += 1
         elif t in ("relu", "lrelu", "tanh"):
@@ -380,7 +386,8 @@ class Tape:
     """A compiled layer list: forward keeps what backward-data needs; no weight gradients."""
 
     def __init__(self, layers, in_shape, P, scope, B, k, stride, bn_training, dev):
-        self.stages, self.out_shape = compile_layers(layers, in_shape, P, scope, B, k, stride, bn_training, dev)
+        self.folds = []
+        self.stages, self.out_shape = compile_layers(layers, in_shape, P, scope, B, k, stride, bn_training, dev, self.folds)
 
     def forward(self, x):
         for st in self.stages:
@@ -421,6 +428,7 @@ class RefineEngine:
         self.use_graph = use_graph
         self._graphs = {}
         self._gstream = None                 # the side stream hipGraphs are warmed up and captured on
+        self._ws_epoch = K.WS.epoch          # the parameter state the folded affines / graph workspaces were derived from
         # sync_bn = True (default process group) or a process group: this engine's batch is one shard of a logical batch of
         # world_size * batch_size samples; D's batch statistics are all-reduced so the result equals the unsplit batch's
         # bn_groups = G: ``batch_size`` holds G logical batches of batch_size / G samples back to back.  Convolutions do not
@@ -465,17 +473,47 @@ class RefineEngine:
                     drop_partials(st.inner)
         drop_partials(self.d.stages); drop_partials(self.g_tail.stages)
 
+    # -- parameters changed under the engine ---------------------------------------------------
+    def _sync_weights(self):
+        """Every entry point starts here: one integer compare.  The parameters are read by pointer (raw gamma / beta / bias /
+        the N == 1 linear), through packed copies (conv / deconv / wide linear weights, cached in ``K.WS``) and through folded
+        inference-bn affines; after ``ops.set_variables`` / a shaping step (``K.WS.invalidate()``) the last two are stale, and a
+        captured hipGraph would replay a MIX of old and new state.  Any engine -- also one built directly, not through
+        ``model.GAN`` -- re-derives them here before its next use."""
+        if self._ws_epoch != K.WS.epoch:
+            self._resync()
+
+    def _resync(self):
+        epoch = K.WS.epoch
+        with torch.cuda.device(self.dev):
+            for tape in (self.g_head, self.g_tail, self.d):
+                for a, c, gamma, beta, mm, mv in tape.folds:
+                    K.bn_fold(gamma, beta, mm, mv, out=(a, c))
+            if self._gstream is not None and self._graphs:
+                # the captured graphs read the workspaces packed on the capture stream: one eager forward + backward there
+                # re-packs every layer into those SAME buffers (eager calls on other streams re-pack lazily by themselves)
+                cur = torch.cuda.current_stream(self.dev)
+                self._gstream.wait_stream(cur)
+                with torch.cuda.stream(self._gstream):
+                    self.forward_logits(self.theta, self.logit)
+                    self.backward_to_feature()
+                cur.wait_stream(self._gstream)
+        self._ws_epoch = epoch
+
     # -- pieces (sampling/collaborator.py:26-39) ------------------------------------------------
     def input_to_feature(self, z):
         """G head (nsgan/GAN.py:87-92)."""
+        self._sync_weights()
         return self.g_head.forward(z)
 
     def feature_to_data(self, feat):
         """G tail (nsgan/GAN.py:94-101)."""
+        self._sync_weights()
         return self.g_tail.forward(feat)
 
     def discriminator(self, x):
         """D with batch-statistics bn (nsgan/GAN.py:59-70 bound at :175)."""
+        self._sync_weights()
         return self.d.forward(x)
 
     def forward_logits(self, theta, logit_out):
@@ -488,6 +526,7 @@ class RefineEngine:
         return self.g_tail.backward(self.d.backward(self.dlogits))
 
     def compute_forward_logits_and_grad(self, feature):
+        self._sync_weights()
         self.forward_logits(feature, self.logit)
         return self.logit, self.backward_to_feature()
 
@@ -533,6 +572,7 @@ class RefineEngine:
             self.forced.copy_(torch.as_tensor(np.asarray(indices), dtype=torch.int32))
         if tuple(feature0.shape) != tuple(self.theta.shape):
             raise L.CgsError(f"feature batch {tuple(feature0.shape)} != engine shape {tuple(self.theta.shape)}")
+        self._sync_weights()
         with torch.cuda.device(self.dev):
             self.theta.copy_(feature0)
             key = (steps, float(rate), alpha, prob, vmin, vmax)
@@ -563,18 +603,11 @@ class RefineEngine:
         return self.images, self.default_logit, self.best_logit, self.best_step, self.best_theta
 
     def refresh_weights(self):
-        """Call after the parameter tensors were updated in place (``shaping.DShaper.step``): re-packs every layer's
-        weights into the existing workspaces (one eager forward + backward on the current stream and, if hipGraphs were
-        captured, one on their capture stream -- the workspaces the graphs read), so captured hipGraphs stay valid."""
+        """Call after the parameter tensors were updated in place by a kernel torch does not see (``shaping.DShaper.step``):
+        marks every packed copy stale (for ALL engines: each one re-derives its state at its next call, ``_sync_weights``)
+        and brings this engine up to date now -- folded affines, and the workspaces its captured hipGraphs read."""
         K.WS.invalidate()
-        with torch.cuda.device(self.dev):
-            self.compute_forward_logits_and_grad(self.theta)
-            if self._gstream is not None:        # the captured graphs read the workspaces packed on the capture stream
-                cur = torch.cuda.current_stream(self.dev)
-                self._gstream.wait_stream(cur)
-                with torch.cuda.stream(self._gstream):
-                    self.compute_forward_logits_and_grad(self.theta)
-                cur.wait_stream(self._gstream)
+        self._resync()
 
     def refine_from_z(self, z, steps, rate, **kw):
         """Propose (G head) + refine + render: one whole unit of the BASELINE metric."""

@@ -31,8 +31,10 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-# ---- optional per-kernel timing (bench.py): {kernel_name: [flops, [(ev_start, ev_end), ...], executed_flops]} or None.
-# Events are recorded on the stream the kernel is launched on (torch's current stream).
+# ---- optional per-kernel timing (bench.py): {name: [flops, [(ev_start, ev_end), ...], executed_flops, algorithmic_bytes]} or None.
+# Events are recorded on the stream the kernel is launched on (torch's current stream).  Conv-family records are keyed by the
+# kernel instantiation the dispatcher launched (cgs_last_kernel); the HBM-bound multi-kernel ops (batch norm passes, the
+# momentum update) by their entry point.
 PROFILE = None
 
 
@@ -40,10 +42,10 @@ PROFILE_BY_LAYER = False      # key the records by kernel + layer shape instead 
 
 
 class _Prof:
-    __slots__ = ("name", "flops", "e0")
+    __slots__ = ("name", "flops", "e0", "nbytes", "op")
 
-    def __init__(self, flops, tag=""):
-        self.name, self.flops, self.e0 = tag, flops, None
+    def __init__(self, flops, tag="", nbytes=0.0, op=None):
+        self.name, self.flops, self.e0, self.nbytes, self.op = tag, flops, None, nbytes, op
         if PROFILE is not None:
             self.e0 = torch.cuda.Event(enable_timing=True)
             self.e0.record()
@@ -52,12 +54,21 @@ class _Prof:
         if self.e0 is not None:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record()
-            kname = L.load().cgs_last_kernel().decode()        # the instantiation the dispatcher actually launched
-            executed = float(L.load().cgs_last_executed_flops()) or self.flops     # minus the skipped zero-padding taps
-            rec = PROFILE.setdefault(kname + " " + self.name if PROFILE_BY_LAYER else kname, [0.0, [], 0.0])
+            if self.op is not None:
+                kname, executed = self.op, self.flops
+            else:
+                kname = L.load().cgs_last_kernel().decode()        # the instantiation the dispatcher actually launched
+                executed = float(L.load().cgs_last_executed_flops()) or self.flops     # minus the skipped zero-padding taps
+            rec = PROFILE.setdefault(kname + " " + self.name if PROFILE_BY_LAYER and self.name else kname, [0.0, [], 0.0, 0.0])
             rec[0] += self.flops
             rec[1].append((self.e0, e1))
             rec[2] += executed
+            rec[3] += self.nbytes
+
+
+def _nb(*tensors):
+    """Algorithmic HBM bytes of a launch: every operand tensor once."""
+    return 4.0 * sum(t.numel() for t in tensors if t is not None)
 
 
 def same_out(size, stride):
@@ -74,6 +85,7 @@ class _WsCache:
     def __init__(self):
         self._d = {}
         self._family = {}
+        self.epoch = 0        # bumped by invalidate(): engines compare it with the epoch their packed copies / folded affines belong to
 
     def plan(self, op, B, H, W, cin, ho, wo, cout, kh, kw, sh, sw, epilogue):
         """(kernel family, workspace bytes) of a call; asked of the library once per distinct call signature."""
@@ -105,14 +117,20 @@ class _WsCache:
             return hit[2], 0
         ws = torch.empty(nbytes // 4, dtype=torch.float32, device=w.device)
         if len(self._d) > 512:
-            self._d.clear()
+            # only entries whose weight tensor is gone: a captured hipGraph holds the raw address of its workspaces
+            # (ws_prepacked = 1), so an entry of a live weight is never dropped behind an engine's back
+            for k in [k for k, v in self._d.items() if v[0]() is None]:
+                del self._d[k]
         self._d[key] = (weakref.ref(w), w._version, ws)
         return ws, 0
 
     def invalidate(self):
-        """Weights were updated in place by a kernel torch does not see (the Adam step): every packed copy is stale."""
+        """Weights were updated in place by a kernel torch does not see (the Adam step, a checkpoint restore): every packed
+        copy is stale.  Eager calls re-pack on their next use; every RefineEngine notices the new epoch at its next call and
+        re-folds its inference-bn affines and re-packs the workspaces its captured hipGraphs read (engine._resync)."""
         for key, (ref, _, ws) in list(self._d.items()):
             self._d[key] = (ref, -1, ws)
+        self.epoch += 1
 
     def clear(self):
         self._d.clear()
@@ -144,7 +162,7 @@ def conv2d_fwd(x, w, bias, sh=2, sw=2, epilogue=L.EPI_NONE, ep_a=None, ep_b=None
     ws, pre = WS.get(w, L.CONV_FWD, kh, kw, sh, sw, Cin, Cout, (B, H, W), epilogue,
                      ptrs=(_ptr(x), _ptr(bias), _ptr(y), _ptr(ep_a), _ptr(ep_b)))
     Ho, Wo = y.shape[1], y.shape[2]
-    pr = _Prof(2.0 * B * Ho * Wo * Cout * kh * kw * Cin, f"conv_fwd {H}x{W} {Cin}->{Cout}") if PROFILE is not None else None
+    pr = _Prof(2.0 * B * Ho * Wo * Cout * kh * kw * Cin, f"conv_fwd {H}x{W} {Cin}->{Cout}", _nb(x, w, y)) if PROFILE is not None else None
     L.call("cgs_conv2d_nhwc_fwd", _ptr(x), _ptr(w), _ptr(bias), _ptr(y), B, H, W, Cin, Cout, kh, kw, sh, sw,
            epilogue, _ptr(ep_a), _ptr(ep_b), _ptr(ws), ws.numel() * 4, pre, _stream())
     if pr is not None:
@@ -171,7 +189,7 @@ def conv2d_fwd_stats(x, w, bias, part, sh=2, sw=2, out=None):
     y = out if out is not None else torch.empty((B, same_out(H, sh), same_out(W, sw), Cout), dtype=torch.float32, device=x.device)
     ws, pre = WS.get(w, L.CONV_FWD, kh, kw, sh, sw, Cin, Cout, (B, H, W), L.EPI_NONE, ptrs=(_ptr(x), _ptr(bias), _ptr(y), _ptr(part)))
     Ho, Wo = y.shape[1], y.shape[2]
-    pr = _Prof(2.0 * B * Ho * Wo * Cout * kh * kw * Cin, f"conv_fwd {H}x{W} {Cin}->{Cout}") if PROFILE is not None else None
+    pr = _Prof(2.0 * B * Ho * Wo * Cout * kh * kw * Cin, f"conv_fwd {H}x{W} {Cin}->{Cout}", _nb(x, w, y)) if PROFILE is not None else None
     L.call("cgs_conv2d_nhwc_fwd_stats", _ptr(x), _ptr(w), _ptr(bias), _ptr(y), B, H, W, Cin, Cout, kh, kw, sh, sw,
            _ptr(ws), ws.numel() * 4, pre, _ptr(part), part.numel() * 4, _stream())
     if pr is not None:
@@ -188,8 +206,11 @@ def bn_train_lrelu_fwd_from_partials(x, part, gamma, beta, leak=LEAK, eps=BN_EPS
     mean, invstd = stats if stats is not None else (torch.empty(C, dtype=torch.float32, device=x.device),
                                                     torch.empty(C, dtype=torch.float32, device=x.device))
     ws = _bn_workspace(M, C, x.device)
+    pr = _Prof(0.0, "", _nb(x, y), op="bn_train_lrelu_fwd_from_partials") if PROFILE is not None else None     # read x, write y
     L.call("cgs_bn_train_lrelu_fwd_from_partials", _ptr(x), _ptr(part), part.shape[0], _ptr(gamma), _ptr(beta), eps, leak, _ptr(y),
            _ptr(mean), _ptr(invstd), M, C, _ptr(ws), ws.numel() * 4, _stream())
+    if pr is not None:
+        pr.done()
     return y, mean, invstd
 
 
@@ -204,7 +225,7 @@ def conv2d_bwd_data(dy, w, in_hw, sh=2, sw=2, out=None, epilogue=L.EPI_NONE, ep_
     ws, pre = WS.get(w, L.CONV_BWD_DATA, kh, kw, sh, sw, Cin, Cout, (B, H, W), epilogue,
                      ptrs=(_ptr(dy), _ptr(dx), _ptr(ep_a), _ptr(ep_aux)))
     Ho, Wo = dy.shape[1], dy.shape[2]
-    pr = _Prof(2.0 * B * Ho * Wo * Cout * kh * kw * Cin, f"conv_bwd {H}x{W} {Cin}<-{Cout}") if PROFILE is not None else None
+    pr = _Prof(2.0 * B * Ho * Wo * Cout * kh * kw * Cin, f"conv_bwd {H}x{W} {Cin}<-{Cout}", _nb(dy, w, dx, ep_aux)) if PROFILE is not None else None
     L.call("cgs_conv2d_nhwc_bwd_data", _ptr(dy), _ptr(w), _ptr(dx), B, H, W, Cin, Cout, kh, kw, sh, sw,
            epilogue, _ptr(ep_a), _ptr(ep_aux), _ptr(ws), ws.numel() * 4, pre, _stream())
     if pr is not None:
@@ -223,7 +244,7 @@ def deconv2d_fwd(x, w, bias, out_hw, sh=2, sw=2, epilogue=L.EPI_NONE, ep_a=None,
     y = out if out is not None else torch.empty((B, Ho, Wo, Cout), dtype=torch.float32, device=x.device)
     ws, pre = WS.get(w, L.DECONV_FWD, kh, kw, sh, sw, Cin, Cout, (B, H, W), epilogue, (Ho, Wo),
                      ptrs=(_ptr(x), _ptr(bias), _ptr(y), _ptr(ep_a), _ptr(ep_b)))
-    pr = _Prof(2.0 * B * H * W * Cin * kh * kw * Cout, f"deconv_fwd {H}x{W} {Cin}->{Cout}") if PROFILE is not None else None
+    pr = _Prof(2.0 * B * H * W * Cin * kh * kw * Cout, f"deconv_fwd {H}x{W} {Cin}->{Cout}", _nb(x, w, y)) if PROFILE is not None else None
     L.call("cgs_deconv2d_nhwc_fwd", _ptr(x), _ptr(w), _ptr(bias), _ptr(y), B, H, W, Cin, Ho, Wo, Cout, kh, kw, sh, sw,
            epilogue, _ptr(ep_a), _ptr(ep_b), _ptr(ws), ws.numel() * 4, pre, _stream())
     if pr is not None:
@@ -240,7 +261,7 @@ def deconv2d_bwd_data(dy, w, in_hw, sh=2, sw=2, out=None, epilogue=L.EPI_NONE, e
     dx = out if out is not None else torch.empty((B, H, W, Cin), dtype=torch.float32, device=dy.device)
     ws, pre = WS.get(w, L.DECONV_BWD_DATA, kh, kw, sh, sw, Cin, Cout, (B, H, W), epilogue, (Ho, Wo),
                      ptrs=(_ptr(dy), _ptr(dx), _ptr(ep_a), _ptr(ep_aux)))
-    pr = _Prof(2.0 * B * H * W * Cin * kh * kw * Cout, f"deconv_bwd {H}x{W} {Cin}<-{Cout}") if PROFILE is not None else None
+    pr = _Prof(2.0 * B * H * W * Cin * kh * kw * Cout, f"deconv_bwd {H}x{W} {Cin}<-{Cout}", _nb(dy, w, dx, ep_aux)) if PROFILE is not None else None
     L.call("cgs_deconv2d_nhwc_bwd_data", _ptr(dy), _ptr(w), _ptr(dx), B, H, W, Cin, Ho, Wo, Cout, kh, kw, sh, sw,
            epilogue, _ptr(ep_a), _ptr(ep_aux), _ptr(ws), ws.numel() * 4, pre, _stream())
     if pr is not None:
@@ -257,10 +278,16 @@ def linear_fwd(x, w, bias, epilogue=L.EPI_NONE, out=None):
         raise L.CgsError(f"linear: Matrix rows {K2} != input features {K}")
     y = out if out is not None else torch.empty((B, N), dtype=torch.float32, device=x.device)
     if N == 1:
+        pr = _Prof(2.0 * B * K, "", _nb(x, w, y), op="linear_out1_fwd") if PROFILE is not None else None
         L.call("cgs_linear_fwd", _ptr(x), _ptr(w), _ptr(bias), _ptr(y), B, K, N, epilogue, None, 0, 0, _stream())
+        if pr is not None:
+            pr.done()
         return y
     ws, pre = WS.get(w, L.CONV_FWD, 1, 1, 1, 1, K, N, (B, 1, 1), epilogue, ptrs=(_ptr(x), _ptr(bias), _ptr(y)))
+    pr = _Prof(2.0 * B * K * N, f"linear_fwd {K}->{N}", _nb(x, w, y)) if PROFILE is not None else None
     L.call("cgs_linear_fwd", _ptr(x), _ptr(w), _ptr(bias), _ptr(y), B, K, N, epilogue, _ptr(ws), ws.numel() * 4, pre, _stream())
+    if pr is not None:
+        pr.done()
     return y
 
 
@@ -270,10 +297,16 @@ def linear_bwd_data(dy, w, out=None):
     K = w.shape[0]
     dx = out if out is not None else torch.empty((B, K), dtype=torch.float32, device=dy.device)
     if N == 1:
+        pr = _Prof(2.0 * B * K, "", _nb(dy, w, dx), op="linear_out1_bwd") if PROFILE is not None else None
         L.call("cgs_linear_bwd_data", _ptr(dy), _ptr(w), _ptr(dx), B, K, N, None, 0, 0, _stream())
+        if pr is not None:
+            pr.done()
         return dx
     ws, pre = WS.get(w, L.CONV_BWD_DATA, 1, 1, 1, 1, K, N, (B, 1, 1), ptrs=(_ptr(dy), _ptr(dx)))
+    pr = _Prof(2.0 * B * K * N, f"linear_bwd {K}<-{N}", _nb(dy, w, dx)) if PROFILE is not None else None
     L.call("cgs_linear_bwd_data", _ptr(dy), _ptr(w), _ptr(dx), B, K, N, _ptr(ws), ws.numel() * 4, pre, _stream())
+    if pr is not None:
+        pr.done()
     return dx
 
 
@@ -291,8 +324,11 @@ def bn_train_lrelu_fwd(x, gamma, beta, leak=LEAK, eps=BN_EPS, out=None, stats=No
         mean = torch.empty(C, dtype=torch.float32, device=x.device)
         invstd = torch.empty(C, dtype=torch.float32, device=x.device)
     ws = _bn_workspace(M, C, x.device)
+    pr = _Prof(0.0, "", _nb(x, x, y), op="bn_train_lrelu_fwd") if PROFILE is not None else None     # statistics pass + apply pass
     L.call("cgs_bn_train_lrelu_fwd", _ptr(x), _ptr(gamma), _ptr(beta), eps, leak, _ptr(y), _ptr(mean), _ptr(invstd),
            M, C, _ptr(ws), ws.numel() * 4, _stream())
+    if pr is not None:
+        pr.done()
     return y, mean, invstd
 
 
@@ -302,8 +338,11 @@ def bn_train_lrelu_bwd_data(dy, x, gamma, beta, mean, invstd, leak=LEAK, out=Non
     M = x.numel() // C
     dx = out if out is not None else torch.empty_like(x)
     ws = _bn_workspace(M, C, x.device)
+    pr = _Prof(0.0, "", _nb(dy, x, dy, x, dx), op="bn_train_lrelu_bwd_data") if PROFILE is not None else None   # sums pass (dy, x) + apply pass (dy, x -> dx)
     L.call("cgs_bn_train_lrelu_bwd_data", _ptr(dy), _ptr(x), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(invstd), leak,
            _ptr(dx), M, C, _ptr(ws), ws.numel() * 4, _stream())
+    if pr is not None:
+        pr.done()
     return dx
 
 
@@ -374,8 +413,11 @@ def instnorm_lrelu_fwd(x, scale, offset, leak=1.0, eps=BN_EPS, out=None, stats=N
     mean, invstd = stats if stats is not None else (torch.empty((B, C), dtype=torch.float32, device=x.device),
                                                      torch.empty((B, C), dtype=torch.float32, device=x.device))
     ws = _in_workspace(B, HW, C, x.device)
+    pr = _Prof(0.0, "", _nb(x, x, y), op="instnorm_lrelu_fwd") if PROFILE is not None else None
     L.call("cgs_instnorm_lrelu_fwd", _ptr(x), _ptr(scale), _ptr(offset), eps, leak, _ptr(y), _ptr(mean), _ptr(invstd), B, HW, C,
            _ptr(ws), ws.numel() * 4, _stream())
+    if pr is not None:
+        pr.done()
     return y, mean, invstd
 
 
@@ -385,8 +427,11 @@ def instnorm_lrelu_bwd_data(dy, x, scale, offset, mean, invstd, leak=1.0, out=No
     HW = x.numel() // (B * C)
     dx = out if out is not None else torch.empty_like(x)
     ws = _in_workspace(B, HW, C, x.device)
+    pr = _Prof(0.0, "", _nb(dy, x, dy, x, dx), op="instnorm_lrelu_bwd_data") if PROFILE is not None else None
     L.call("cgs_instnorm_lrelu_bwd_data", _ptr(dy), _ptr(x), _ptr(scale), _ptr(offset), _ptr(mean), _ptr(invstd), leak, _ptr(dx),
            B, HW, C, _ptr(ws), ws.numel() * 4, _stream())
+    if pr is not None:
+        pr.done()
     return dx
 
 
@@ -397,11 +442,11 @@ def add(a, b, out=None):
     return o
 
 
-def bn_fold(gamma, beta, moving_mean, moving_var, eps=BN_EPS):
-    """Inference-mode bn as a per-channel affine (a, b).  nsgan/GAN.py:87,94."""
+def bn_fold(gamma, beta, moving_mean, moving_var, eps=BN_EPS, out=None):
+    """Inference-mode bn as a per-channel affine (a, b).  nsgan/GAN.py:87,94.  ``out`` = (a, b) to refresh in place."""
     C = gamma.numel()
-    a = torch.empty(C, dtype=torch.float32, device=gamma.device)
-    b = torch.empty(C, dtype=torch.float32, device=gamma.device)
+    a, b = out if out is not None else (torch.empty(C, dtype=torch.float32, device=gamma.device),
+                                        torch.empty(C, dtype=torch.float32, device=gamma.device))
     L.call("cgs_bn_fold", _ptr(gamma), _ptr(beta), _ptr(moving_mean), _ptr(moving_var), eps, _ptr(a), _ptr(b), C, _stream())
     return a, b
 
@@ -505,8 +550,11 @@ def clip(x, vmin, vmax, out=None):
 def refine_update(theta, m, g, rate, alpha, first, vmin=None, vmax=None):
     """In-place momentum / sgd step on theta (+ optional clip).  policy.py:27-37, collaborator.py:66-70."""
     use_clip = 1 if (vmin and vmax) else 0          # the reference's truthiness test (quirk Q5)
+    pr = _Prof(0.0, "", _nb(theta, theta, m, g) + (0.0 if first else _nb(m)), op="refine_update") if PROFILE is not None else None
     L.call("cgs_refine_update", _ptr(theta), _ptr(m), _ptr(g), rate, alpha, 1 if first else 0, use_clip,
            float(vmin or 0.0), float(vmax or 0.0), theta.numel(), _stream())
+    if pr is not None:
+        pr.done()
 
 
 def refine_select(theta, logit, forced, step_index, best_theta, best_logit, best_step):

@@ -2,6 +2,7 @@
 cpu_baseline objects; smoke() runs and checks itself against the oracle."""
 import json
 import os
+import socket
 import subprocess
 import sys
 
@@ -12,6 +13,13 @@ pytestmark = pytest.mark.gpu
 
 REQUIRED = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
             "dtype", "data", "config", "roofline", "cpu_baseline"]
+
+
+def free_port():
+    """A free rendezvous port on the loopback interface (the way bench.self_launch picks its own)."""
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
 
 
 def run_bench(*extra):
@@ -32,6 +40,13 @@ def test_bench_line_small_config():
     assert "workload" in d["config"] and "model" not in d["config"]
     r = d["roofline"]
     assert r["bound"] in ("mfma", "hbm") and r["peak"] > 0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert 0 < r["frac"] <= 1.0 and r["nominal_frac"] >= r["frac"] - 1e-3     # frac counts what is issued to the matrix cores: never above the machine
+    assert 0 < r["step_executed_frac"] <= 1.0
+    for h in d["hbm"].values():
+        assert 0 < h["frac"] <= 1.0 and h["unit"] == "GB/s" and h["algorithmic_bytes"] > 0
+    for name, o in d["other_configs"].items():
+        if name != "synthetic2d":
+            assert 0 < o["roofline"]["frac"] <= 1.0 and o["cpu_baseline"]["value"] > 0
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
 
@@ -55,7 +70,7 @@ def test_bench_under_torchrun_runs_the_rccl_gather():
     pool inside the timed region, barrier, MAX all-reduce of the time."""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
-                          "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--arch", "mnist", "--steps", "2",
+                          "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--arch", "mnist", "--steps", "2",
                           "--warmup", "1", "--refine-steps", "3", "--no-cpu-baseline"], cwd=ROOT, capture_output=True, text=True,
                          timeout=900, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
@@ -63,19 +78,64 @@ def test_bench_under_torchrun_runs_the_rccl_gather():
     assert len(lines) == 1, out.stdout
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["value"] > 0 and "RCCL" not in d["config"]["parallelism"]
+    x = d["dist"]
+    assert x["backend"] == "nccl" and x["world_size"] == 1 and x["ranks_seen"] == 1 and x["gather_ms_per_step"] > 0
+    assert x["pool_rows_match_ranks"] is True and d["config"]["hipgraph"] is True and "hipgraph_fallback" not in d["config"]
 
 
-def test_gather_pool_on_rccl_world1_is_identity_through_the_collective():
-    """dist.gather_pool's all_gather_into_tensor on the nccl (RCCL) backend, in-process at world size 1."""
+def test_two_ranks_on_the_one_gpu_through_the_whole_multi_rank_path():
+    """`python bench.py --gpus 2 --backend gloo --share-gpu` on the 1-GPU box -- self_launch -> torch.distributed.run
+    children (started before any GPU call) -> rank-offset seeds -> hipGraph replay per rank -> gather of the pool (gloo: staged
+    through the host; the same dist.gather_pool call RCCL serves on the 8-GPU node) -> MAX-reduce of the time -> ONE JSON line from
+    rank 0 -> the child's exit code relayed."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("RANK", None); env.pop("WORLD_SIZE", None); env.pop("MASTER_ADDR", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu", "--arch", "mnist",
+                          "--steps", "3", "--warmup", "1", "--refine-steps", "3", "--no-cpu-baseline"], cwd=ROOT, capture_output=True,
+                         text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout                                      # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["global_batch"] == 2 * 64 * 16 and "x2" in d["config"]["parallelism"]
+    x = d["dist"]
+    assert x["backend"] == "gloo" and x["world_size"] == 2 and x["ranks_seen"] == 2
+    assert x["pool_bytes"] == 2 * 64 * 16 * 28 * 28 * 4 and x["gather_ms_per_step"] > 0
+    assert x["pool_rows_match_ranks"] is True and x["pool_rank_sums_distinct"] is True     # rank r's rows ARE rank r's images; seeds differ
+    assert x["hipgraph_ranks"] == 2 and d["config"]["hipgraph"] is True
+    lo, hi = x["per_rank_samples_per_s"]
+    assert 0 < lo <= hi and d["value"] <= 2.0 * hi * 1.01                                   # whole-job value = both ranks over the MAX time
+    assert "other_configs" not in d and d["roofline"]["frac"] <= 1.0
+    # a wrong launch is refused, not silently run at another size
+    bad = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+                          "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--arch", "mnist"],
+                         cwd=ROOT, capture_output=True, text=True, timeout=300, env=env)
+    assert bad.returncode != 0 and "WORLD_SIZE=1" in (bad.stderr + bad.stdout)
+
+
+def test_gather_pool_on_rccl_world1_goes_through_the_collective():
+    """cgs_amd.dist.gather_pool on the nccl (RCCL) backend, in-process at world size 1: the library's own gather function runs
+    all_gather_into_tensor (no world-1 short-circuit), into a fresh and into a caller-owned pool buffer."""
     code = (
         "import os, sys, torch, torch.distributed as dist\n"
         f"sys.path.insert(0, {ROOT!r})\n"
-        "os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29534', RANK='0', WORLD_SIZE='1')\n"
+        "import cgs_amd.dist as D\n"
+        f"os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='{free_port()}', RANK='0', WORLD_SIZE='1')\n"
         "dev = torch.device('cuda:0'); torch.cuda.set_device(dev)\n"
         "dist.init_process_group('nccl', device_id=dev)\n"
+        "calls = []\n"
+        "real = dist.all_gather_into_tensor\n"
+        "def spy(*a, **k):\n"
+        "    calls.append(1); return real(*a, **k)\n"
+        "dist.all_gather_into_tensor = spy\n"
         "x = torch.arange(24, dtype=torch.float32, device=dev).view(4, 6)\n"
-        "pool = torch.empty_like(x); dist.all_gather_into_tensor(pool, x)\n"
-        "assert torch.equal(pool, x)\n"
+        "pool = D.gather_pool(x)\n"
+        "assert torch.equal(pool, x) and pool.data_ptr() != x.data_ptr() and len(calls) == 1\n"
+        "mine = torch.zeros_like(x); got = D.gather_pool(x, out=mine)\n"
+        "assert got is mine and torch.equal(mine, x) and len(calls) == 2\n"
+        "assert D.gather_pool(x, skip_trivial=True) is x and len(calls) == 2\n"
+        "rows = D.all_gather_floats([0, 3.5], device=dev); assert rows.shape == (1, 2) and rows[0, 1] == 3.5\n"
         "t = torch.tensor([3.5], dtype=torch.float64, device=dev); dist.all_reduce(t, op=dist.ReduceOp.MAX); assert t.item() == 3.5\n"
         "dist.destroy_process_group(); print('RCCL_OK')\n")
     out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=600,

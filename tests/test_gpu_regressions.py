@@ -176,3 +176,57 @@ def test_loss_and_clip_entry_points():
     assert (g.cpu().double() - (torch.sigmoid(l.detach().cpu().double()) - 1)).abs().max().item() < 1e-6
     x = rnd((1000,), 2, 3.0)
     assert torch.equal(K.clip(x.to(d), -0.5, 1.25).cpu(), torch.clamp(x, -0.5, 1.25))
+
+
+@pytest.mark.parametrize("how", ["set_variables", "inplace_invalidate"])
+def test_directly_built_graph_engines_follow_a_parameter_restore(how):
+    """engines built DIRECTLY (bench.py, shaping, user code) -- not through model.GAN.engine(), which
+    rebuilds on a generation bump -- with captured hipGraphs: after the parameters change under them (ops.set_variables
+    restoring into the live tensors, or an in-place update + WS.invalidate()) EVERY such engine must replay the new state:
+    re-packed conv / deconv weights and re-folded G bn affines, not a mix of stale packed copies and new raw gamma / beta."""
+    from cgs_amd import kernels as K, ops
+    from cgs_amd.engine import RefineEngine
+    from cgs_amd.nets import to_device
+    d = dev()
+    ops.reset_variables()
+    B, Ks = 8, 3
+    P0, P1 = N.init_params("mnist", 2019, True), N.init_params("mnist", 7, True)
+    ops.set_variables(P0, d)
+    live = ops.variables()                                               # the engines hold THESE tensors
+    z = torch.from_numpy(np.random.RandomState(4).uniform(-1, 1, (B, 62)).astype(np.float32)).to(d)
+    engines = [RefineEngine("mnist", live, B, d, use_graph=True) for _ in range(2)]
+    before = [[t.clone() for t in e.refine_from_z(z, Ks, 0.1)] for e in engines]     # capture
+    for e in engines:
+        e.refine_from_z(z, Ks, 0.1)                                                     # replay
+    if how == "set_variables":
+        ops.set_variables(P1, d)
+    else:
+        with torch.no_grad():
+            for k, v in P1.items():
+                live[k].copy_(v.to(d))
+        K.WS.invalidate()
+    fresh = RefineEngine("mnist", to_device(P1, d), B, d)                # eager engine that only ever saw P1
+    want = [t.clone() for t in fresh.refine_from_z(z, Ks, 0.1)]
+    for e, b in zip(engines, before):
+        got = e.refine_from_z(z, Ks, 0.1)                                # replays the graph captured on P0's packed copies
+        assert not torch.equal(got[0], b[0])
+        for a, w in zip(got, want):
+            assert torch.equal(a, w)
+    ops.reset_variables()
+
+
+def test_packed_weight_cache_never_drops_live_entries():
+    """the cache used to clear itself past 512 entries -- under a captured hipGraph that frees workspaces the
+    graph still reads.  Now only entries whose weight tensor died are evicted."""
+    from cgs_amd import kernels as K
+    d = dev()
+    K.WS.clear()
+    w_live = rnd((3, 3, 16, 16), 1, 0.1).to(d)
+    x = rnd((2, 8, 8, 16), 2).to(d)
+    y0 = K.conv2d_fwd(x, w_live, None, 1, 1).clone()
+    live_keys = set(K.WS._d)
+    for i in range(600):                                                  # 600 short-lived weights
+        K.conv2d_fwd(x, rnd((1, 1, 16, 4), 10 + i, 0.1).to(d), None, 1, 1)
+    assert live_keys <= set(K.WS._d) and len(K.WS._d) < 200               # the live entry stayed, the dead ones went
+    assert torch.equal(K.conv2d_fwd(x, w_live, None, 1, 1), y0)
+    K.WS.clear()

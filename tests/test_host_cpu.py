@@ -228,8 +228,12 @@ def _gloo_worker(rank, world, port, out):
     def fake_refine(zb):                       # stand-in for the GPU engine: deterministic function of z
         return zb.view(4, 5, 1).repeat(1, 1, 2), zb.sum(1), torch.full((4,), float(rank))
     img, logit, step = D.refine_pool(fake_refine, z)
+    rows = D.all_gather_floats([rank, 10.0 + rank])               # bench.py's bookkeeping gather (host tensors under gloo)
+    mine = torch.zeros(world * 2, 3)
+    got = D.gather_pool(torch.full((2, 3), float(rank)), out=mine)   # caller-owned pool buffer
+    assert got is mine and all((mine[2 * r:2 * r + 2] == r).all() for r in range(world))
     if rank == 0:
-        torch.save((img, logit, step), out)
+        torch.save((img, logit, step, torch.from_numpy(rows)), out)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -238,9 +242,13 @@ def test_sharding_and_gather_over_gloo(tmp_path):
     import torch.multiprocessing as mp
     from cgs_amd import dist as D
     world, out = 2, str(tmp_path / "pool.pt")
-    port = 29500 + (os.getpid() % 2000)
+    import socket
+    with socket.socket() as so:                                   # a free rendezvous port on the loopback interface
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
     mp.spawn(_gloo_worker, args=(world, port, out), nprocs=world, join=True)
-    img, logit, step = torch.load(out)
+    img, logit, step, rows = torch.load(out)
+    assert rows.shape == (world, 2) and rows[:, 0].tolist() == [0.0, 1.0] and rows[:, 1].tolist() == [10.0, 11.0]
     assert img.shape == (world * 3 * 4, 5, 2) and logit.shape == (24,) and step.shape == (24,)
     for r in range(world):
         z = torch.from_numpy(D.z_batches(r, 3, 4, 5)).reshape(12, 5)
