@@ -14,7 +14,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from conftest import GOLDEN
+from conftest import GOLDEN, golden_feature0
 from oracle import nets_ref as N
 from oracle import sampling_ref as S
 
@@ -43,18 +43,22 @@ def grad_close(got, want):
 
 
 def check_against_golden(g, img, dl, ol, os_, of, traj_tol=2e-3, render=None):
+    """Against what the reference's own collaborator.Refiner produced.  optimal_step: EQUAL everywhere except where the two
+    arithmetics' best logits tie within the trajectory tolerance (a flipped select is only tolerable on a numerical tie), and
+    from batch 64 up equal on >= 99 % of the samples.  Images: the G tail amplifies feature drift
+    (inference bn divides by sqrt(moving_var ~ 0.02) three times), so the K-step image is compared at 5x the logit tolerance
+    and the RENDER itself tightly (1e-4) on the golden feature."""
     assert relerr(dl.cpu().numpy(), g["default_logit"]) < 1e-4
     assert relerr(ol.cpu().numpy(), g["optimal_logit"]) < traj_tol
     steps_ok = os_.cpu().numpy() == g["optimal_step"]
-    if not steps_ok.all():     # a flipped select is only tolerable on a numerical tie
+    if not steps_ok.all():
         bad = ~steps_ok
         assert np.all(np.abs(ol.cpu().numpy()[bad] - g["optimal_logit"][bad]) < traj_tol * np.abs(g["optimal_logit"]).max())
     ok = steps_ok
-    assert ok.mean() >= (0.99 if len(ok) >= 64 else 0.75)      # >= 99 % (expressible from batch 64 up)
+    if len(ok) >= 64:
+        assert ok.mean() >= 0.99
     assert relerr(of.cpu().numpy()[ok], g["optimal_feature"][ok]) < traj_tol
-    # images: the G tail amplifies feature drift (inference bn divides by sqrt(moving_var ~ 0.02) three times),
-    # so the trajectory comparison is loose and the RENDER itself is checked tightly on the golden feature.
-    assert relerr(img.cpu().numpy()[ok], g["images"][ok]) < 25 * traj_tol
+    assert relerr(img.cpu().numpy()[ok], g["images"][ok]) < 5 * traj_tol
     if render is not None:
         again = render(torch.from_numpy(g["optimal_feature"]).to(img.device))
         assert relerr(again.cpu().numpy(), g["images"]) < 1e-4
@@ -81,10 +85,11 @@ def test_engine_matches_reference_golden(path, use_graph):
     d = dev()
     eng = RefineEngine(arch, to_device(P, d), len(g["z"]), d, use_graph=use_graph)
     f0 = eng.input_to_feature(torch.from_numpy(g["z"]).to(d))
-    assert relerr(f0.cpu().numpy(), g["feature0"]) < 1e-4             # the propose step (G head)
+    feature0 = golden_feature0(g, arch, P)
+    assert relerr(f0.cpu().numpy(), feature0) < 1e-4                  # the propose step (G head)
     mode = str(g["mode"][0])
     for _ in range(2 if use_graph else 1):                              # 2nd call = graph replay
-        out = eng.refine(torch.from_numpy(g["feature0"]).to(d), int(g["K"][0]), float(g["rate"][0]), "momentum", mode,
+        out = eng.refine(torch.from_numpy(feature0).to(d), int(g["K"][0]), float(g["rate"][0]), "momentum", mode,
                          g["indices"] if mode == "probabilistic" else None, vmin, vmax)
         check_against_golden(g, *[t.clone() for t in out], render=lambda f: eng.feature_to_data(f).clone())
 

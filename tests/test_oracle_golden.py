@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import GOLDEN, load_golden
+from conftest import GOLDEN, golden_feature0, load_golden
 from oracle import nets_ref as N
 from oracle import sampling_ref as S
 
@@ -60,11 +60,12 @@ def test_g3_collaborator_matches_reference(path):
     assert abs(chk - float(g["params_checksum"][0])) <= 1e-9 * chk   # same weights as at capture time
     with torch.no_grad():
         f0 = N.input_to_feature(arch, P, torch.from_numpy(g["z"]))
-    np.testing.assert_allclose(f0.numpy(), g["feature0"], rtol=1e-5, atol=1e-6)
+    feature0 = golden_feature0(g, arch, P)
+    np.testing.assert_allclose(f0.numpy(), feature0, rtol=1e-5, atol=1e-6)
     c = g["constraints"]
     vmin, vmax = (None, None) if np.isnan(c[0]) else (float(c[0]), float(c[1]))
     img, dl, ol, os_, of = S.collaborative_refine(
-        torch.from_numpy(g["feature0"]), lambda f: N.feature_to_data(arch, P, f),
+        torch.from_numpy(feature0), lambda f: N.feature_to_data(arch, P, f),
         lambda x: N.discriminator(arch, P, x), K, float(g["rate"][0]), "momentum", mode,
         indices=g["indices"] if mode == "probabilistic" else None, vmin=vmin, vmax=vmax)
     np.testing.assert_allclose(dl.numpy(), g["default_logit"], rtol=1e-4, atol=1e-5)
@@ -75,7 +76,7 @@ def test_g3_collaborator_matches_reference(path):
     if mode == "probabilistic":          # quirk Q2: index K => never selected => step stays 1, feature stays theta0
         never = g["indices"] == K
         assert np.all(g["optimal_step"][never] == 1)
-        np.testing.assert_array_equal(of.numpy()[never], g["feature0"][never])
+        np.testing.assert_array_equal(of.numpy()[never], feature0[never])
 
 
 def test_g6_rejector_mask_bit_exact():
