@@ -42,12 +42,15 @@ def grad_close(got, want):
     return bool(per.max() < 5e-2 and (per < 2e-3).sum() >= B - 1), per
 
 
-def check_against_golden(g, img, dl, ol, os_, of, traj_tol=2e-3, render=None):
+def check_against_golden(g, img, dl, ol, os_, of, traj_tol=2e-3, render=None, oracle_render=None):
     """Against what the reference's own collaborator.Refiner produced.  optimal_step: EQUAL everywhere except where the two
     arithmetics' best logits tie within the trajectory tolerance (a flipped select is only tolerable on a numerical tie), and
-    from batch 64 up equal on >= 99 % of the samples.  Images: the G tail amplifies feature drift
-    (inference bn divides by sqrt(moving_var ~ 0.02) three times), so the K-step image is compared at 5x the logit tolerance
-    and the RENDER itself tightly (1e-4) on the golden feature."""
+    from batch 64 up equal on >= 99 % of the samples.  Measured on MI355X (tools/golden_diag.py): steps
+    100 % equal in all 12 goldens, logits <= 2.8e-4 (1.5e-3 at K = 50), features <= 1e-4.
+    Images: the DCGAN G tails amplify feature drift ~300x (inference bn divides by sqrt(moving_var ~ 0.02) per layer: a 7e-5
+    feature difference is a 2e-2 image difference), so the K-step image against the golden is only a sanity bound; the image is
+    pinned tightly (1e-4) twice instead: the engine's render of the GOLDEN feature against the golden image, and the returned
+    image against the ORACLE's render of the engine's own optimal feature."""
     assert relerr(dl.cpu().numpy(), g["default_logit"]) < 1e-4
     assert relerr(ol.cpu().numpy(), g["optimal_logit"]) < traj_tol
     steps_ok = os_.cpu().numpy() == g["optimal_step"]
@@ -58,7 +61,11 @@ def check_against_golden(g, img, dl, ol, os_, of, traj_tol=2e-3, render=None):
     if len(ok) >= 64:
         assert ok.mean() >= 0.99
     assert relerr(of.cpu().numpy()[ok], g["optimal_feature"][ok]) < traj_tol
-    assert relerr(img.cpu().numpy()[ok], g["images"][ok]) < 5 * traj_tol
+    assert relerr(img.cpu().numpy()[ok], g["images"][ok]) < 25 * traj_tol
+    if oracle_render is not None:
+        with torch.no_grad():
+            mine = oracle_render(of.cpu())
+        assert relerr(img.cpu().numpy(), mine.numpy()) < 1e-4
     if render is not None:
         again = render(torch.from_numpy(g["optimal_feature"]).to(img.device))
         assert relerr(again.cpu().numpy(), g["images"]) < 1e-4
@@ -91,7 +98,8 @@ def test_engine_matches_reference_golden(path, use_graph):
     for _ in range(2 if use_graph else 1):                              # 2nd call = graph replay
         out = eng.refine(torch.from_numpy(feature0).to(d), int(g["K"][0]), float(g["rate"][0]), "momentum", mode,
                          g["indices"] if mode == "probabilistic" else None, vmin, vmax)
-        check_against_golden(g, *[t.clone() for t in out], render=lambda f: eng.feature_to_data(f).clone())
+        check_against_golden(g, *[t.clone() for t in out], render=lambda f: eng.feature_to_data(f).clone(),
+                             oracle_render=lambda f: N.feature_to_data(arch, P, f))
 
 
 @pytest.mark.parametrize("path", [p for p in G3 if "K5" in p], ids=lambda p: os.path.basename(p)[10:-4])
@@ -125,7 +133,8 @@ def test_refiner_class_generic_and_engine_paths(path):
         ref2.set_constraints(vmin, vmax)
     assert ref2._engine_for(len(f0)) is not None
     img2 = ref2.build_refiner(f0, real, mode, indices=idx)
-    check_against_golden(g, img2, ref2.default_logit, ref2.optimal_logit, ref2.optimal_step, ref2.optimal_feature)
+    check_against_golden(g, img2, ref2.default_logit, ref2.optimal_logit, ref2.optimal_step, ref2.optimal_feature,
+                         oracle_render=lambda f: N.feature_to_data(arch, P, f))
     # one evaluation: logits + gradient vs the oracle (collaborator.py:26-39)
     lm, grad = ref.compute_forward_logits_and_grad(f0)
     lm_o, grad_o = S.forward_logits_and_grad(torch.from_numpy(g["feature0"]), lambda f: N.feature_to_data(arch, P, f),
