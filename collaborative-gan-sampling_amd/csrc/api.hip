@@ -68,19 +68,23 @@ static int choose_family(const CgsLayer& L, bool dirT, int B, int epilogue, bool
 
 static int run_dir(const CgsLayer& L, bool dirT, int B, const float* in, const float* w, const float* bias, float* out,
                    int epilogue, const float* ep_a, const float* ep_b, const float* ep_aux, void* ws, size_t ws_bytes,
-                   int prepacked, hipStream_t s, const char* who, float* stat_part = nullptr) {
+                   int prepacked, hipStream_t s, const char* who, float* stat_part = nullptr, unsigned* sign_out = nullptr,
+                   const unsigned* aux_signs = nullptr) {
     cgs_note_flops(0.0);
     if (B <= 0) return cgs_set_error(CGS_EINVAL, "%s: B=%d", who, B);
     if (!in || !w || !out) return cgs_set_error(CGS_EINVAL, "%s: null tensor", who);
     if (epilogue < CGS_EPI_NONE || epilogue > CGS_EPI_TANH_BWD) return cgs_set_error(CGS_EINVAL, "%s: epilogue %d", who, epilogue);
     if (epilogue == CGS_EPI_AFFINE_RELU && (!ep_a || !ep_b)) return cgs_set_error(CGS_EINVAL, "%s: affine epilogue needs a,b", who);
-    if (epilogue >= CGS_EPI_RELU_BWD_AFFINE && (!ep_aux || (epilogue == CGS_EPI_RELU_BWD_AFFINE && !ep_a)))
+    if (epilogue >= CGS_EPI_RELU_BWD_AFFINE && ((!ep_aux && !aux_signs) || (epilogue == CGS_EPI_RELU_BWD_AFFINE && !ep_a)))
         return cgs_set_error(CGS_EINVAL, "%s: backward epilogue %d needs aux%s", who, epilogue, epilogue == CGS_EPI_RELU_BWD_AFFINE ? " and a" : "");
     if (dirT && (L.sh > 2 || L.sw > 2)) return cgs_set_error(CGS_EINVAL, "%s: transposed direction supports stride <= 2", who);
     const bool rest_al = !(((uintptr_t)out & 15) || ((uintptr_t)bias & 15) || ((uintptr_t)ep_a & 15) || ((uintptr_t)ep_b & 15) ||
                            ((uintptr_t)ep_aux & 15));
     const int fam = choose_family(L, dirT, B, epilogue, ws != nullptr, ws_bytes, !((uintptr_t)in & 15), !((uintptr_t)ws & 15), rest_al);
     if (stat_part && fam != CGS_FAMILY_IGEMM) return cgs_set_error(CGS_EINVAL, "%s: fused statistics are an implicit-GEMM feature (see cgs_conv_stat_partials)", who);
+    if (sign_out && fam != CGS_FAMILY_IGEMM) return cgs_set_error(CGS_EINVAL, "%s: this call cannot leave a sign mask (see cgs_conv_signs_ok)", who);
+    if (aux_signs && fam != CGS_FAMILY_PATCH) return cgs_set_error(CGS_EINVAL, "%s: this call cannot take a sign mask (see cgs_conv_signs_ok)", who);
+    if (((uintptr_t)sign_out & 3) || ((uintptr_t)aux_signs & 3)) return cgs_set_error(CGS_EINVAL, "%s: sign mask must be 4-byte aligned", who);
     switch (fam) {
         case CGS_FAMILY_QUAD:
             return cgs_convt_quad_launch(L, B, in, w, bias, out, epilogue, ep_a, ep_aux, (float*)ws, ws_bytes, prepacked, s);
@@ -89,12 +93,14 @@ static int run_dir(const CgsLayer& L, bool dirT, int B, const float* in, const f
         case CGS_FAMILY_SMALLN_F:
             return cgs_conv_smalln_f_launch(L, B, in, w, bias, out, epilogue, (float*)ws, ws_bytes, prepacked, s);
         case CGS_FAMILY_PATCH:
-            return cgs_conv_patch_launch(L, dirT, B, in, w, bias, out, epilogue, ep_a, ep_b, ep_aux, (float*)ws, ws_bytes, prepacked, s);
+            return cgs_conv_patch_launch(L, dirT, B, in, w, bias, out, epilogue, ep_a, ep_b, ep_aux, (float*)ws, ws_bytes, prepacked, s, aux_signs);
         default: break;
     }
     IgemmParams p;
     p.in = in; p.bias = bias; p.ep_a = ep_a; p.ep_b = ep_b; p.ep_aux = ep_aux; p.out = out; p.B = B; p.epilogue = epilogue;
     p.stat_part = stat_part;
+    p.sign_out = sign_out;
+    p.sign_plane = (long)B * (dirT ? L.Hb * L.Wb : L.Hs * L.Ws);
     if (dirT) cgs_geom_T(L, p); else cgs_geom_F(L, p);
     const size_t need = cgs_packed_floats(p) * sizeof(float);
     if (!ws || ws_bytes < need) return cgs_set_error(CGS_EWORKSPACE, "%s: workspace %zu < %zu bytes", who, ws_bytes, need);
@@ -117,6 +123,7 @@ static int run_dir(const CgsLayer& L, bool dirT, int B, const float* in, const f
         p.in = in + (size_t)b0 * (in_img / 4);
         p.out = out + (size_t)b0 * (out_img / 4);
         p.ep_aux = ep_aux ? ep_aux + (size_t)b0 * (out_img / 4) : nullptr;
+        p.sign_out = sign_out ? sign_out + (size_t)b0 * p.Hout * p.Wout : nullptr;      // (plane-major: the chunk's pixels inside every plane)
         int rc = cgs_igemm_launch(p, (char*)ws + need, ws_bytes - need, s);
         if (rc) return rc;
     }
@@ -144,7 +151,7 @@ size_t cgs_conv_ws_bytes_for(int op, int B, int H, int W, int Cin, int Cout, int
     else { L.Hs = H; L.Ws = W; L.Cs = Cin; L.Hb = H * sh; L.Wb = W * sw; L.Cb = Cout; }   // bound: output = stride * input
     if (dirT && (sh > 2 || sw > 2)) return packed;
     IgemmParams p;
-    p.B = B; p.stat_part = nullptr;
+    p.B = B; p.stat_part = nullptr; p.sign_out = nullptr; p.sign_plane = 0;
     if (dirT) cgs_geom_T(L, p); else cgs_geom_F(L, p);
     return packed + cgs_igemm_splitk_bytes(p);
 }
@@ -245,6 +252,54 @@ int cgs_deconv2d_nhwc_bwd_data(const float* dy, const float* w, float* dx, int B
     int rc = make_layer(L, kh, kw, sh, sw, Ho, Wo, Cout, H, W, Cin, "deconv2d_nhwc_bwd_data");
     if (rc) return rc;
     return run_dir(L, false, B, dy, w, nullptr, dx, epilogue, ep_a, nullptr, ep_aux, ws, ws_bytes, ws_prepacked, (hipStream_t)stream, "deconv2d_nhwc_bwd_data");
+}
+
+// ---- sign masks (cgs_hip.h): the activation gradient of relu / lrelu needs one bit per element of the saved activation ----
+int cgs_conv_signs_ok(int op, int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int sh, int sw, int epilogue,
+                      size_t ws_bytes) {
+    const int fam = cgs_conv_family(op, B, H, W, Cin, Ho, Wo, Cout, kh, kw, sh, sw, epilogue, ws_bytes);
+    if (fam < 0) return 0;
+    const bool deconv = (op == CGS_DECONV_FWD || op == CGS_DECONV_BWD_DATA);
+    const bool dirT = (op == CGS_CONV_BWD_DATA || op == CGS_DECONV_FWD);
+    CgsLayer L;
+    L.kh = kh; L.kw = kw; L.sh = sh; L.sw = sw;
+    if (!deconv) { L.Hb = H; L.Wb = W; L.Cb = Cin; L.Hs = cgs_ceil_div(H, sh); L.Ws = cgs_ceil_div(W, sw); L.Cs = Cout; }
+    else { L.Hs = H; L.Ws = W; L.Cs = Cin; L.Hb = Ho; L.Wb = Wo; L.Cb = Cout; }
+    if (epilogue >= CGS_EPI_RELU_BWD_AFFINE)          // consumer: a backward-data whose epilogue applies relu' / lrelu'
+        return fam == CGS_FAMILY_PATCH && cgs_conv_patch_signs_ok(L, dirT, epilogue);
+    if (fam != CGS_FAMILY_IGEMM || (dirT && (sh > 2 || sw > 2))) return 0;        // producer: a forward with the relu / lrelu epilogue
+    IgemmParams p;
+    p.B = B; p.stat_part = nullptr; p.sign_out = nullptr; p.sign_plane = 0; p.epilogue = epilogue;
+    if (dirT) cgs_geom_T(L, p); else cgs_geom_F(L, p);
+    const size_t in_img = (size_t)p.Hin * p.Win * p.Cred * 4, out_img = (size_t)p.Hout * p.Wout * p.N * 4;
+    if ((size_t)B * (in_img > out_img ? in_img : out_img) > 0x7fffffffUL) return 0;      // (a split batch may fall under the split-K threshold)
+    return cgs_igemm_signs_ok(p);
+}
+
+int cgs_deconv2d_nhwc_fwd_signs(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int Cin,
+                                int Ho, int Wo, int Cout, int kh, int kw, int sh, int sw, int epilogue, const float* ep_a,
+                                const float* ep_b, unsigned* signs, void* ws, size_t ws_bytes, int ws_prepacked, void* stream) {
+    if (!signs) return cgs_set_error(CGS_EINVAL, "deconv2d_nhwc_fwd_signs: null sign mask");
+    if (!cgs_conv_signs_ok(CGS_DECONV_FWD, B, H, W, Cin, Ho, Wo, Cout, kh, kw, sh, sw, epilogue, ws_bytes))
+        return cgs_set_error(CGS_EINVAL, "deconv2d_nhwc_fwd_signs: not available for this call (cgs_conv_signs_ok == 0)");
+    CgsLayer L;
+    int rc = make_layer(L, kh, kw, sh, sw, Ho, Wo, Cout, H, W, Cin, "deconv2d_nhwc_fwd_signs");
+    if (rc) return rc;
+    return run_dir(L, true, B, x, w, bias, y, epilogue, ep_a, ep_b, nullptr, ws, ws_bytes, ws_prepacked, (hipStream_t)stream,
+                   "deconv2d_nhwc_fwd_signs", nullptr, signs);
+}
+
+int cgs_deconv2d_nhwc_bwd_data_signs(const float* dy, const float* w, float* dx, int B, int H, int W, int Cin, int Ho, int Wo,
+                                     int Cout, int kh, int kw, int sh, int sw, int epilogue, const float* ep_a,
+                                     const unsigned* aux_signs, void* ws, size_t ws_bytes, int ws_prepacked, void* stream) {
+    if (!aux_signs) return cgs_set_error(CGS_EINVAL, "deconv2d_nhwc_bwd_data_signs: null sign mask");
+    if (!cgs_conv_signs_ok(CGS_DECONV_BWD_DATA, B, H, W, Cin, Ho, Wo, Cout, kh, kw, sh, sw, epilogue, ws_bytes))
+        return cgs_set_error(CGS_EINVAL, "deconv2d_nhwc_bwd_data_signs: not available for this call (cgs_conv_signs_ok == 0)");
+    CgsLayer L;
+    int rc = make_layer(L, kh, kw, sh, sw, Ho, Wo, Cout, H, W, Cin, "deconv2d_nhwc_bwd_data_signs");
+    if (rc) return rc;
+    return run_dir(L, false, B, dy, w, nullptr, dx, epilogue, ep_a, nullptr, nullptr, ws, ws_bytes, ws_prepacked, (hipStream_t)stream,
+                   "deconv2d_nhwc_bwd_data_signs", nullptr, nullptr, aux_signs);
 }
 
 }  // extern "C"

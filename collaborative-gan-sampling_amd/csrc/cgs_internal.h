@@ -75,6 +75,8 @@ struct IgemmParams {
     int xcd_map;         // block id -> (XCD, local index) decode: an m-tile's n-tiles run on one XCD (see igemm_kernel)
     int uni;             // uniform-tile K loop allowed (host policy, see cgs_igemm_launch)
     int lpt;             // pixel-major only: m-tiles visit the pixels in perm[] order (most valid taps first)
+    unsigned* sign_out;  // != null: sign bitmask of the stored output (layout: cgs_hip.h, "sign masks"); wide epilogue, N % 32 == 0, no split-K
+    long sign_plane;     // words per 32-channel plane of the mask = pixels of the WHOLE tensor (a launch may be one batch chunk of it)
     float* stat_part;    // != null: per-(m-tile, wave row) column sums / sums of squares of the output, [2 * m-tiles][2][N] (fused batch-norm statistics)
     int vec;             // the 32-channel-chunk K order / 16-byte row gathers apply: Cred % 32 == 0 and at most 16 taps per axis
     int prio_t[3];       // progress thresholds (1/256 of the block's K tiles) at which a block steps its wave priority down; 0 = off
@@ -148,4 +150,6 @@ int cgs_conv_patch_T_ok(const CgsLayer& L);          // backward-data of a strid
 size_t cgs_conv_patch_ws_floats(const CgsLayer& L, bool dirT);
 int cgs_conv_patch_launch(const CgsLayer& L, bool dirT, int B, const float* in, const float* w, const float* bias, float* out,
                           int epilogue, const float* ep_a, const float* ep_b, const float* ep_aux, float* ws, size_t ws_bytes,
-                          int prepacked, hipStream_t s);
+                          int prepacked, hipStream_t s, const unsigned* aux_signs = nullptr);
+int cgs_conv_patch_signs_ok(const CgsLayer& L, bool dirT, int epilogue);     // can the *_BWD epilogue take a sign mask instead of the fp32 aux tensor?
+int cgs_igemm_signs_ok(const IgemmParams& p);                                 // can this launch leave the sign mask of its output? (call after the geometry is set)

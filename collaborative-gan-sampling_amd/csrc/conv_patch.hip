@@ -22,6 +22,7 @@ struct PatchParams {
     const float* ep_a;
     const float* ep_b;
     const float* ep_aux;
+    const unsigned* aux_signs;   // sign mask of the aux tensor (cgs_hip.h, "sign masks") instead of ep_aux: 1 bit per element
     float* out;           // [B,Hout,Wout,N]
     int B, Hin, Win, Cred, Hout, Wout, N, Np;
     int kh, kw, pt, pl, K, Kp;
@@ -264,12 +265,41 @@ __device__ __forceinline__ void patch2_store(const PatchParams& p, __amdgpu_buff
         }
 }
 
-// AUXP: the *_BWD epilogues read an aux tensor of the output's shape (the saved activation of the layer below).  Loading it in the
+// the same store with relu' / lrelu' taken from the sign mask: nw = lane L's un-shuffled word of pixel L of the wave's 4 x 16
+// pixels.  Register r of row tile tm is pixel 32 tm + (r & 3) + 8 (r >> 2) in lanes 0-31 and that + 4 in lanes 32-63, and a
+// lane's channel is its index in the half: {readlane(nw, pixel), readlane(nw, pixel + 4)} IS the 64-bit lane mask of "aux > 0".
+template <int EPI>
+__device__ __forceinline__ void patch2_store_signs(const PatchParams& p, __amdgpu_buffer_rsrc_t out_rsrc, const f32x16 (&acc)[2],
+                                                   unsigned base, unsigned rowstride, float ea, unsigned nw) {
+    const unsigned pixb = (unsigned)p.N * 4u;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2);
+            const unsigned o = base + (unsigned)(2 * tm + row / TC) * rowstride + (unsigned)(row % TC) * pixb;
+            const unsigned lo = __builtin_amdgcn_readlane(nw, 32 * tm + row), hi = __builtin_amdgcn_readlane(nw, 32 * tm + row + 4);
+            const bool pos = __builtin_amdgcn_inverse_ballot_w64(((unsigned long long)hi << 32) | lo);
+            const float v = acc[tm][r];
+            const float y = EPI == CGS_EPI_RELU_BWD_AFFINE ? (pos ? v * ea : 0.f) : (pos ? v : 0.2f * v);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y), out_rsrc, o, 0, 0);
+        }
+}
+
+// AUXM = 1: the *_BWD epilogues read an aux tensor of the output's shape (the saved activation of the layer below).  Loading it in the
 // epilogue put a chain of global-load latencies into every tile (221 -> 262 us with one dword per register); here its 8 float4
 // per lane are PREFETCHED right after the tile's barrier, in the 16-byte-per-lane layout, and the accumulators are transposed to
 // that layout through a small LDS tile when the MFMAs are done.
-template <int KH, int RP, int R, int PLD, bool AUXP>     // R = kw * Cin floats per tap row (<= RP), PLD = patch floats per thread (ceil(PH * PW * Cin / 256))
-__global__ __launch_bounds__(256, AUXP ? 2 : 3) void conv_patch2_kernel(PatchParams p, int tiles_total, int tiles_per_block) {
+// AUXM = 2: relu' / lrelu' need the SIGN of the saved activation only: the producing forward epilogue left a bitmask
+// (p.aux_signs, one 32-bit word per pixel and 32 channels, a plane per channel group: 8 MB instead of the 268 MB fp32 tensor of
+// the 32x32x64 layer at batch 1024).  A wave's 4 tile rows x 16 pixels are 64 words = ONE coalesced dword load per tile, lane L
+// holding pixel L's word, prefetched after the tile's barrier; after the MFMAs each lane un-shuffles its word to "bit c = channel
+// c" (31 VALU ops per tile for the whole wave), and for accumulator register r the two pixels the wave's lane halves hold come
+// out with two v_readlane straight into a 64-bit lane mask: the epilogue stays in the ACCUMULATOR layout of the plain kernel
+// (no LDS transpose, one v_cndmask per element) and three blocks fit a CU again.
+template <int KH, int RP, int R, int PLD, int AUXM>     // R = kw * Cin floats per tap row (<= RP), PLD = patch floats per thread (ceil(PH * PW * Cin / 256))
+__global__ __launch_bounds__(256, AUXM == 1 ? 2 : 3) void conv_patch2_kernel(PatchParams p, int tiles_total, int tiles_per_block) {
+    constexpr bool AUXP = AUXM != 0;
     constexpr int HALF = RP / 2, NQ = RP / 4, NS = KH * HALF;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int patch_f = p.PH * p.pitch;
@@ -291,6 +321,9 @@ __global__ __launch_bounds__(256, AUXP ? 2 : 3) void conv_patch2_kernel(PatchPar
     const unsigned out_bytes = (unsigned)p.B * (unsigned)p.Hout * (unsigned)p.Wout * (unsigned)p.N * 4u;
     const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, (int)out_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t aux_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.ep_aux ? p.ep_aux : p.out), 0, (int)out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t sg_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.aux_signs ? (const void*)p.aux_signs : (const void*)p.out), 0,
+                                                                             (int)(out_bytes >> 5), 0x00020000);     // one word per 32 floats
+    const unsigned sg_plane_b = (unsigned)p.B * (unsigned)p.Hout * (unsigned)p.Wout * 4u;                            // bytes of one 32-channel plane
     const int rowf = p.PW * p.Cred;                      // valid floats per patch row
     const int rowlen = p.Win * p.Cred;
     // this thread's patch elements: (patch row, column) -> LDS offset and image offset relative to the tile's patch origin (loop invariant)
@@ -396,7 +429,12 @@ __global__ __launch_bounds__(256, AUXP ? 2 : 3) void conv_patch2_kernel(PatchPar
             const float* P = Ps + (size_t)(it & 1) * patch_f;
             const unsigned tile_off = (unsigned)(((b * p.Hout + oy0) * p.Wout + ox0) * p.N) * 4u;      // scalar
             f32x4 auxv[2][4];
-            if constexpr (AUXP) {
+            unsigned sgw = 0;
+            if constexpr (AUXM == 2) {
+                // lane L <-> pixel (tile row wm * 4 + L / 16, column L % 16) of the wave's 64 pixels, plane of its 32-channel group
+                const unsigned pixw = (unsigned)((b * p.Hout + oy0 + wm * 4 + (lane >> 4)) * p.Wout + ox0 + (lane & 15));
+                sgw = __builtin_amdgcn_raw_buffer_load_b32(sg_rsrc, pixw * 4u, (unsigned)((n0 >> 5) + wn) * sg_plane_b, 0);
+            } else if constexpr (AUXM == 1) {
                 const unsigned ab = tile_off + (unsigned)(n0 + wn * 32 + c4) * 4u + (unsigned)(wm * 4) * rowstride;
 #pragma unroll
                 for (int tm = 0; tm < 2; ++tm)
@@ -445,7 +483,22 @@ __global__ __launch_bounds__(256, AUXP ? 2 : 3) void conv_patch2_kernel(PatchPar
             // buffer_store_dword writes two whole 128-byte channel runs (rows R and R + 4).  No LDS round trip, and every
             // address is one of two per-lane bases (tile row 0 / 1 of the row tile) plus an instruction immediate.
             // (The LDS-transposed 16-byte form took 7k cycles per tile here -- a chain of LDS latencies -- against 5k of MFMAs.)
-            if constexpr (AUXP) {
+            if constexpr (AUXM == 2) {
+                // un-shuffle this lane's word: bit 8e + q holds channel 4q + e  ->  bit c holds channel c
+                unsigned nw = 0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    unsigned t8 = (sgw >> (8 * e)) & 0xffu;
+                    t8 = (t8 | (t8 << 12)) & 0x000F000Fu;
+                    t8 = (t8 | (t8 << 6)) & 0x03030303u;
+                    t8 = (t8 | (t8 << 3)) & 0x11111111u;
+                    nw |= t8 << e;
+                }
+                if (nj < p.N) {
+                    if (p.epilogue == CGS_EPI_RELU_BWD_AFFINE) patch2_store_signs<CGS_EPI_RELU_BWD_AFFINE>(p, out_rsrc, acc, obase_l + tile_off, rowstride, ea1, nw);
+                    else patch2_store_signs<CGS_EPI_LRELU_BWD>(p, out_rsrc, acc, obase_l + tile_off, rowstride, ea1, nw);
+                }
+            } else if constexpr (AUXM == 1) {
                 const unsigned ob = tile_off + (unsigned)(n0 + wn * 32 + c4) * 4u + (unsigned)(wm * 4) * rowstride;
                 const bool live = n0 + wn * 32 + c4 < p.N;
                 f32x4 ea4 = {1.f, 1.f, 1.f, 1.f};
@@ -564,12 +617,18 @@ __global__ void pack_patch_weights_T_kernel(const float* __restrict__ w, float* 
     }
 }
 
+int cgs_conv_patch_signs_ok(const CgsLayer& L, bool dirT, int epilogue) {
+    return patch2_rp(L, dirT) != 0 && (L.Cs % 32) == 0 && (epilogue == CGS_EPI_RELU_BWD_AFFINE || epilogue == CGS_EPI_LRELU_BWD);
+}
+
 int cgs_conv_patch_launch(const CgsLayer& L, bool dirT, int B, const float* in, const float* w, const float* bias, float* out,
                           int epilogue, const float* ep_a, const float* ep_b, const float* ep_aux, float* ws, size_t ws_bytes,
-                          int prepacked, hipStream_t s) {
+                          int prepacked, hipStream_t s, const unsigned* aux_signs) {
+    if (aux_signs && !cgs_conv_patch_signs_ok(L, dirT, epilogue))
+        return cgs_set_error(CGS_EINVAL, "conv_patch: a sign mask serves the relu' / lrelu' epilogues of the 5x5x3 stride-2 kernel with N %% 32 == 0");
     PatchParams p;
     patch_geom(L, dirT, p);
-    p.in = in; p.wk = ws; p.bias = bias; p.ep_a = ep_a; p.ep_b = ep_b; p.ep_aux = ep_aux; p.out = out; p.B = B; p.epilogue = epilogue;
+    p.in = in; p.wk = ws; p.bias = bias; p.ep_a = ep_a; p.ep_b = ep_b; p.ep_aux = ep_aux; p.aux_signs = aux_signs; p.out = out; p.B = B; p.epilogue = epilogue;
     const size_t need = cgs_conv_patch_ws_floats(L, dirT) * sizeof(float);
     if (!ws || ws_bytes < need) return cgs_set_error(CGS_EWORKSPACE, "conv_patch: workspace %zu < %zu bytes", ws_bytes, need);
     if ((long)B * p.Hin * p.Win * p.Cred * 4 > 0x7fffffffL) return cgs_set_error(CGS_EINVAL, "conv_patch: input exceeds 2 GiB");
@@ -581,21 +640,24 @@ int cgs_conv_patch_launch(const CgsLayer& L, bool dirT, int B, const float* in, 
             CGS_CHECK_LAUNCH("pack_patch2_weights");
         }
         const bool auxp = epilogue >= CGS_EPI_RELU_BWD_AFFINE;
-        const size_t smem2 = ((size_t)2 * p.PH * p.pitch + (auxp ? (size_t)4 * 32 * 36 : 0)) * sizeof(float);
-        CGS_SMEM_ATTR(96 * 1024, "conv_patch2", conv_patch2_kernel<5, 16, 15, 8, false>);
-        CGS_SMEM_ATTR(96 * 1024, "conv_patch2 (aux)", conv_patch2_kernel<5, 16, 15, 8, true>);
+        const bool sgn = auxp && aux_signs != nullptr;
+        const size_t smem2 = ((size_t)2 * p.PH * p.pitch + ((auxp && !sgn) ? (size_t)4 * 32 * 36 : 0)) * sizeof(float);
+        CGS_SMEM_ATTR(96 * 1024, "conv_patch2", conv_patch2_kernel<5, 16, 15, 8, 0>);
+        CGS_SMEM_ATTR(96 * 1024, "conv_patch2 (aux)", conv_patch2_kernel<5, 16, 15, 8, 1>);
+        CGS_SMEM_ATTR(96 * 1024, "conv_patch2 (signs)", conv_patch2_kernel<5, 16, 15, 8, 2>);
         if (smem2 > 96 * 1024 || p.PH * p.PW * p.Cred > 8 * 256) return cgs_set_error(CGS_EINVAL, "conv_patch: patch too large");
         const long tiles2 = (long)B * (p.Hout / TR) * (p.Wout / TC) * (p.Np / PBN);
         if (tiles2 == 0) return CGS_OK;
         if (tiles2 > 0x7fffffffL) return cgs_set_error(CGS_EINVAL, "conv_patch: grid too large");
-        const long slots = auxp ? 512 : 768;          // persistent blocks: two (aux-prefetch form) or three per CU
+        const long slots = (auxp && !sgn) ? 512 : 768;          // persistent blocks: two (fp32 aux-prefetch form) or three per CU
         long per2 = (tiles2 + slots - 1) / slots;
         if (per2 < 4) per2 = tiles2 >= 4 * 256 ? 4 : 1;
         const unsigned nblk2 = (unsigned)((tiles2 + per2 - 1) / per2);
-        if (auxp) hipLaunchKernelGGL((conv_patch2_kernel<5, 16, 15, 8, true>), dim3(nblk2), dim3(256), smem2, s, p, (int)tiles2, (int)per2);
-        else hipLaunchKernelGGL((conv_patch2_kernel<5, 16, 15, 8, false>), dim3(nblk2), dim3(256), smem2, s, p, (int)tiles2, (int)per2);
+        if (sgn) hipLaunchKernelGGL((conv_patch2_kernel<5, 16, 15, 8, 2>), dim3(nblk2), dim3(256), smem2, s, p, (int)tiles2, (int)per2);
+        else if (auxp) hipLaunchKernelGGL((conv_patch2_kernel<5, 16, 15, 8, 1>), dim3(nblk2), dim3(256), smem2, s, p, (int)tiles2, (int)per2);
+        else hipLaunchKernelGGL((conv_patch2_kernel<5, 16, 15, 8, 0>), dim3(nblk2), dim3(256), smem2, s, p, (int)tiles2, (int)per2);
         CGS_CHECK_LAUNCH("conv_patch2");
-        cgs_note_kernel(auxp ? "conv_patch2_kernel<5, 16, 15, 8, true>" : "conv_patch2_kernel<5, 16, 15, 8, false>");
+        cgs_note_kernel(sgn ? "conv_patch2_kernel<5, 16, 15, 8, 2>" : auxp ? "conv_patch2_kernel<5, 16, 15, 8, 1>" : "conv_patch2_kernel<5, 16, 15, 8, 0>");
         return CGS_OK;
     }
     if (!prepacked) {

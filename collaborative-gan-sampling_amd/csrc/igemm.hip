@@ -139,6 +139,37 @@ int cgs_pack_weights(const IgemmParams& p, const CgsLayer& L, bool dirT, const f
 // Row pass of the wide epilogue for ONE epilogue mode (compile-time): branch-free inner loops and a compact
 // instruction footprint.  (With the mode as a run-time switch inside the unrolled loops the epilogue was ~21k lines
 // of ISA with 1.6k branches and took 20 us per block, 10 % of the block's life.)
+// SG: also leave the SIGN MASK of the stored values (p.sign_out; N % 32 == 0): the activation gradient of the layer above needs
+// one bit per element, not the fp32 tensor.  A row's 4-channel lanes sit in consecutive lanes, so v_cmp of element e over the
+// wave (ballot) holds, in the 8 bits starting at (lane & ~7), channels 4q + e (q = 0..7) of this lane's 32-channel group:
+// word = sum_e byte_e << 8e, i.e. bit 8 * (c % 4) + (c % 32) / 4 <-> channel c; the lane with (lane & 7) == 0 stores it into
+// the group's plane (one word per pixel, pixels contiguous: the consumer reads a tile row's words as one coalesced run).
+template <int EPI, int ROWS, int RPP, int LDE, bool SG>
+__device__ __forceinline__ void epilogue_rows_signs(const IgemmParams& p, const float* E, const int* rowpix_tile, int rsub, int c4,
+                                                    int n, f32x4 bias, f32x4 ea, f32x4 eb) {
+    const int lane = threadIdx.x & 63;
+    unsigned* plane = p.sign_out + (size_t)(n >> 5) * p.sign_plane;
+#pragma unroll
+    for (int it = 0; it < ROWS / RPP; ++it) {
+        const int lrow = it * RPP + rsub;
+        const int pix = rowpix_tile[lrow];
+        const bool live = pix >= 0;
+        const f32x4 v = *(const f32x4*)(E + lrow * LDE + c4);
+        const size_t o = (size_t)(live ? pix : 0) * p.N + n;
+        f32x4 y;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] = epilogue_apply(v[e] + bias[e], EPI, ea[e], eb[e], 0.f);
+        if (live) *(f32x4*)(p.out + o) = y;
+        unsigned word = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const unsigned long long bal = __builtin_amdgcn_ballot_w64(live && y[e] > 0.f);
+            word |= ((unsigned)(bal >> (lane & ~7)) & 0xffu) << (8 * e);
+        }
+        if (live && (lane & 7) == 0) plane[pix] = word;
+    }
+}
+
 template <int EPI, int ROWS, int RPP, int LDE, bool ST = false>
 __device__ __forceinline__ void epilogue_rows(const IgemmParams& p, const float* E, const int* rowpix_tile, int rsub, int c4,
                                               int n, f32x4 bias, f32x4 ea, f32x4 eb, f32x4* sa = nullptr, f32x4* sb = nullptr) {
@@ -604,45 +635,57 @@ __global__ __launch_bounds__(64 * NW, 2) void igemm_kernel(IgemmParams p) {
         d_.kt = c__ ? a_.kt : b_.kt; d_.sub = c__ ? a_.sub : b_.sub; d_.ia = c__ ? a_.ia : b_.ia;               \
         d_.ib = c__ ? a_.ib : b_.ib; d_.chunk = c__ ? a_.chunk : b_.chunk;                                      \
     } while (0)
-        KIt nxt = cur, ld = cur;
-        if (cur.kt < nk) nxt = kit_next(cur);
-        KIT_SEL(ld, nxt.kt < nk, nxt, cur);          // tile to prefetch (the current one again after the last)
-        if (cur.kt < nk) {
-            FRAG_READ(0, 0, fa0, fb0);
-            ADDR_TILE_V(ld);
-        }
-        for (int buf = 0; cur.kt < nk; buf ^= 1) {
+        // (the loop body as a macro over the addressing form: the uniform-tile form -- all rows of the tile one base pixel, the
+        // whole tap / channel offset in the buffer loads' scalar operand, no per-row bounds select -- serves the pixel-major
+        // launches here exactly as in the 16-deep kernels below)
+#define K_LOOP32(ADDR_, ISSUE_)                                                                                 \
+    {                                                                                                           \
+        KIt nxt = cur, ld = cur;                                                                                \
+        if (cur.kt < nk) nxt = kit_next(cur);                                                                   \
+        KIT_SEL(ld, nxt.kt < nk, nxt, cur);          /* tile to prefetch (the current one again after the last) */ \
+        if (cur.kt < nk) {                                                                                      \
+            FRAG_READ(0, 0, fa0, fb0);                                                                          \
+            ADDR_(ld);                                                                                          \
+        }                                                                                                       \
+        for (int buf = 0; cur.kt < nk; buf ^= 1) {                                                              \
+            DIAG_TILES32;                                                                                       \
+            ISSUE_(ld);                                                                                         \
+            _Pragma("unroll") for (int jj = 0; jj + 1 < NG; jj += 2) {     /* NG is even: fragments ping-pong between two register sets */ \
+                FRAG_READ(buf, jj + 1, fa1, fb1);                                                               \
+                __builtin_amdgcn_sched_barrier(0);                                                              \
+                MFMA_EXEC(fa0, fb0);                                                                            \
+                __builtin_amdgcn_sched_barrier(0);                                                              \
+                if (jj + 2 < NG) {                                                                              \
+                    FRAG_READ(buf, jj + 2, fa0, fb0);                                                           \
+                    __builtin_amdgcn_sched_barrier(0);                                                          \
+                    MFMA_EXEC(fa1, fb1);                                                                        \
+                    __builtin_amdgcn_sched_barrier(0);                                                          \
+                }                                                                                               \
+            }                                                                                                   \
+            STORE_TILE(buf ^ 1);                                                                                \
+            __syncthreads();                                                                                    \
+            FRAG_READ(buf ^ 1, 0, fa0, fb0);         /* first fragments of the next tile (a harmless re-read after the last one) */ \
+            __builtin_amdgcn_sched_barrier(0);                                                                  \
+            /* last MFMA group of this tile + the address arithmetic of the tile after next */                  \
+            cur = nxt;                                                                                          \
+            if (cur.kt < nk) {                                                                                  \
+                nxt = kit_next(cur);                                                                            \
+                KIT_SEL(ld, nxt.kt < nk, nxt, cur);                                                             \
+            }                                                                                                   \
+            ADDR_(ld);                                                                                          \
+            MFMA_EXEC(fa1, fb1);                                                                                \
+            __builtin_amdgcn_sched_barrier(0);                                                                  \
+        }                                                                                                       \
+    }
 #ifdef CGS_DIAG_STAMPS
-            ++diag_tiles;
+#define DIAG_TILES32 ++diag_tiles
+#else
+#define DIAG_TILES32
 #endif
-            ISSUE_TILE_V(ld);
-#pragma unroll
-            for (int jj = 0; jj + 1 < NG; jj += 2) {     // NG is even: fragments ping-pong between two register sets
-                FRAG_READ(buf, jj + 1, fa1, fb1);
-                __builtin_amdgcn_sched_barrier(0);
-                MFMA_EXEC(fa0, fb0);
-                __builtin_amdgcn_sched_barrier(0);
-                if (jj + 2 < NG) {
-                    FRAG_READ(buf, jj + 2, fa0, fb0);
-                    __builtin_amdgcn_sched_barrier(0);
-                    MFMA_EXEC(fa1, fb1);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-            STORE_TILE(buf ^ 1);
-            __syncthreads();
-            FRAG_READ(buf ^ 1, 0, fa0, fb0);         // first fragments of the next tile (a harmless re-read after the last one)
-            __builtin_amdgcn_sched_barrier(0);
-            // last MFMA group of this tile + the address arithmetic of the tile after next
-            cur = nxt;
-            if (cur.kt < nk) {
-                nxt = kit_next(cur);
-                KIT_SEL(ld, nxt.kt < nk, nxt, cur);
-            }
-            ADDR_TILE_V(ld);
-            MFMA_EXEC(fa1, fb1);
-            __builtin_amdgcn_sched_barrier(0);
-        }
+        if (uni) K_LOOP32(ADDR_TILE_U, ISSUE_TILE_U)
+        else K_LOOP32(ADDR_TILE_V, ISSUE_TILE_V)
+#undef K_LOOP32
+#undef DIAG_TILES32
     } else if constexpr (VEC) {
         // Two copies of the body, one per LDS buffer: the buffer offsets are then instruction immediates instead of a VALU add
         // per address and tile.  The pair loop has ONE exit (at its top, on a two-tile look-ahead), an odd last tile runs in a
@@ -782,6 +825,9 @@ __global__ __launch_bounds__(64 * NW, 2) void igemm_kernel(IgemmParams p) {
                 const int* rp = rowpix + wm * (BM / 2) + ph * ER;
                 if (p.stat_part) {        // (only with CGS_EPI_NONE: the statistics are those of the stored tensor)
                     epilogue_rows<CGS_EPI_NONE, ER, RPP, LDE, true>(p, E, rp, rsub, c4, n, bias, ea, eb, &st_a, &st_b);
+                } else if (p.sign_out) {  // (N % 32 == 0: every lane of the wave is inside N, the ballots see whole rows)
+                    if (p.epilogue == CGS_EPI_AFFINE_RELU) epilogue_rows_signs<CGS_EPI_AFFINE_RELU, ER, RPP, LDE, true>(p, E, rp, rsub, c4, n, bias, ea, eb);
+                    else epilogue_rows_signs<CGS_EPI_LRELU, ER, RPP, LDE, true>(p, E, rp, rsub, c4, n, bias, ea, eb);
                 } else
                 switch (p.epilogue) {     // wave-uniform; each case is one compact branch-free row loop
                     case CGS_EPI_NONE: epilogue_rows<CGS_EPI_NONE, ER, RPP, LDE>(p, E, rp, rsub, c4, n, bias, ea, eb); break;
@@ -914,6 +960,10 @@ static int choose_splitk(const IgemmParams& p) {
     return s < 2 ? 1 : (int)s;
 }
 
+int cgs_igemm_signs_ok(const IgemmParams& p) {
+    return (p.N % 32) == 0 && (p.epilogue == CGS_EPI_AFFINE_RELU || p.epilogue == CGS_EPI_LRELU) && choose_splitk(p) <= 1;
+}
+
 size_t cgs_igemm_splitk_bytes(const IgemmParams& p) {
     const int s = choose_splitk(p);
     if (s <= 1) return 0;
@@ -1008,8 +1058,10 @@ int cgs_igemm_launch(const IgemmParams& p_in, void* slab, size_t slab_bytes, hip
         return cgs_set_error(CGS_EINVAL, "igemm: a tensor of one launch exceeds 2 GiB (the caller splits the batch)");
     if (p.stat_part && (p.nclasses != 1 || (p.N & 3) || p.epilogue != CGS_EPI_NONE))
         return cgs_set_error(CGS_EINVAL, "igemm: fused statistics need the forward direction, N %% 4 == 0 and no epilogue");
+    if (p.sign_out && !cgs_igemm_signs_ok(p))
+        return cgs_set_error(CGS_EINVAL, "igemm: a sign mask needs N %% 32 == 0, the relu / lrelu forward epilogues and a grid that is not split over K");
     {   // split-K for under-filled grids, if the caller's workspace has room for the partial slabs
-        const size_t need = p.stat_part ? 0 : cgs_igemm_splitk_bytes(p);      // (the statistics come out of the one-pass epilogue)
+        const size_t need = (p.stat_part || p.sign_out) ? 0 : cgs_igemm_splitk_bytes(p);      // (the statistics / signs come out of the one-pass epilogue)
         if (need && slab && slab_bytes >= need) {
             p.splitk = choose_splitk(p); p.slab = (float*)slab;
             size_t off = 0;

@@ -92,8 +92,11 @@ class _Deconv(_Stage):
         self.out = torch.empty((B,) + tuple(out_shape), dtype=torch.float32, device=dev)
         self.dx = torch.empty((B,) + tuple(in_shape), dtype=torch.float32, device=dev)
 
+    signs = None        # int32 [B*Ho*Wo*C/32]: this stage's forward leaves the sign mask of its (relu'd) output there ...
+    bwd_signs = None    # ... and this stage's backward-data reads the mask of the stage below instead of its fp32 output
+
     def fwd(self, x):
-        return K.deconv2d_fwd(x, self.w, self.b, self.out_hw, self.s, self.s, self.epi, self.a, self.c, out=self.out)
+        return K.deconv2d_fwd(x, self.w, self.b, self.out_hw, self.s, self.s, self.epi, self.a, self.c, out=self.out, signs=self.signs)
 
     def bwd(self, dy):
         if not self.pre_folded:
@@ -102,7 +105,13 @@ class _Deconv(_Stage):
             elif self.epi == L.EPI_TANH:
                 dy = K.tanh_bwd(dy, self.out, out=dy)
         e, a, aux = self.bwd_epi
-        return K.deconv2d_bwd_data(dy, self.w, self.in_hw, self.s, self.s, out=self.dx, epilogue=e, ep_a=a, ep_aux=aux)
+        return K.deconv2d_bwd_data(dy, self.w, self.in_hw, self.s, self.s, out=self.dx, epilogue=e, ep_a=a, ep_aux=aux,
+                                   ep_signs=self.bwd_signs)
+
+    def call_dims(self):
+        """(B, H, W, Cin, Ho, Wo, Cout, kh, kw) of the forward call."""
+        kh, kw, Cout, Cin = self.w.shape
+        return (self.out.shape[0], self.in_hw[0], self.in_hw[1], Cin, self.out_hw[0], self.out_hw[1], Cout, kh, kw)
 
 
 class _Linear(_Stage):
@@ -371,6 +380,15 @@ def link_backward_fusion(stages):
             continue
         if isinstance(below, _Deconv) and below.epi == L.EPI_AFFINE_RELU:
             above.bwd_epi = (L.EPI_RELU_BWD_AFFINE, below.a, below.out)
+            # relu' needs the sign of below.out only: where the consumer is the HBM-bound 3-channel backward-data kernel and the
+            # producer can leave a bitmask from its epilogue, the 1-bit mask replaces the fp32 read (include/cgs_hip.h, "sign masks")
+            import os
+            if isinstance(above, _Deconv) and not os.environ.get("CGS_NO_SIGN_MASKS"):      # (A/B switch for measurements)
+                s_ = (below.s, below.s)
+                if (K.conv_signs_ok(L.DECONV_FWD, *below.call_dims(), *s_, L.EPI_AFFINE_RELU)
+                        and K.conv_signs_ok(L.DECONV_BWD_DATA, *above.call_dims(), above.s, above.s, L.EPI_RELU_BWD_AFFINE)):
+                    below.signs = torch.empty(below.out.numel() // 32, dtype=torch.int32, device=below.out.device)
+                    above.bwd_signs = below.signs
         elif isinstance(below, _Deconv) and below.epi == L.EPI_TANH:
             above.bwd_epi = (L.EPI_TANH_BWD, None, below.out)
         elif isinstance(below, _Conv) and below.epi == L.EPI_LRELU:

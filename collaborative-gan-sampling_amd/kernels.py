@@ -233,8 +233,16 @@ def conv2d_bwd_data(dy, w, in_hw, sh=2, sw=2, out=None, epilogue=L.EPI_NONE, ep_
     return dx
 
 
-def deconv2d_fwd(x, w, bias, out_hw, sh=2, sw=2, epilogue=L.EPI_NONE, ep_a=None, ep_b=None, out=None):
-    """tf.nn.conv2d_transpose (default 'SAME') + bias (+ fused epilogue).  nsgan/ops.py:55,61-62."""
+def conv_signs_ok(op, B, H, W, Cin, Ho, Wo, Cout, kh, kw, sh, sw, epilogue):
+    """Can this call leave (forward, relu / lrelu epilogue) or take (backward-data, relu' / lrelu' epilogue) a sign mask
+    instead of the fp32 aux tensor?  (include/cgs_hip.h, "sign masks")"""
+    _, nbytes = WS.plan(op, B, H, W, Cin, Ho, Wo, Cout, kh, kw, sh, sw, epilogue)
+    return bool(L.load().cgs_conv_signs_ok(op, B, H, W, Cin, Ho, Wo, Cout, kh, kw, sh, sw, epilogue, nbytes))
+
+
+def deconv2d_fwd(x, w, bias, out_hw, sh=2, sw=2, epilogue=L.EPI_NONE, ep_a=None, ep_b=None, out=None, signs=None):
+    """tf.nn.conv2d_transpose (default 'SAME') + bias (+ fused epilogue).  nsgan/ops.py:55,61-62.
+    ``signs``: int32 [B*Ho*Wo*Cout/32] that receives the sign mask of the output (only where ``conv_signs_ok``)."""
     _chk(x, "x"); _chk(w, "w")
     B, H, W, Cin = x.shape
     kh, kw, Cout, Cin2 = w.shape
@@ -245,15 +253,20 @@ def deconv2d_fwd(x, w, bias, out_hw, sh=2, sw=2, epilogue=L.EPI_NONE, ep_a=None,
     ws, pre = WS.get(w, L.DECONV_FWD, kh, kw, sh, sw, Cin, Cout, (B, H, W), epilogue, (Ho, Wo),
                      ptrs=(_ptr(x), _ptr(bias), _ptr(y), _ptr(ep_a), _ptr(ep_b)))
     pr = _Prof(2.0 * B * H * W * Cin * kh * kw * Cout, f"deconv_fwd {H}x{W} {Cin}->{Cout}", _nb(x, w, y)) if PROFILE is not None else None
-    L.call("cgs_deconv2d_nhwc_fwd", _ptr(x), _ptr(w), _ptr(bias), _ptr(y), B, H, W, Cin, Ho, Wo, Cout, kh, kw, sh, sw,
-           epilogue, _ptr(ep_a), _ptr(ep_b), _ptr(ws), ws.numel() * 4, pre, _stream())
+    if signs is not None:
+        L.call("cgs_deconv2d_nhwc_fwd_signs", _ptr(x), _ptr(w), _ptr(bias), _ptr(y), B, H, W, Cin, Ho, Wo, Cout, kh, kw, sh, sw,
+               epilogue, _ptr(ep_a), _ptr(ep_b), signs.data_ptr(), _ptr(ws), ws.numel() * 4, pre, _stream())
+    else:
+        L.call("cgs_deconv2d_nhwc_fwd", _ptr(x), _ptr(w), _ptr(bias), _ptr(y), B, H, W, Cin, Ho, Wo, Cout, kh, kw, sh, sw,
+               epilogue, _ptr(ep_a), _ptr(ep_b), _ptr(ws), ws.numel() * 4, pre, _stream())
     if pr is not None:
         pr.done()
     return y
 
 
-def deconv2d_bwd_data(dy, w, in_hw, sh=2, sw=2, out=None, epilogue=L.EPI_NONE, ep_a=None, ep_aux=None):
-    """Input gradient of deconv2d_fwd: a strided 'SAME' conv of dy with the deconv weights."""
+def deconv2d_bwd_data(dy, w, in_hw, sh=2, sw=2, out=None, epilogue=L.EPI_NONE, ep_a=None, ep_aux=None, ep_signs=None):
+    """Input gradient of deconv2d_fwd: a strided 'SAME' conv of dy with the deconv weights.
+    ``ep_signs``: the sign mask of the saved activation instead of ``ep_aux`` (relu' / lrelu' epilogues, where ``conv_signs_ok``)."""
     _chk(dy, "dy"); _chk(w, "w")
     kh, kw, Cout, Cin = w.shape
     B, Ho, Wo, _ = dy.shape
@@ -261,9 +274,14 @@ def deconv2d_bwd_data(dy, w, in_hw, sh=2, sw=2, out=None, epilogue=L.EPI_NONE, e
     dx = out if out is not None else torch.empty((B, H, W, Cin), dtype=torch.float32, device=dy.device)
     ws, pre = WS.get(w, L.DECONV_BWD_DATA, kh, kw, sh, sw, Cin, Cout, (B, H, W), epilogue, (Ho, Wo),
                      ptrs=(_ptr(dy), _ptr(dx), _ptr(ep_a), _ptr(ep_aux)))
-    pr = _Prof(2.0 * B * H * W * Cin * kh * kw * Cout, f"deconv_bwd {H}x{W} {Cin}<-{Cout}", _nb(dy, w, dx, ep_aux)) if PROFILE is not None else None
-    L.call("cgs_deconv2d_nhwc_bwd_data", _ptr(dy), _ptr(w), _ptr(dx), B, H, W, Cin, Ho, Wo, Cout, kh, kw, sh, sw,
-           epilogue, _ptr(ep_a), _ptr(ep_aux), _ptr(ws), ws.numel() * 4, pre, _stream())
+    pr = _Prof(2.0 * B * H * W * Cin * kh * kw * Cout, f"deconv_bwd {H}x{W} {Cin}<-{Cout}",
+               _nb(dy, w, dx, ep_aux if ep_signs is None else ep_signs)) if PROFILE is not None else None
+    if ep_signs is not None:
+        L.call("cgs_deconv2d_nhwc_bwd_data_signs", _ptr(dy), _ptr(w), _ptr(dx), B, H, W, Cin, Ho, Wo, Cout, kh, kw, sh, sw,
+               epilogue, _ptr(ep_a), ep_signs.data_ptr(), _ptr(ws), ws.numel() * 4, pre, _stream())
+    else:
+        L.call("cgs_deconv2d_nhwc_bwd_data", _ptr(dy), _ptr(w), _ptr(dx), B, H, W, Cin, Ho, Wo, Cout, kh, kw, sh, sw,
+               epilogue, _ptr(ep_a), _ptr(ep_aux), _ptr(ws), ws.numel() * 4, pre, _stream())
     if pr is not None:
         pr.done()
     return dx

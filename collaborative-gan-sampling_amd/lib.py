@@ -34,6 +34,9 @@ SIGNATURES = {
     "cgs_conv2d_nhwc_bwd_data": (_i, [_p] * 3 + [_i] * 9 + [_i, _p, _p, _p, _z, _i, _p]),
     "cgs_deconv2d_nhwc_fwd": (_i, [_p] * 4 + [_i] * 11 + [_i, _p, _p, _p, _z, _i, _p]),
     "cgs_deconv2d_nhwc_bwd_data": (_i, [_p] * 3 + [_i] * 11 + [_i, _p, _p, _p, _z, _i, _p]),
+    "cgs_conv_signs_ok": (_i, [_i] * 13 + [_z]),
+    "cgs_deconv2d_nhwc_fwd_signs": (_i, [_p] * 4 + [_i] * 11 + [_i, _p, _p, _p, _p, _z, _i, _p]),
+    "cgs_deconv2d_nhwc_bwd_data_signs": (_i, [_p] * 3 + [_i] * 11 + [_i, _p, _p, _p, _z, _i, _p]),
     "cgs_linear_fwd": (_i, [_p] * 4 + [_i] * 4 + [_p, _z, _i, _p]),
     "cgs_linear_bwd_data": (_i, [_p] * 3 + [_i] * 3 + [_p, _z, _i, _p]),
     "cgs_bn_ws_bytes": (_z, [_i, _i]),

@@ -127,6 +127,30 @@ int cgs_deconv2d_nhwc_bwd_data(const float* dy, const float* w, float* dx,
                                int epilogue, const float* ep_a, const float* ep_aux,
                                void* ws, size_t ws_bytes, int ws_prepacked, void* stream);
 
+/* ---- sign masks -------------------------------------------------------------------------------------------------------
+ * d relu / d lrelu need ONE BIT of the saved activation (is it > 0), not the fp32 tensor: where the consumer of that
+ * gradient is an HBM-bound kernel -- the backward-data of the generator's last, 3-channel deconv (a strided conv of the
+ * image gradient whose epilogue applies relu'(y) * a of nsgan/GAN.py:98-99's bn + relu; tf.gradients at
+ * sampling/collaborator.py:31) -- the producing forward launch leaves a bitmask next to its output and the backward launch
+ * reads that instead (8 MB instead of 268 MB for the 32x32x64 map at batch 1024).
+ * Layout, for a tensor [P pixels][C channels], C % 32 == 0: one plane of P words per 32-channel group,
+ * uint32 word[(c / 32) * P + p], bit 8 * (c % 4) + (c % 32) / 4 is set iff x[p][c] > 0 (the bit order of the producing
+ * epilogue's lane layout; the consumer un-shuffles it).  Caller-allocated, P * C / 8 bytes, 4-byte aligned.
+ * cgs_conv_signs_ok: 1 if the call with these arguments can LEAVE a mask (op a forward with CGS_EPI_LRELU / CGS_EPI_AFFINE_RELU)
+ * or TAKE one (op a backward-data with CGS_EPI_LRELU_BWD / CGS_EPI_RELU_BWD_AFFINE); 0 = use the fp32 aux tensor. */
+int cgs_conv_signs_ok(int op, int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int sh, int sw,
+                      int epilogue, size_t ws_bytes);
+/* cgs_deconv2d_nhwc_fwd that also writes the sign mask of y (after the epilogue) to signs. */
+int cgs_deconv2d_nhwc_fwd_signs(const float* x, const float* w, const float* bias, float* y,
+                                int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int sh, int sw,
+                                int epilogue, const float* ep_a, const float* ep_b, unsigned* signs,
+                                void* ws, size_t ws_bytes, int ws_prepacked, void* stream);
+/* cgs_deconv2d_nhwc_bwd_data whose relu' / lrelu' epilogue reads the sign mask of the saved activation (shape of dx). */
+int cgs_deconv2d_nhwc_bwd_data_signs(const float* dy, const float* w, float* dx,
+                                     int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int sh, int sw,
+                                     int epilogue, const float* ep_a, const unsigned* aux_signs,
+                                     void* ws, size_t ws_bytes, int ws_prepacked, void* stream);
+
 /* linear: y[B,out] = x[B,in] @ w[in,out] + bias, then epilogue (NONE or LRELU).
  * Replaces tf.matmul + bias at nsgan/ops.py:81-83.  ws as for conv (op CGS_CONV_FWD, kh=kw=1). */
 int cgs_linear_fwd(const float* x, const float* w, const float* bias, float* y, int B, int in, int out,

@@ -482,3 +482,92 @@ def test_fused_statistics_not_offered_where_unsupported():
     from cgs_amd import kernels as K
     assert K.conv_stat_partials((8, 64, 64, 3), (5, 5, 3, 64), 2, 2) == 0       # the 3-channel patch kernel serves this conv
     assert K.conv_stat_partials((8, 16, 16, 32), (5, 5, 32, 6), 2, 2) == 0      # Cout % 4 != 0
+
+
+def unpack_signs(words, P, C):
+    """include/cgs_hip.h "sign masks": word[(c / 32) * P + p], bit 8 * (c % 4) + (c % 32) / 4  ->  bool [P, C]."""
+    w = words.cpu().numpy().view(np.uint32).reshape(C // 32, P)
+    c = np.arange(C)
+    return ((w[c // 32, :].T >> (8 * (c % 4) + (c % 32) // 4)) & 1).astype(bool)
+
+
+def pack_signs(pos):
+    """bool [P, C] -> the mask words (int32 [C/32 * P]) in the documented layout."""
+    P, C = pos.shape
+    c = np.arange(C)
+    words = np.zeros((C // 32, P), dtype=np.uint32)
+    np.bitwise_or.at(words, ((c // 32)[None, :].repeat(P, 0), np.arange(P)[:, None].repeat(C, 1)),
+                     pos.astype(np.uint32) << (8 * (c % 4) + (c % 32) // 4).astype(np.uint32)[None, :])
+    return words.view(np.int32).reshape(-1)
+
+
+@pytest.mark.parametrize("epi", ["affine_relu", "lrelu"])
+@pytest.mark.parametrize("B,H,Cin,Cout", [(128, 8, 128, 64), (130, 8, 64, 96), (128, 8, 64, 128)])
+def test_forward_epilogue_leaves_the_sign_mask(B, H, Cin, Cout, epi):
+    """cgs_deconv2d_nhwc_fwd_signs: the same output, bit for bit, as the plain call, plus the documented bitmask of (y > 0):
+    BN = 64 and BN = 128 tiles (8 / 16 lanes per row), a channel count that is not a multiple of 64, a ragged batch."""
+    from cgs_amd import kernels as K, lib
+    d = dev()
+    x, w, b = rnd((B, H, H, Cin), 1).to(d), rnd((5, 5, Cout, Cin), 2, 0.05).to(d), rnd((Cout,), 3, 0.1).to(d)
+    a, c = (rnd((Cout,), 4).abs() + 0.5).to(d), rnd((Cout,), 5, 0.1).to(d)
+    e = lib.EPI_AFFINE_RELU if epi == "affine_relu" else lib.EPI_LRELU
+    ea, ec = (a, c) if epi == "affine_relu" else (None, None)
+    assert K.conv_signs_ok(lib.DECONV_FWD, B, H, H, Cin, 2 * H, 2 * H, Cout, 5, 5, 2, 2, e)
+    y0 = K.deconv2d_fwd(x, w, b, (2 * H, 2 * H), 2, 2, e, ea, ec)
+    signs = torch.full((y0.numel() // 32,), -1, dtype=torch.int32, device=d)
+    y1 = K.deconv2d_fwd(x, w, b, (2 * H, 2 * H), 2, 2, e, ea, ec, signs=signs)
+    assert torch.equal(y0, y1)
+    got = unpack_signs(signs, B * 4 * H * H, Cout)
+    assert np.array_equal(got, (y1 > 0).cpu().numpy().reshape(-1, Cout))
+    # not offered: split-K grids (tiny batch), channel counts off the 32 granule, epilogues without a kink
+    assert not K.conv_signs_ok(lib.DECONV_FWD, 2, H, H, Cin, 2 * H, 2 * H, Cout, 5, 5, 2, 2, e)
+    assert not K.conv_signs_ok(lib.DECONV_FWD, B, H, H, Cin, 2 * H, 2 * H, 40, 5, 5, 2, 2, e)
+    assert not K.conv_signs_ok(lib.DECONV_FWD, B, H, H, Cin, 2 * H, 2 * H, Cout, 5, 5, 2, 2, lib.EPI_TANH)
+    with pytest.raises(lib.CgsError):
+        K.deconv2d_fwd(x[:2], w, b, (2 * H, 2 * H), 2, 2, e, ea, ec, signs=signs)
+
+
+@pytest.mark.parametrize("mode", ["relu_affine", "lrelu"])
+@pytest.mark.parametrize("B,H,C", [(3, 16, 64), (5, 8, 32), (2, 32, 96)])
+def test_backward_epilogue_reads_the_sign_mask(B, H, C, mode):
+    """cgs_deconv2d_nhwc_bwd_data_signs (the 5x5x3 stride-2 LDS-patch kernel): relu' / lrelu' from the 1-bit mask gives exactly
+    what the fp32 aux tensor gives -- masks built here in the documented layout, aux values include exact zeros and negatives."""
+    from cgs_amd import kernels as K, lib
+    d = dev()
+    W = 16 if H < 32 else 32
+    dy, w = rnd((B, 2 * H, 2 * W, 3), 1).to(d), rnd((5, 5, 3, C), 2, 0.05).to(d)
+    aux = rnd((B, H, W, C), 3)
+    aux[aux.abs() < 0.3] = 0.0                                   # relu outputs are exactly 0 on a third of the elements
+    a = (rnd((C,), 4).abs() + 0.5).to(d)
+    e = lib.EPI_RELU_BWD_AFFINE if mode == "relu_affine" else lib.EPI_LRELU_BWD
+    assert K.conv_signs_ok(lib.DECONV_BWD_DATA, B, H, W, C, 2 * H, 2 * W, 3, 5, 5, 2, 2, e)
+    want = K.deconv2d_bwd_data(dy, w, (H, W), 2, 2, epilogue=e, ep_a=a if mode == "relu_affine" else None, ep_aux=aux.to(d))
+    assert lib.last_kernel() == "conv_patch2_kernel<5, 16, 15, 8, 1>"
+    pos = (aux > 0).numpy().reshape(-1, C)
+    assert np.array_equal(unpack_signs(torch.from_numpy(pack_signs(pos)), pos.shape[0], C), pos)
+    signs = torch.from_numpy(pack_signs(pos)).to(d)
+    got = K.deconv2d_bwd_data(dy, w, (H, W), 2, 2, epilogue=e, ep_a=a if mode == "relu_affine" else None, ep_signs=signs)
+    assert lib.last_kernel() == "conv_patch2_kernel<5, 16, 15, 8, 2>"
+    assert torch.equal(got, want)
+    assert not K.conv_signs_ok(lib.DECONV_BWD_DATA, B, H, W, C, 2 * H, 2 * W, 3, 5, 5, 2, 2, lib.EPI_TANH_BWD)
+
+
+def test_engine_uses_sign_masks_and_matches_the_fp32_aux_path(monkeypatch):
+    """dcgan64 / dcgan32: g_h3's forward leaves the mask, g_h4's backward-data reads it; the refinement is bit-equal to the
+    engine built with CGS_NO_SIGN_MASKS (the fp32 aux read)."""
+    from cgs_amd import engine as E
+    from cgs_amd.nets import init_params
+    d = dev()
+    B, Ks = 128, 2
+    P = init_params("dcgan64", d, seed=5)
+    z = rnd((B, 100), 7).to(d)
+    eng = E.RefineEngine("dcgan64", P, B, d)
+    tail = [st for st in eng.g_tail.stages if isinstance(st, E._Deconv)]
+    assert tail[-2].signs is not None and tail[-1].bwd_signs is tail[-2].signs
+    got = [t.clone() for t in eng.refine_from_z(z, Ks, 0.1)]
+    monkeypatch.setenv("CGS_NO_SIGN_MASKS", "1")
+    ref = E.RefineEngine("dcgan64", P, B, d)
+    assert all(st.signs is None for st in ref.g_tail.stages if isinstance(st, E._Deconv))
+    want = ref.refine_from_z(z, Ks, 0.1)
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
