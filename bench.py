@@ -7,7 +7,7 @@ render, images left in HBM.  Default workload = BASELINE configs[2]: DCGAN Celeb
 per GPU, K = 20 (the configuration the 10k samples/s target is quoted on; it fits one GPU).
 Inputs (z batches) and weights are resident in HBM before the timed region.  Two steps are in flight per GPU
 (--streams), and for the small configurations several logical batches share one launch, each with its own
-batch-norm statistics (--fuse; dcgan32 4 x 256, mnist 16 x 64): the work and the results of a step are unchanged.
+batch-norm statistics (--fuse; dcgan32 8 x 256, mnist 32 x 64: ~2048 samples per launch): the work and the results of a step are unchanged.
 The K-step program of a step is replayed as a hipGraph (the launch-bound inner loop: ~1300 dependent launches per step;
 --no-graph launches them one by one); the per-kernel HIP-event timing behind `roofline` then comes from one extra step
 launched eagerly on one stream right after the timed region (the same kernels with the same arguments).
@@ -49,6 +49,10 @@ HBM_OPS = {
     "bn_train_lrelu_bwd_data": ["bn_partial_kernel<1>", "bn_finalize_kernel<1>", "bn_restat_kernel", "bn_apply_bwd_kernel"],
     "refine_update": ["refine_update_kernel"],
 }
+# logical batches fused per launch by default (tools/sweep_fuse.sh on MI355X, two launches in flight: mnist 16 -> 24.3 k,
+# 24 -> 26.1 k, 32 -> 26.3 k, 40 -> 27.1 k samples/s; dcgan32 4 -> 26.5 k, 6 -> 27.5 k, 8 -> 28.6 k): the tails and the per-launch
+# fixed costs of the ~13-27 GFLOP layers amortise over more rows
+FUSE = {"dcgan32": 8, "mnist": 32}
 THREE_CHANNEL = ("convt_rows_kernel", "conv_patch2_kernel", "conv_patch_kernel", "convt_quad")
 
 
@@ -250,7 +254,7 @@ def other_configs(dev, skip, want_cpu):
     from cgs_amd import nets
     from cgs_amd.engine import RefineEngine
     out = {}
-    for arch, B, Ksteps, G, steps in (("mnist", 64, 50, 16, 6), ("dcgan32", 256, 20, 4, 6)):
+    for arch, B, Ksteps, G, steps in (("mnist", 64, 50, FUSE["mnist"], 6), ("dcgan32", 256, 20, FUSE["dcgan32"], 6)):
         if arch == skip:
             continue
         A = nets.ARCHS[arch]
@@ -325,7 +329,7 @@ def main():
                          "batch overlap the big kernels of the other (measured: 1 -> 5040, 2 -> 5500, 3 -> 5460 samples/s)")
     ap.add_argument("--fuse", type=int, default=0,
                     help="logical batches fused into one engine batch (conv launches G times larger, batch-norm statistics kept "
-                         "per logical batch).  Default: as many as make ~1024 samples per launch (dcgan64 1, dcgan32 4, mnist 16)")
+                         "per logical batch).  Default: dcgan64 1, dcgan32 8, mnist 32 (~2048 samples per launch; measured sweep in DESIGN.md 6)")
     ap.add_argument("--sync-bn", action="store_true",
                     help="treat the N ranks' batches as ONE logical batch of N*B samples: all-reduce D's batch-norm sums "
                          "(needs the torch.distributed launch; eager only)")
@@ -381,7 +385,7 @@ def main():
     P = nets.init_params(args.arch, dev, seed=2019)                     # same frozen weights on every rank
     if args.sync_bn and not use_dist:
         raise SystemExit("--sync-bn needs the torch.distributed launch (python -m torch.distributed.run ... bench.py)")
-    G = args.fuse if args.fuse > 0 else {"dcgan32": 4, "mnist": 16}.get(args.arch, 1) if not args.sync_bn else 1
+    G = args.fuse if args.fuse > 0 else FUSE.get(args.arch, 1) if not args.sync_bn else 1
     graph_forced = args.graph is True
     if args.graph is None:
         # default: replay graphs at every world size (the engine captures in thread-local mode on its own side stream, so RCCL's

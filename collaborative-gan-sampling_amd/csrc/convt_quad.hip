@@ -15,6 +15,8 @@
 // needed); the packed weights (37 KB for 9 x 64 x 16) sit in LDS for the whole block.
 #include <stdio.h>
 
+#include <stdlib.h>
+
 #include "cgs_internal.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -374,9 +376,14 @@ __global__ void pack_rows_weights_kernel(const float* __restrict__ w, float* __r
 // (row, chunk) steps of a task become straight-line code -- which row taps apply to a step is known, the loads of step s + 2
 // are in flight under the MFMAs of step s with exact vmcnt waits (with the generic form's uniform branches the compiler waits
 // for vmcnt(0) before every MFMA group, which serialises loads and matrix work: 133 us instead of 9x for dcgan64's g_h4)
-template <int N, int MT, bool S5>   // N output channels, MT 16-pixel tiles per input row (Ws <= 16 * MT)
+// NP: output row pairs per task.  2 (round 2): 4 input rows per 2 pairs, every input row read by two tasks (HBM bytes 475 MB for
+// 319 algorithmic on dcgan64's g_h4).  4: 6 input rows per 4 pairs -- a quarter fewer loads, 1.5 reads per row instead of 2 -- for
+// twice the accumulators (64 VGPRs; the launch runs two blocks = 4 waves per SIMD anyway, so 128 VGPRs are there).
+// AUXE: the *_BWD epilogues (an aux tensor of the output's shape); compiled apart so that the forward form carries no aux registers.
+template <int N, int MT, bool S5, int NP, bool AUXE>   // N output channels, MT 16-pixel tiles per input row (Ws <= 16 * MT)
 __global__ __launch_bounds__(512, 4) void convt_rows_kernel(RowsParams p, int tasks_total, int tasks_per_block) {
     const int kh = S5 ? 5 : p.kh, pt = S5 ? 1 : p.pt, dmin_y = S5 ? -1 : p.dmin_y, ny = S5 ? 3 : p.ny;
+    constexpr int NYO = 2 * NP;                             // output rows per task
     constexpr int NWV = 8;                                  // waves per block
     // staging of one output row pair: [2 rows][pixel -2 .. ROWS][SL floats]; the pixels < 0 and >= Ws and the columns >= 16 stay
     // zero, so the gather needs no bounds: its three terms are the lane's base address + instruction immediates
@@ -434,18 +441,19 @@ __global__ __launch_bounds__(512, 4) void convt_rows_kernel(RowsParams p, int ta
     }
     __syncthreads();
     const int nchunk = S5 ? 4 : p.Cs >> 4;
-    const int nrow = ny + 1;                              // input rows feeding TWO consecutive output row pairs
-    const int nit = S5 ? 16 : nrow * nchunk;
+    const int nrow = ny + NP - 1;                         // input rows feeding NP consecutive output row pairs
+    constexpr int NIT5 = (3 + NP - 1) * 4;                // S5: (row, chunk) steps of a task
+    const int nit = S5 ? NIT5 : nrow * nchunk;
     const size_t out_row = (size_t)2 * p.Ws * N;
 
-    // a task = two consecutive output row pairs (R0, R0 + 1) of one image: the 4 (ny + 1) input rows R0 + dmin_y .. are read once
-    // for both (a row pair alone needs 3: a third fewer loads), the packed weights of a row tap serve both M tiles
-    const int pairs_y = (p.Hs + 1) >> 1;
+    // a task = NP consecutive output row pairs (R0 .. R0 + NP - 1) of one image: the ny + NP - 1 input rows R0 + dmin_y .. are read
+    // once for all of them (a row pair alone needs 3), the packed weights of a row tap serve both M tiles
+    const int pairs_y = (p.Hs + NP - 1) / NP;
     for (int t = t_begin + wave; t < t_end; t += NWV) {
-        const int b = t / pairs_y, R0 = (t - b * pairs_y) * 2;
-        f32x4 acc[4][MT];
+        const int b = t / pairs_y, R0 = (t - b * pairs_y) * NP;
+        f32x4 acc[NYO][MT];
 #pragma unroll
-        for (int y = 0; y < 4; ++y)
+        for (int y = 0; y < NYO; ++y)
 #pragma unroll
             for (int m = 0; m < MT; ++m) acc[y][m] = f32x4{0.f, 0.f, 0.f, 0.f};
         f32x4 a0[MT], a1[MT], a2[MT];
@@ -474,13 +482,15 @@ __global__ __launch_bounds__(512, 4) void convt_rows_kernel(RowsParams p, int ta
     do {                                                                                                    \
         const int d_ = (it_) / nchunk, j_ = (it_) - d_ * nchunk;                                            \
         const int ky_ = pt - 2 * (dmin_y + d_);                                                         \
-        _Pragma("unroll") for (int y = 0; y < 4; ++y)                                                       \
+        _Pragma("unroll") for (int y = 0; y < NYO; ++y)                                                     \
             if ((unsigned)(ky_ + y) < (unsigned)kh) ROWS_MFMA(a_, acc[y], ky_ + y, j_);                   \
     } while (0)
-        // the aux values of the backward epilogues: the first row pair's are requested before the K loop, the second pair's
-        // before the first pair's gather
-        f32x4 aux[NU], aux_n[NU];
-        if (p.epilogue >= CGS_EPI_RELU_BWD_AFFINE) {
+        // the aux values of the backward epilogues (NP = 2: the first row pair's are requested before the K loop, the next pair's
+        // before the current pair's gather; the tall form has no registers for a second set and requests each pair's before its
+        // accumulators go through the staging tile)
+        constexpr bool AUX2 = AUXE && NP == 2;
+        f32x4 aux[AUXE ? NU : 1], aux_n[AUX2 ? NU : 1];
+        if constexpr (AUX2) {
             const size_t o0 = ((size_t)(b * 2 * p.Hs + 2 * R0)) * out_row;
 #pragma unroll
             for (int u = 0; u < NU; ++u) {
@@ -491,7 +501,7 @@ __global__ __launch_bounds__(512, 4) void convt_rows_kernel(RowsParams p, int ta
         ROWS_LOAD_A(a0, 0);
         if (1 < nit) ROWS_LOAD_A(a1, 1);
 #pragma unroll
-        for (int it = 0; it < (S5 ? 16 : nit); it += 3) {   // two steps of loads in flight under each step's MFMAs
+        for (int it = 0; it < (S5 ? NIT5 : nit); it += 3) {   // two steps of loads in flight under each step's MFMAs
             // (sched_barrier: left alone, the scheduler hoists the straight-line form's fragment reads and loads far ahead and spills)
             if (it + 2 < nit) ROWS_LOAD_A(a2, it + 2);
             if (S5) __builtin_amdgcn_sched_barrier(0);
@@ -514,23 +524,26 @@ __global__ __launch_bounds__(512, 4) void convt_rows_kernel(RowsParams p, int ta
 #undef ROWS_MFMA
 #undef ROWS_STEP
 #pragma unroll
-        for (int hp = 0; hp < 2; ++hp) {                    // the two row pairs, one after the other through the staging tile
+        for (int hp = 0; hp < NP; ++hp) {                   // the row pairs, one after the other through the staging tile
             if (R0 + hp >= p.Hs) break;
             const size_t o_pair = ((size_t)(b * 2 * p.Hs + 2 * (R0 + hp))) * out_row;
             int gq[NU];
 #pragma unroll
             for (int u = 0; u < NU; ++u) gq[u] = Tq[u * 64 + lane];
-            if (p.epilogue >= CGS_EPI_RELU_BWD_AFFINE) {
-                if (hp == 0) {
-                    if (R0 + 1 < p.Hs) {
-#pragma unroll
-                        for (int u = 0; u < NU; ++u)
-                            if (gq[u] >= 0) aux_n[u] = *(const f32x4*)(p.ep_aux + o_pair + 2 * out_row + gq[u]);
-                    }
-                } else {
+            if constexpr (AUX2) {     // this pair's aux values were requested one pair ago; request the next pair's now
+                if (hp > 0) {
 #pragma unroll
                     for (int u = 0; u < NU; ++u) aux[u] = aux_n[u];
                 }
+                if (hp + 1 < NP && R0 + hp + 1 < p.Hs) {
+#pragma unroll
+                    for (int u = 0; u < NU; ++u)
+                        if (gq[u] >= 0) aux_n[u] = *(const f32x4*)(p.ep_aux + o_pair + 2 * out_row + gq[u]);
+                }
+            } else if constexpr (AUXE) {
+#pragma unroll
+                for (int u = 0; u < NU; ++u)
+                    if (gq[u] >= 0) aux[u] = *(const f32x4*)(p.ep_aux + o_pair + gq[u]);
             }
             // Q -> staging (C/D layout of 16x16x4: column = lane & 15, row = (lane >> 4) * 4 + reg); the previous reads of the tile
             // are complete (LDS operations of one wave finish in order; the fences only pin the compiler)
@@ -562,10 +575,10 @@ __global__ __launch_bounds__(512, 4) void convt_rows_kernel(RowsParams p, int ta
                 } else if (p.epilogue == CGS_EPI_LRELU) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.2f * v[e]);
-                } else if (p.epilogue >= CGS_EPI_RELU_BWD_AFFINE) {
+                } else if (AUXE && p.epilogue >= CGS_EPI_RELU_BWD_AFFINE) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float y = aux[u][e];
+                        const float y = aux[AUXE ? u : 0][e];
                         if (p.epilogue == CGS_EPI_TANH_BWD) v[e] *= (1.f - y * y);
                         else if (p.epilogue == CGS_EPI_LRELU_BWD) v[e] = y > 0.f ? v[e] : 0.2f * v[e];
                         else v[e] = y > 0.f ? v[e] * p.ep_a[(gq[u] + e) % N] : 0.f;
@@ -636,7 +649,15 @@ int cgs_convt_quad_launch(const CgsLayer& L, int B, const float* in, const float
             hipLaunchKernelGGL(pack_rows_weights_kernel, dim3((unsigned)((wfl + 255) / 256)), dim3(256), 0, s, w, ws, L.kh, L.kw, L.Cb, L.Cs);
             CGS_CHECK_LAUNCH("pack_rows_weights");
         }
-        const long tasks = (long)B * ((L.Hs + 1) / 2);      // two output row pairs per task
+        const bool s5 = L.kh == 5 && L.Cs == 64 && pt == 1 && p.dmin_y == -1 && p.ny == 3;
+        // output row pairs per task: the forward 5x5 64 -> 3 layers run the tall form (with an aux epilogue its 64 accumulators + the
+        // aux values do not fit 128 VGPRs: 35 spilled registers)
+        const bool tall_ok = s5 && L.Cb == 3 && L.Hs >= 8 && epilogue < CGS_EPI_RELU_BWD_AFFINE;
+        int np = tall_ok ? 4 : 2;
+#ifdef CGS_EXPERIMENT
+        if (getenv("CGS_ROWS_NP")) np = atoi(getenv("CGS_ROWS_NP")) == 4 && tall_ok ? 4 : 2;
+#endif
+        const long tasks = (long)B * ((L.Hs + np - 1) / np);
         if (tasks == 0) return CGS_OK;
         // persistent blocks of 8 independent waves, two per CU; a block's waves walk neighbouring row pairs of a contiguous run
         long blocks = (tasks + 7) / 8;
@@ -646,30 +667,33 @@ int cgs_convt_quad_launch(const CgsLayer& L, int B, const float* in, const float
         blocks = (tasks + per - 1) / per;
         const int nu = (2 * (2 * mt * 16 * L.Cb / 4) + 63) / 64;
         const size_t smem = (wfl + (size_t)8 * (2 * (mt * 16 + 3) * 20) + (size_t)nu * 64 * 9) * sizeof(float);
-#define ROWS_LAUNCH(NN, MM, SS)                                                                                      \
+#define ROWS_LAUNCH(NN, MM, SS, PP)                                                                                  \
+    if (epilogue >= CGS_EPI_RELU_BWD_AFFINE) ROWS_LAUNCH_(NN, MM, SS, PP, true) else ROWS_LAUNCH_(NN, MM, SS, PP, false)
+#define ROWS_LAUNCH_(NN, MM, SS, PP, AA)                                                                             \
     {                                                                                                              \
         static bool done_[64] = {};                                                                                \
         int dv_ = 0;                                                                                               \
         (void)hipGetDevice(&dv_);                                                                                  \
         dv_ &= 63;                                                                                                 \
         if (!done_[dv_]) {                                                                                         \
-            hipError_t e = hipFuncSetAttribute((const void*)convt_rows_kernel<NN, MM, SS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            hipError_t e = hipFuncSetAttribute((const void*)convt_rows_kernel<NN, MM, SS, PP, AA>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
             if (e != hipSuccess) return cgs_set_error(CGS_ELAUNCH, "convt_rows smem attr: %s", hipGetErrorString(e)); \
             done_[dv_] = true;                                                                                     \
         }                                                                                                          \
-        hipLaunchKernelGGL((convt_rows_kernel<NN, MM, SS>), dim3((unsigned)blocks), dim3(512), smem, s, r, (int)tasks, (int)per); \
+        hipLaunchKernelGGL((convt_rows_kernel<NN, MM, SS, PP, AA>), dim3((unsigned)blocks), dim3(512), smem, s, r, (int)tasks, (int)per); \
     }
-        const bool s5 = L.kh == 5 && L.Cs == 64 && pt == 1 && p.dmin_y == -1 && p.ny == 3;
         if (L.Cb == 3) {
-            if (mt == 1) { if (s5) ROWS_LAUNCH(3, 1, true) else ROWS_LAUNCH(3, 1, false) }
-            else { if (s5) ROWS_LAUNCH(3, 2, true) else ROWS_LAUNCH(3, 2, false) }
+            if (mt == 1) { if (s5 && np == 4) ROWS_LAUNCH_(3, 1, true, 4, false) else if (s5) ROWS_LAUNCH(3, 1, true, 2) else ROWS_LAUNCH(3, 1, false, 2) }
+            else { if (s5 && np == 4) ROWS_LAUNCH_(3, 2, true, 4, false) else if (s5) ROWS_LAUNCH(3, 2, true, 2) else ROWS_LAUNCH(3, 2, false, 2) }
         } else {
-            if (mt == 1) ROWS_LAUNCH(1, 1, false) else ROWS_LAUNCH(1, 2, false)
+            if (mt == 1) ROWS_LAUNCH(1, 1, false, 2) else ROWS_LAUNCH(1, 2, false, 2)
         }
 #undef ROWS_LAUNCH
+#undef ROWS_LAUNCH_
         CGS_CHECK_LAUNCH("convt_rows");
         static thread_local char name[48];
-        snprintf(name, sizeof(name), "convt_rows_kernel<%d, %d, %s>", L.Cb, mt, (s5 && L.Cb == 3) ? "true" : "false");       // as rocprofv3 prints it
+        snprintf(name, sizeof(name), "convt_rows_kernel<%d, %d, %s, %d, %s>", L.Cb, mt, (s5 && L.Cb == 3) ? "true" : "false", np,
+                 epilogue >= CGS_EPI_RELU_BWD_AFFINE ? "true" : "false");       // as rocprofv3 prints it
         cgs_note_kernel(name);
         return CGS_OK;
     }

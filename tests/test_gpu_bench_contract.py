@@ -98,10 +98,10 @@ def test_two_ranks_on_the_one_gpu_through_the_whole_multi_rank_path():
     assert len(lines) == 1, out.stdout                                      # rank 0 only
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["value"] > 0
-    assert d["config"]["global_batch"] == 2 * 64 * 16 and "x2" in d["config"]["parallelism"]
+    assert d["config"]["global_batch"] == 2 * 64 * 32 and "x2" in d["config"]["parallelism"]
     x = d["dist"]
     assert x["backend"] == "gloo" and x["world_size"] == 2 and x["ranks_seen"] == 2
-    assert x["pool_bytes"] == 2 * 64 * 16 * 28 * 28 * 4 and x["gather_ms_per_step"] > 0
+    assert x["pool_bytes"] == 2 * 64 * 32 * 28 * 28 * 4 and x["gather_ms_per_step"] > 0
     assert x["pool_rows_match_ranks"] is True and x["pool_rank_sums_distinct"] is True     # rank r's rows ARE rank r's images; seeds differ
     assert x["hipgraph_ranks"] == 2 and d["config"]["hipgraph"] is True
     lo, hi = x["per_rank_samples_per_s"]

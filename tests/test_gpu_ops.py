@@ -157,13 +157,16 @@ def test_deconv2d_bwd_data(B, H, W, Cin, Ho, Wo, Cout, k, s):
 
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout,k,name", [
-    (37, 32, 32, 64, 3, 5, "convt_rows_kernel<3, 2, true>"),      # dcgan64 g_h4 / d_h0 backward-data; row pairs not a multiple of the 8 waves
-    (9, 16, 16, 64, 3, 5, "convt_rows_kernel<3, 1, true>"),       # dcgan32 g_h4: the straight-line 5x5x64 form, one pixel tile, odd image count
-    (300, 16, 16, 32, 3, 5, "convt_rows_kernel<3, 1, false>"),     # dcgan32; 4800 row pairs over 512 persistent blocks
-    (5, 14, 14, 64, 1, 4, "convt_rows_kernel<1, 1, false>"),       # mnist g_dc4 (4x4 kernel, one channel, 14 of 16 pixels per tile)
-    (3, 20, 12, 32, 3, 5, "convt_rows_kernel<3, 1, false>"),       # ragged width, non-square
-    (2, 9, 24, 16, 3, 3, "convt_rows_kernel<3, 2, false>"),        # 3x3 kernel, 24 of 32 pixels
-    (2, 7, 24, 16, 1, 5, "convt_rows_kernel<1, 2, false>"),        # one channel, odd number of row pairs
+    # (kernel template arguments: N, 16-pixel tiles per row, straight-line 5x5x64 form, row pairs per task, aux epilogue)
+    (37, 32, 32, 64, 3, 5, "convt_rows_kernel<3, 2, true, 4|2, %s>"),      # dcgan64 g_h4 (tall form) / d_h0 backward-data; row pairs not a multiple of the 8 waves
+    (9, 16, 16, 64, 3, 5, "convt_rows_kernel<3, 1, true, 4|2, %s>"),       # dcgan32 g_h4: the straight-line 5x5x64 form, one pixel tile, odd image count
+    (5, 10, 16, 64, 3, 5, "convt_rows_kernel<3, 1, true, 4|2, %s>"),       # the tall form with a ragged last task (10 row pairs = 4 + 4 + 2)
+    (3, 6, 32, 64, 3, 5, "convt_rows_kernel<3, 2, true, 2|2, %s>"),        # fewer than 8 input rows: two row pairs per task
+    (300, 16, 16, 32, 3, 5, "convt_rows_kernel<3, 1, false, 2|2, %s>"),    # dcgan32; 4800 row pairs over 512 persistent blocks
+    (5, 14, 14, 64, 1, 4, "convt_rows_kernel<1, 1, false, 2|2, %s>"),      # mnist g_dc4 (4x4 kernel, one channel, 14 of 16 pixels per tile)
+    (3, 20, 12, 32, 3, 5, "convt_rows_kernel<3, 1, false, 2|2, %s>"),      # ragged width, non-square
+    (2, 9, 24, 16, 3, 3, "convt_rows_kernel<3, 2, false, 2|2, %s>"),       # 3x3 kernel, 24 of 32 pixels
+    (2, 7, 24, 16, 1, 5, "convt_rows_kernel<1, 2, false, 2|2, %s>"),       # one channel, odd number of row pairs
     (2, 6, 48, 16, 1, 5, "convt_quad_lds_kernel<1, 16, 3>"),  # wider than 32 pixels -> quad form
     (2, 8, 40, 16, 3, 5, "convt_quad_lds_kernel<3, 16, 3>"),  # wider than the rows form takes with 3 channels -> quad form
 ])
@@ -173,8 +176,14 @@ def test_rows_form_of_small_channel_transposed_conv(B, H, W, Cin, Cout, k, name)
     from cgs_amd import kernels as K, lib
     d = dev()
     x, w, b = rnd((B, H, W, Cin), 1), rnd((k, k, Cout, Cin), 2, 0.05), rnd((Cout,), 3, 0.1)
+    def kname(aux):      # "...<.., fwd pairs|bwd pairs, %s>" -> the instantiation of the forward (no aux) / backward (aux) call
+        if "|" not in name:
+            return name
+        head, rest = name.split("|")
+        pairs_f = head.rsplit(", ", 1)[1]
+        return (head if not aux else head[:-len(pairs_f)] + rest.split(",")[0]) + ", " + ("true>" if aux else "false>")
     got = K.deconv2d_fwd(x.to(d), w.to(d), b.to(d), (2 * H, 2 * W), 2, 2, lib.EPI_TANH)
-    assert lib.last_kernel() == name, lib.last_kernel()
+    assert lib.last_kernel() == kname(False), lib.last_kernel()
     close(got, torch.tanh(R.deconv2d(x, w, b, (B, 2 * H, 2 * W, Cout), 2, 2)), 2e-5)
     got = K.deconv2d_fwd(x.to(d), w.to(d), None, (2 * H, 2 * W), 2, 2)
     close(got, R.deconv2d(x, w, torch.zeros(Cout), (B, 2 * H, 2 * W, Cout), 2, 2), 2e-5)
@@ -185,7 +194,7 @@ def test_rows_form_of_small_channel_transposed_conv(B, H, W, Cin, Cout, k, name)
     (R.conv2d(xb, wc, torch.zeros(Cin), 2, 2) * dy).sum().backward()
     aux = rnd((B, 2 * H, 2 * W, Cout), 7, 0.5)
     got = K.conv2d_bwd_data(dy.to(d), wc.to(d), (2 * H, 2 * W), 2, 2, epilogue=lib.EPI_TANH_BWD, ep_aux=aux.to(d))
-    assert lib.last_kernel() == name, lib.last_kernel()
+    assert lib.last_kernel() == kname(True), lib.last_kernel()
     close(got, xb.grad * (1 - aux * aux), 2e-5)
 
 

@@ -1,5 +1,6 @@
-python -m pytest tests/test_gpu_ops.py -x -q -m gpu -k "sign" 2>&1 | tail -15
-for i in 1 2; do
-echo -n "signs on : "; python bench.py --no-cpu-baseline --no-other-configs 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], {k:v['avg_us'] for k,v in d['kernels'].items() if 'patch2' in k})"
-echo -n "signs off: "; CGS_NO_SIGN_MASKS=1 python bench.py --no-cpu-baseline --no-other-configs 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], {k:v['avg_us'] for k,v in d['kernels'].items() if 'patch2' in k})"
-done
+for i in 1 2 3; do
+for V in "CGS_NONE=1" "CGS_NO_SIGN_MASKS=1"; do
+echo -n "$V: "; env $V python bench.py --steps 40 --warmup 4 --no-cpu-baseline --no-other-configs 2>/dev/null | python -c "
+import sys,json
+d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['ms_per_step_median'])"
+done; done
