@@ -217,8 +217,8 @@ def test_a_wrong_lrelu_backward_slope_is_caught_on_every_seed(seed, monkeypatch)
         return dx
 
     def contraction(name):
-        def f(dy, w, in_hw, sh=2, sw=2, out=None, epilogue=L.EPI_NONE, ep_a=None, ep_aux=None):
-            dx = real[name](dy, w, in_hw, sh, sw, out=out, epilogue=epilogue, ep_a=ep_a, ep_aux=ep_aux)
+        def f(dy, w, in_hw, sh=2, sw=2, out=None, epilogue=L.EPI_NONE, ep_a=None, ep_aux=None, **kw):
+            dx = real[name](dy, w, in_hw, sh, sw, out=out, epilogue=epilogue, ep_a=ep_a, ep_aux=ep_aux, **kw)
             return spoil(dx, ep_aux) if epilogue == L.EPI_LRELU_BWD else dx
         return f
 

@@ -290,3 +290,51 @@ def test_bench_self_launches_its_ranks_as_child_processes(monkeypatch):
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
     assert cmd[-6:] == ["--gpus", "2", "--steps", "2", "--warmup", "1"] and cmd[-7].endswith("bench.py")
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_tf_checkpoint_converter_runs_against_the_checkpoint_reader_interface(tmp_path, monkeypatch):
+    """tools/tf_ckpt_to_safetensors.py (reference saver: nsgan/GAN.py:465-491) has no TensorFlow to run against in
+    this image.  Its own logic -- argument handling, reading every variable through the ``tf.train.load_checkpoint`` /
+    CheckpointReader interface (``get_variable_to_shape_map``, ``get_tensor``), TF-name cleaning (':0' suffixes, optimizer
+    slots, ``beta1_power``), validation against the arch, the .safetensors it writes -- executes here against a reader with
+    that interface over an in-memory dump laid out like a TF1 Saver checkpoint of the mnist net."""
+    import importlib.util
+    import sys
+    import types
+    from cgs_amd import checkpoint
+    from oracle import nets_ref as N
+    P = N.init_params("mnist", 2019, True)
+    dump = {k: v.numpy() for k, v in P.items()}
+    dump["discriminator/d_conv1/w/Adam"] = np.zeros_like(dump["discriminator/d_conv1/w"])       # optimizer slots the Saver also writes
+    dump["discriminator/d_conv1/w/Adam_1"] = np.zeros_like(dump["discriminator/d_conv1/w"])
+    dump["beta1_power"] = np.float32(0.5)
+    dump["beta2_power"] = np.float32(0.999)
+    seen = {}
+
+    class Reader:
+        def get_variable_to_shape_map(self):
+            return {k: list(np.shape(v)) for k, v in dump.items()}
+
+        def get_tensor(self, name):
+            return dump[name]
+
+    def load_checkpoint(path):
+        seen["path"] = path
+        return Reader()
+    tf = types.ModuleType("tensorflow")
+    tf.train = types.SimpleNamespace(load_checkpoint=load_checkpoint)
+    monkeypatch.setitem(sys.modules, "tensorflow", tf)
+    spec = importlib.util.spec_from_file_location("tf_ckpt_to_safetensors", os.path.join(ROOT, "tools", "tf_ckpt_to_safetensors.py"))
+    tool = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tool)
+    out = str(tmp_path / "mnist_5000.safetensors")
+    monkeypatch.setattr(sys, "argv", ["tf_ckpt_to_safetensors.py", "checkpoint/GAN_mnist_64_62/GAN/model-5000", out, "--arch", "mnist"])
+    tool.main()
+    assert seen["path"].endswith("model-5000")
+    loaded = checkpoint.load(out)
+    assert set(loaded) == set(P)                                         # slots and power accumulators dropped, every variable kept
+    for k, v in P.items():
+        assert torch.equal(torch.as_tensor(loaded[k]), v), k
+    monkeypatch.setattr(sys, "argv", ["tf_ckpt_to_safetensors.py", "x/model-1", out, "--arch", "dcgan32"])
+    with pytest.raises(KeyError):                                        # a checkpoint of another net is refused, not written
+        tool.main()
