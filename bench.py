@@ -53,7 +53,7 @@ HBM_OPS = {
 # 24 -> 26.1 k, 32 -> 26.3 k, 40 -> 27.1 k samples/s; dcgan32 4 -> 26.5 k, 6 -> 27.5 k, 8 -> 28.6 k): the tails and the per-launch
 # fixed costs of the ~13-27 GFLOP layers amortise over more rows
 FUSE = {"dcgan32": 8, "mnist": 32}
-THREE_CHANNEL = ("convt_rows_kernel", "conv_patch2_kernel", "conv_patch_kernel", "convt_quad")
+THREE_CHANNEL = ("convt_rows_kernel", "conv_patch2_kernel", "conv_patch_kernel", "convt_quad", "convt_taps_kernel", "conv_taps_kernel")
 
 
 def _traffic_table():

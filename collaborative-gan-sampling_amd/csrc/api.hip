@@ -60,6 +60,7 @@ static int choose_family(const CgsLayer& L, bool dirT, int B, int epilogue, bool
     if (!dirT && cgs_conv_smalln_f_ok(L, B, epilogue) && have_ws && ws_bytes >= cgs_conv_smalln_f_ws_floats(L) * sizeof(float) &&
         in_al && ws_al)
         return CGS_FAMILY_SMALLN_F;
+    if (!dirT && cgs_conv_taps_ok(L, epilogue)) return CGS_FAMILY_TAPS;                     // K = 16 taps: no packed weights, no alignment needs
     const bool patch_f = !dirT && cgs_conv_patch_ok(L, epilogue), patch_t = dirT && cgs_conv_patch_T_ok(L);
     if ((patch_f || patch_t) && have_ws && ws_bytes >= cgs_conv_patch_ws_floats(L, dirT) * sizeof(float) && ws_al && rest_al)
         return CGS_FAMILY_PATCH;
@@ -83,7 +84,7 @@ static int run_dir(const CgsLayer& L, bool dirT, int B, const float* in, const f
     const int fam = choose_family(L, dirT, B, epilogue, ws != nullptr, ws_bytes, !((uintptr_t)in & 15), !((uintptr_t)ws & 15), rest_al);
     if (stat_part && fam != CGS_FAMILY_IGEMM) return cgs_set_error(CGS_EINVAL, "%s: fused statistics are an implicit-GEMM feature (see cgs_conv_stat_partials)", who);
     if (sign_out && fam != CGS_FAMILY_IGEMM) return cgs_set_error(CGS_EINVAL, "%s: this call cannot leave a sign mask (see cgs_conv_signs_ok)", who);
-    if (aux_signs && fam != CGS_FAMILY_PATCH) return cgs_set_error(CGS_EINVAL, "%s: this call cannot take a sign mask (see cgs_conv_signs_ok)", who);
+    if (aux_signs && fam != CGS_FAMILY_PATCH && fam != CGS_FAMILY_TAPS) return cgs_set_error(CGS_EINVAL, "%s: this call cannot take a sign mask (see cgs_conv_signs_ok)", who);
     if (((uintptr_t)sign_out & 3) || ((uintptr_t)aux_signs & 3)) return cgs_set_error(CGS_EINVAL, "%s: sign mask must be 4-byte aligned", who);
     switch (fam) {
         case CGS_FAMILY_QUAD:
@@ -92,6 +93,8 @@ static int run_dir(const CgsLayer& L, bool dirT, int B, const float* in, const f
             return cgs_convt_smalln_launch(L, B, in, w, bias, out, epilogue, s);
         case CGS_FAMILY_SMALLN_F:
             return cgs_conv_smalln_f_launch(L, B, in, w, bias, out, epilogue, (float*)ws, ws_bytes, prepacked, s);
+        case CGS_FAMILY_TAPS:
+            return cgs_conv_taps_launch(L, B, in, w, bias, out, epilogue, ep_a, ep_b, ep_aux, aux_signs, s);
         case CGS_FAMILY_PATCH:
             return cgs_conv_patch_launch(L, dirT, B, in, w, bias, out, epilogue, ep_a, ep_b, ep_aux, (float*)ws, ws_bytes, prepacked, s, aux_signs);
         default: break;
@@ -266,7 +269,7 @@ int cgs_conv_signs_ok(int op, int B, int H, int W, int Cin, int Ho, int Wo, int 
     if (!deconv) { L.Hb = H; L.Wb = W; L.Cb = Cin; L.Hs = cgs_ceil_div(H, sh); L.Ws = cgs_ceil_div(W, sw); L.Cs = Cout; }
     else { L.Hs = H; L.Ws = W; L.Cs = Cin; L.Hb = Ho; L.Wb = Wo; L.Cb = Cout; }
     if (epilogue >= CGS_EPI_RELU_BWD_AFFINE)          // consumer: a backward-data whose epilogue applies relu' / lrelu'
-        return fam == CGS_FAMILY_PATCH && cgs_conv_patch_signs_ok(L, dirT, epilogue);
+        return (fam == CGS_FAMILY_PATCH && cgs_conv_patch_signs_ok(L, dirT, epilogue)) || (fam == CGS_FAMILY_TAPS && cgs_conv_taps_signs_ok(L, epilogue));
     if (fam != CGS_FAMILY_IGEMM || (dirT && (sh > 2 || sw > 2))) return 0;        // producer: a forward with the relu / lrelu epilogue
     IgemmParams p;
     p.B = B; p.stat_part = nullptr; p.sign_out = nullptr; p.sign_plane = 0; p.epilogue = epilogue;

@@ -102,6 +102,13 @@ int cgs_pack_weights(const IgemmParams& p, const CgsLayer& L, bool dirT, const f
 int cgs_igemm_launch(const IgemmParams& p, void* slab, size_t slab_bytes, hipStream_t s);
 size_t cgs_igemm_splitk_bytes(const IgemmParams& p);   // slab bytes the launch would like (0 = no split-K)
 size_t cgs_convt_quad_ws_floats_bound(int kh, int kw, int Cs);
+int cgs_convt_taps_ok(const CgsLayer& L);          // 4x4 stride-2 transposed conv to one channel: all 16 taps as MFMA columns (convt_taps.hip)
+int cgs_convt_taps_launch(const CgsLayer& L, int B, const float* in, const float* w, const float* bias, float* out, int epilogue,
+                          const float* ep_a, const float* ep_aux, hipStream_t s);
+int cgs_conv_taps_ok(const CgsLayer& L, int epilogue);      // its forward twin: 4x4 stride-2 conv FROM one channel (K = 16)
+int cgs_conv_taps_signs_ok(const CgsLayer& L, int epilogue);
+int cgs_conv_taps_launch(const CgsLayer& L, int B, const float* in, const float* w, const float* bias, float* out, int epilogue,
+                         const float* ep_a, const float* ep_b, const float* ep_aux, const unsigned* aux_signs, hipStream_t s);
 int cgs_convt_quad_launch(const CgsLayer& L, int B, const float* in, const float* w, const float* bias, float* out,
                           int epilogue, const float* ep_a, const float* ep_aux, float* ws, size_t ws_bytes, int prepacked,
                           hipStream_t s);

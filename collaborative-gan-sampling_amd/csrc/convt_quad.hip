@@ -638,6 +638,11 @@ int cgs_convt_quad_launch(const CgsLayer& L, int B, const float* in, const float
     quad_range(L.kw, pl, p.dmin_x, hx);
     p.ny = hy - p.dmin_y + 1; p.nx = hx - p.dmin_x + 1;
     if ((long)B * L.Hs * L.Ws * L.Cs * 4 > 0x7fffffffL) return cgs_set_error(CGS_EINVAL, "convt_quad: input exceeds 2 GiB (split the batch)");
+#ifdef CGS_EXPERIMENT
+    if (cgs_convt_taps_ok(L) && !getenv("CGS_NO_TAPS")) return cgs_convt_taps_launch(L, B, in, w, bias, out, epilogue, ep_a, ep_aux, s);
+#else
+    if (cgs_convt_taps_ok(L)) return cgs_convt_taps_launch(L, B, in, w, bias, out, epilogue, ep_a, ep_aux, s);      // (reads the unpacked weights)
+#endif
     if (const int mt = rows_mt(L)) {
         RowsParams r;
         r.in = in; r.wp = ws; r.bias = bias; r.out = out; r.ep_a = ep_a; r.ep_aux = ep_aux;

@@ -1108,14 +1108,28 @@ int cgs_igemm_launch(const IgemmParams& p_in, void* slab, size_t slab_bytes, hip
     // pipe's gaps; the epilogue stages half a wave tile at a time to fit) win 2.5-9 % when every parity class brings at
     // least two blocks per CU, and lose up to 11 % on smaller grids, where a CU holds one block and the doubled barrier
     // count per FLOP is all that is left of the change (measured per layer, 40 launches each, dcgan64 / dcgan32 / config 5).
+    // Mid-size grids (round 3, measured per layer on config 5's PatchGAN / up-sampling layers at batch 8, tools/ab_tmp.sh): a launch
+    // of 256..511 blocks of 128x128 leaves half of the 512 block slots of the 32-deep form empty (one block per CU: nobody hides
+    // its barrier and load latencies) -- as 128x64 blocks it fills them: 64x64 128<-256 85 -> 75 us, 128x128 64->128 88 -> 77 us,
+    // 32x32 256->512 302 -> 265 us (not for grids < 256 blocks, which are split over K instead: 32x32 256<-512 272 -> 295 us)
+    // (with the 32-deep K tiles: the same grids as 16-deep 128x64 blocks measured 93 / 329 us for the last two)
+    bool mid = false;
+    if (wide && vec && p.splitk == 1) {
+        const long wb = igemm_blocks(p, 128);
+        if (wb >= 256 && wb < 512) { wide = false; mid = true; }
+    }
     bool deep = true;
-    if (vec && p.splitk == 1) {
-        long min_blocks = 1L << 40;
+    if (vec && p.splitk == 1 && !mid) {
+        long min_blocks = 1L << 40, tot_blocks = 0;
         for (int i = 0; i < p.nclasses; ++i) {
             const long m = (long)p.B * p.cls[i].R * p.cls[i].C;
-            if (m > 0) { const long bl = (m + 127) / 128 * (p.Np / (wide ? 128 : 64)); if (bl < min_blocks) min_blocks = bl; }
+            if (m > 0) { const long bl = (m + 127) / 128 * (p.Np / (wide ? 128 : 64)); if (bl < min_blocks) min_blocks = bl; tot_blocks += bl; }
         }
         deep = min_blocks < 512;        // (thresholds 256 / 512 / 1024 measured: 512 is best on dcgan64 and neutral elsewhere)
+        // ... except image-major launches whose classes TOGETHER fill the 1024 slots of the 16-deep form with even tiles (the four
+        // parity classes of config 5's transposed layers, 256 blocks each: 128x128 64<-128 102 -> 86 us, 64x64 256->128 164 -> 152 us);
+        // the pixel-major 8x8 256<-512 layer of dcgan64 (1024 very uneven blocks) stays 32-deep: 0.61 vs 0.74 ms
+        if (deep && !p.pix_major && p.nclasses > 1 && tot_blocks >= 1024) deep = false;
     }
     {
         // Launches whose blocks are all resident at once (one "round": <= 4 blocks per CU with the 16-deep tiles, 2 with the

@@ -163,7 +163,12 @@ def test_deconv2d_bwd_data(B, H, W, Cin, Ho, Wo, Cout, k, s):
     (5, 10, 16, 64, 3, 5, "convt_rows_kernel<3, 1, true, 4|2, %s>"),       # the tall form with a ragged last task (10 row pairs = 4 + 4 + 2)
     (3, 6, 32, 64, 3, 5, "convt_rows_kernel<3, 2, true, 2|2, %s>"),        # fewer than 8 input rows: two row pairs per task
     (300, 16, 16, 32, 3, 5, "convt_rows_kernel<3, 1, false, 2|2, %s>"),    # dcgan32; 4800 row pairs over 512 persistent blocks
-    (5, 14, 14, 64, 1, 4, "convt_rows_kernel<1, 1, false, 2|2, %s>"),      # mnist g_dc4 (4x4 kernel, one channel, 14 of 16 pixels per tile)
+    (5, 14, 14, 64, 1, 4, "convt_taps_kernel<4>"),                         # mnist g_dc4 / d_conv1 backward-data (4x4 kernel, one channel): all 16 taps as MFMA columns
+    (700, 14, 14, 64, 1, 4, "convt_taps_kernel<4>"),                       # enough images for whole-image tasks; several tasks per wave
+    (3, 7, 16, 32, 1, 4, "convt_taps_kernel<2>"),                          # 16-pixel rows, a ragged last row block
+    (2, 5, 9, 16, 1, 4, "convt_taps_kernel<1>"),                           # one 16-channel chunk, odd sizes
+    (2, 6, 12, 128, 1, 4, "convt_taps_kernel<8>"),                         # eight chunks
+    (5, 14, 14, 48, 1, 4, "convt_rows_kernel<1, 1, false, 2|2, %s>"),      # a channel count the taps form does not take: rows form (14 of 16 pixels per tile)
     (3, 20, 12, 32, 3, 5, "convt_rows_kernel<3, 1, false, 2|2, %s>"),      # ragged width, non-square
     (2, 9, 24, 16, 3, 3, "convt_rows_kernel<3, 2, false, 2|2, %s>"),       # 3x3 kernel, 24 of 32 pixels
     (2, 7, 24, 16, 1, 5, "convt_rows_kernel<1, 2, false, 2|2, %s>"),       # one channel, odd number of row pairs
@@ -580,3 +585,42 @@ def test_engine_uses_sign_masks_and_matches_the_fp32_aux_path(monkeypatch):
     want = ref.refine_from_z(z, Ks, 0.1)
     for a, b in zip(got, want):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("B,H,W,N", [(5, 28, 28, 64), (3, 27, 13, 32), (2, 10, 18, 96), (67, 14, 14, 128), (1, 2, 2, 64)])
+def test_taps_form_of_the_4x4_conv_from_one_channel(B, H, W, N):
+    """conv_taps_kernel (K = 16 taps on the 32x32x2 MFMA, no packed weights): forward with every forward epilogue, and as the
+    backward-data of a 4x4 stride-2 deconv TO one channel with relu' / lrelu' / tanh' taken from the fp32 aux tensor and -- where
+    a sign suffices -- from the sign mask, bit-equal to the aux form.  Odd sizes, a ragged last 32-pixel tile, 1..4 column tiles."""
+    from cgs_amd import kernels as K, lib
+    d = dev()
+    x, w, b = rnd((B, H, W, 1), 1), rnd((4, 4, 1, N), 2, 0.2), rnd((N,), 3, 0.1)
+    a, c = rnd((N,), 4).abs() + 0.5, rnd((N,), 5, 0.1)
+    lin = R.conv2d(x, w, b, 2, 2)
+    Hs, Ws = lin.shape[1], lin.shape[2]
+    for epi, want in ((lib.EPI_NONE, lin), (lib.EPI_LRELU, R.lrelu(lin)), (lib.EPI_AFFINE_RELU, torch.relu(a * lin + c)), (lib.EPI_TANH, torch.tanh(lin))):
+        got = K.conv2d_fwd(x.to(d), w.to(d), b.to(d), 2, 2, epi, a.to(d) if epi == lib.EPI_AFFINE_RELU else None,
+                           c.to(d) if epi == lib.EPI_AFFINE_RELU else None)
+        assert lib.last_kernel() == f"conv_taps_kernel<{N // 32}, 0>", lib.last_kernel()
+        close(got, want, 2e-5)
+    # deconv [4,4,Cout=1,Cin=N]: backward-data dy [B,H,W,1] -> dx [B,Hs,Ws,N] (needs H == 2 Hs: the even-size cases)
+    if H % 2 == 0 and W % 2 == 0:
+        wd = rnd((4, 4, 1, N), 6, 0.2)
+        xs = rnd((B, Hs, Ws, N), 7).requires_grad_(True)
+        dy = rnd((B, H, W, 1), 8)
+        (R.deconv2d(xs, wd, torch.zeros(1), (B, H, W, 1), 2, 2) * dy).sum().backward()
+        aux = rnd((B, Hs, Ws, N), 9)
+        aux[aux.abs() < 0.3] = 0.0
+        for e, want in ((lib.EPI_NONE, xs.grad), (lib.EPI_RELU_BWD_AFFINE, xs.grad * a * (aux > 0)),
+                        (lib.EPI_LRELU_BWD, xs.grad * torch.where(aux > 0, 1.0, 0.2)), (lib.EPI_TANH_BWD, xs.grad * (1 - aux * aux))):
+            got = K.deconv2d_bwd_data(dy.to(d), wd.to(d), (Hs, Ws), 2, 2, epilogue=e, ep_a=a.to(d) if e == lib.EPI_RELU_BWD_AFFINE else None,
+                                      ep_aux=aux.to(d) if e != lib.EPI_NONE else None)
+            assert lib.last_kernel() == f"conv_taps_kernel<{N // 32}, {0 if e == lib.EPI_NONE else 1}>", lib.last_kernel()
+            close(got, want, 2e-5)
+            if e in (lib.EPI_RELU_BWD_AFFINE, lib.EPI_LRELU_BWD):
+                assert K.conv_signs_ok(lib.DECONV_BWD_DATA, B, Hs, Ws, N, H, W, 1, 4, 4, 2, 2, e)
+                signs = torch.from_numpy(pack_signs((aux > 0).numpy().reshape(-1, N))).to(d)
+                got2 = K.deconv2d_bwd_data(dy.to(d), wd.to(d), (Hs, Ws), 2, 2, epilogue=e, ep_a=a.to(d) if e == lib.EPI_RELU_BWD_AFFINE else None,
+                                           ep_signs=signs)
+                assert lib.last_kernel() == f"conv_taps_kernel<{N // 32}, 2>", lib.last_kernel()
+                assert torch.equal(got2, got)
