@@ -61,6 +61,7 @@ static int choose_family(const CgsLayer& L, bool dirT, int B, int epilogue, bool
         in_al && ws_al)
         return CGS_FAMILY_SMALLN_F;
     if (!dirT && cgs_conv_taps_ok(L, epilogue)) return CGS_FAMILY_TAPS;                     // K = 16 taps: no packed weights, no alignment needs
+    if (!dirT && cgs_conv_dot_ok(L, epilogue) && in_al) return CGS_FAMILY_DOT;             // (after the stride-1 VALU head kernel, which serves the large grids)
     const bool patch_f = !dirT && cgs_conv_patch_ok(L, epilogue), patch_t = dirT && cgs_conv_patch_T_ok(L);
     if ((patch_f || patch_t) && have_ws && ws_bytes >= cgs_conv_patch_ws_floats(L, dirT) * sizeof(float) && ws_al && rest_al)
         return CGS_FAMILY_PATCH;
@@ -93,6 +94,8 @@ static int run_dir(const CgsLayer& L, bool dirT, int B, const float* in, const f
             return cgs_convt_smalln_launch(L, B, in, w, bias, out, epilogue, s);
         case CGS_FAMILY_SMALLN_F:
             return cgs_conv_smalln_f_launch(L, B, in, w, bias, out, epilogue, (float*)ws, ws_bytes, prepacked, s);
+        case CGS_FAMILY_DOT:
+            return cgs_conv_dot_launch(L, B, in, w, bias, out, epilogue, ep_a, ep_b, s);
         case CGS_FAMILY_TAPS:
             return cgs_conv_taps_launch(L, B, in, w, bias, out, epilogue, ep_a, ep_b, ep_aux, aux_signs, s);
         case CGS_FAMILY_PATCH:

@@ -105,6 +105,9 @@ size_t cgs_convt_quad_ws_floats_bound(int kh, int kw, int Cs);
 int cgs_convt_taps_ok(const CgsLayer& L);          // 4x4 stride-2 transposed conv to one channel: all 16 taps as MFMA columns (convt_taps.hip)
 int cgs_convt_taps_launch(const CgsLayer& L, int B, const float* in, const float* w, const float* bias, float* out, int epilogue,
                           const float* ep_a, const float* ep_aux, hipStream_t s);
+int cgs_conv_dot_ok(const CgsLayer& L, int epilogue);       // forward conv to <= 4 channels over a deep reduction: a wave per output pixel (conv_dot.hip)
+int cgs_conv_dot_launch(const CgsLayer& L, int B, const float* in, const float* w, const float* bias, float* out, int epilogue,
+                        const float* ep_a, const float* ep_b, hipStream_t s);
 int cgs_conv_taps_ok(const CgsLayer& L, int epilogue);      // its forward twin: 4x4 stride-2 conv FROM one channel (K = 16)
 int cgs_conv_taps_signs_ok(const CgsLayer& L, int epilogue);
 int cgs_conv_taps_launch(const CgsLayer& L, int B, const float* in, const float* w, const float* bias, float* out, int epilogue,

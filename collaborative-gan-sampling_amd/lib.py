@@ -13,7 +13,7 @@ OK, EINVAL, EWORKSPACE, ELAUNCH = 0, -1, -2, -3
 EPI_NONE, EPI_LRELU, EPI_AFFINE_RELU, EPI_TANH = 0, 1, 2, 3
 EPI_RELU_BWD_AFFINE, EPI_LRELU_BWD, EPI_TANH_BWD = 4, 5, 6
 CONV_FWD, CONV_BWD_DATA, DECONV_FWD, DECONV_BWD_DATA = 0, 1, 2, 3
-FAMILY_IGEMM, FAMILY_QUAD, FAMILY_SMALLN_T, FAMILY_SMALLN_F, FAMILY_PATCH, FAMILY_TAPS = 0, 1, 2, 3, 4, 5
+FAMILY_IGEMM, FAMILY_QUAD, FAMILY_SMALLN_T, FAMILY_SMALLN_F, FAMILY_PATCH, FAMILY_TAPS, FAMILY_DOT = 0, 1, 2, 3, 4, 5, 6
 
 _p, _i, _f, _z = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 _ll = C.c_longlong

@@ -83,6 +83,7 @@ size_t cgs_conv_ws_bytes_for(int op, int B, int H, int W, int Cin, int Cout, int
 #define CGS_FAMILY_SMALLN_F 3   /* stride-1 forward conv with <= 4 output channels (conv_smalln_f.hip)    */
 #define CGS_FAMILY_PATCH 4      /* 3-channel strided / stem convs from an LDS patch (conv_patch.hip)      */
 #define CGS_FAMILY_TAPS 5       /* 4x4 stride-2 conv from ONE channel, K = 16 taps (convt_taps.hip); reads the weights unpacked */
+#define CGS_FAMILY_DOT 6        /* forward conv to <= 4 channels over a deep reduction (conv_dot.hip); weights unpacked         */
 int cgs_conv_family(int op, int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int sh, int sw,
                     int epilogue, size_t ws_bytes);
 

@@ -624,3 +624,21 @@ def test_taps_form_of_the_4x4_conv_from_one_channel(B, H, W, N):
                                            ep_signs=signs)
                 assert lib.last_kernel() == f"conv_taps_kernel<{N // 32}, 2>", lib.last_kernel()
                 assert torch.equal(got2, got)
+
+
+@pytest.mark.parametrize("B,H,W,Cin,N,k,s", [(8, 32, 32, 512, 1, 4, 1), (3, 9, 7, 128, 1, 3, 1), (2, 8, 8, 64, 3, 5, 2), (2, 6, 6, 256, 4, 3, 1),
+                                             (1, 5, 5, 68, 2, 4, 1)])
+def test_deep_reduction_small_n_conv(B, H, W, Cin, N, k, s):
+    """conv_dot_kernel (a wave per output pixel; the PatchGAN logit head 4x4 x 512 -> 1 of config 5): forward with the forward
+    epilogues, odd sizes, stride 2, 1..4 output channels, a channel count that is not a multiple of 256."""
+    from cgs_amd import kernels as K, lib
+    d = dev()
+    x, w, b = rnd((B, H, W, Cin), 1), rnd((k, k, Cin, N), 2, 0.05), rnd((N,), 3, 0.1)
+    lin = R.conv2d(x, w, b, s, s)
+    for epi, want in ((lib.EPI_NONE, lin), (lib.EPI_LRELU, R.lrelu(lin)), (lib.EPI_TANH, torch.tanh(lin))):
+        got = K.conv2d_fwd(x.to(d), w.to(d), b.to(d), s, s, epi)
+        assert lib.last_kernel() == f"conv_dot_kernel<{N}>", lib.last_kernel()
+        # (tanh has slope 1 at 0: its output carries the ABSOLUTE error of the pre-activation, 2e-5 of max|lin| over a K <= 8192 reduction)
+        close(got, want, 2e-5 * (max(1.0, lin.abs().max().item()) if epi == lib.EPI_TANH else 1.0))
+    got = K.conv2d_fwd(x.to(d), w.to(d), None, s, s)
+    close(got, R.conv2d(x, w, torch.zeros(N), s, s), 2e-5)
