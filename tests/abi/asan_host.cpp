@@ -20,6 +20,7 @@ int main() {
         {1024, 64, 3, 64, 5, 2}, {1024, 32, 64, 128, 5, 2}, {1024, 16, 128, 256, 5, 2}, {1024, 8, 256, 512, 5, 2},   // dcgan64 D
         {256, 32, 3, 64, 5, 2}, {256, 4, 256, 512, 5, 2}, {64, 28, 1, 64, 4, 2}, {64, 14, 64, 128, 4, 2},              // dcgan32, mnist
         {8, 256, 3, 64, 7, 1}, {8, 64, 256, 256, 3, 1}, {8, 32, 512, 1, 4, 1}, {8, 256, 64, 3, 7, 1},                  // cyclegan256
+        {2048, 28, 1, 64, 4, 2}, {3, 27, 1, 96, 4, 2}, {8, 32, 512, 4, 4, 1}, {2, 8, 64, 3, 5, 2},                      // taps / deep-dot forms
         {1, 1, 32, 64, 1, 1}, {130, 9, 96, 40, 3, 2}, {5, 6, 32, 64, 3, 2}, {2048, 8, 64, 64, 5, 2}, {3, 17, 5, 7, 5, 2}};
     for (auto& c : convs) {
         const int Ho = (c.H + c.s - 1) / c.s;
@@ -36,6 +37,14 @@ int main() {
                                         op >= CGS_DECONV_FWD ? c.Cin : c.Cout, c.k, c.k, c.s, c.s);
             (void)cgs_conv_family(op, c.B, op >= CGS_DECONV_FWD ? Ho : c.H, op >= CGS_DECONV_FWD ? Ho : c.H, op >= CGS_DECONV_FWD ? c.Cout : c.Cin, c.H, c.H,
                                   op >= CGS_DECONV_FWD ? c.Cin : c.Cout, c.k, c.k, c.s, c.s, CGS_EPI_NONE, WS);
+        }
+        // sign masks: the query for both roles, and the two entry points (refused with CGS_EINVAL where the query says no)
+        for (int epi : {CGS_EPI_LRELU, CGS_EPI_AFFINE_RELU})
+            if (cgs_conv_signs_ok(CGS_DECONV_FWD, c.B, Ho, Ho, c.Cout, c.H, c.H, c.Cin, c.k, c.k, c.s, c.s, epi, WS) || c.B == 130)
+                expect(cgs_deconv2d_nhwc_fwd_signs(P, P, P, P, c.B, Ho, Ho, c.Cout, c.H, c.H, c.Cin, c.k, c.k, c.s, c.s, epi, P, P, (unsigned*)P, P, WS, 0, nullptr), "deconv fwd signs");
+        for (int epi : {CGS_EPI_RELU_BWD_AFFINE, CGS_EPI_LRELU_BWD, CGS_EPI_TANH_BWD}) {
+            (void)cgs_conv_signs_ok(CGS_DECONV_BWD_DATA, c.B, Ho, Ho, c.Cout, c.H, c.H, c.Cin, c.k, c.k, c.s, c.s, epi, WS);
+            expect(cgs_deconv2d_nhwc_bwd_data_signs(P, P, P, c.B, Ho, Ho, c.Cout, c.H, c.H, c.Cin, c.k, c.k, c.s, c.s, epi, P, (const unsigned*)P, P, WS, 0, nullptr), "deconv bwd signs");
         }
         const int G = cgs_conv_stat_partials(c.B, c.H, c.H, c.Cin, c.Cout, c.k, c.k, c.s, c.s, WS);
         expect(cgs_conv2d_nhwc_fwd_stats(P, P, P, P, c.B, c.H, c.H, c.Cin, c.Cout, c.k, c.k, c.s, c.s, P, WS, 0, P, (size_t)(G > 0 ? G : 1) * 2 * c.Cout * 4, nullptr), "conv fwd stats");

@@ -12,7 +12,16 @@ from conftest import ROOT
 
 HIPCC = "/opt/rocm/bin/hipcc"
 CSRC = os.path.join(ROOT, "collaborative-gan-sampling_amd", "csrc")
-SOURCES = ["api", "igemm", "convt_smalln", "convt_quad", "conv_patch", "conv_smalln_f", "wgrad", "mlp2d", "bn", "elementwise"]
+
+
+def _sources():
+    """The library's sources, from its own Makefile (SRC := a.hip b.hip ...)."""
+    with open(os.path.join(CSRC, "Makefile")) as f:
+        line = next(l for l in f if l.startswith("SRC :="))
+    return [s[:-4] for s in line.split(":=")[1].split()]
+
+
+SOURCES = _sources()
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs hipcc")
