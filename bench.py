@@ -283,7 +283,7 @@ def other_configs(dev, skip, want_cpu):
         out[arch]["roofline"] = roof
         out[arch]["hbm"] = {k: {f: v[f] for f in ("avg_us", "achieved", "frac", "share_of_step")} for k, v in hbm.items()}
         if want_cpu:
-            out[arch]["cpu_baseline"] = cpu_baseline(arch, Ksteps, 0.1, seconds=4.0, max_batch=128)
+            out[arch]["cpu_baseline"] = cpu_baseline(arch, Ksteps, 0.1, seconds=4.0, max_batch=1024)
         del z, P
         torch.cuda.empty_cache()
     if skip != "synthetic2d":
