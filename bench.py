@@ -414,6 +414,11 @@ def main():
             with torch.cuda.stream(st):
                 e.refine_from_z(z[0], Ksteps, args.rate)
         torch.cuda.synchronize(dev)
+    if os.environ.get("CGS_BENCH_BREAK_CAPTURE") and args.graph:     # test hook: the first hipGraph capture fails (exercises the fallback below)
+        class _Refused:
+            def __init__(self, *a, **k):
+                raise RuntimeError("hipGraph capture refused (CGS_BENCH_BREAK_CAPTURE test hook)")
+        torch.cuda.graph = _Refused
     engines = build_engines(args.graph)
     try:
         prepare(engines)

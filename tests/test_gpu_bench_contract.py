@@ -51,6 +51,21 @@ def test_bench_line_small_config():
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
 
 
+def test_a_failed_graph_capture_falls_back_to_eager_launches_in_the_same_process():
+    """The default is hipGraph replay at every world size; if the capture raises (here: a test hook refuses it) the run must go on
+    with eager launches in the SAME process and say so in the line -- and with an explicit --graph the failure is an error."""
+    env = dict(os.environ, CGS_BENCH_BREAK_CAPTURE="1")
+    args = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--arch", "mnist", "--steps", "2", "--warmup", "1", "--refine-steps", "3",
+            "--no-cpu-baseline", "--no-other-configs"]
+    out = subprocess.run(args, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert d["value"] > 0 and d["config"]["hipgraph"] is False and "capture refused" in d["config"]["hipgraph_fallback"]
+    assert "launching eagerly instead" in out.stderr
+    out = subprocess.run(args + ["--graph"], cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode != 0 and "capture refused" in out.stderr
+
+
 def test_bench_synthetic2d_line():
     d = run_bench("--arch", "synthetic2d", "--steps", "3", "--warmup", "1")
     for k in REQUIRED:
