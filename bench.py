@@ -48,6 +48,8 @@ HBM_OPS = {
     "bn_train_lrelu_fwd_from_partials": ["bn_slice_sums_kernel", "bn_finalize_slices_kernel", "bn_apply_fwd_kernel"],
     "bn_train_lrelu_bwd_data": ["bn_partial_kernel<1>", "bn_finalize_kernel<1>", "bn_restat_kernel", "bn_apply_bwd_kernel"],
     "refine_update": ["refine_update_kernel"],
+    "linear_out1_fwd": ["linear_out1_fwd_kernel"],
+    "linear_out1_bwd": ["linear_out1_bwd_kernel"],
 }
 # logical batches fused per launch by default (tools/sweep_fuse.sh on MI355X, two launches in flight: mnist 16 -> 24.3 k,
 # 24 -> 26.1 k, 32 -> 26.3 k, 40 -> 27.1 k samples/s; dcgan32 4 -> 26.5 k, 6 -> 27.5 k, 8 -> 28.6 k): the tails and the per-launch

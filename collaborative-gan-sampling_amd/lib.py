@@ -91,6 +91,11 @@ def load():
     """Load libcgs_hip.so (once) and type its entry points.  Raises if it is absent."""
     global _lib
     if _lib is None:
+        # PyTorch hands this library its device pointers and HIP streams, so both must live on ONE HIP runtime instance: torch's
+        # wheel bundles its own libamdhip64, and whichever copy is mapped first serves the SONAME for the whole process.  Loading
+        # this library before torch would bind it (and then torch) to the system runtime: "no ROCm-capable device" at the first
+        # launch (seen with `python __graft_entry__.py smoke`, which builds / loads before it imports torch).
+        import torch  # noqa: F401
         if not os.path.exists(LIB_PATH):
             raise CgsError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(there is no CPU fallback for the device path)")
