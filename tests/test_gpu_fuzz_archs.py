@@ -146,6 +146,9 @@ def kink_flips(name, P, f0_ref, eng, fwd_tol=1e-4):
     return small, large
 
 
+LAST = {"degenerate": False}      # set by run_topology: the oracle's gradient of the last topology was identically zero
+
+
 def run_topology(seed, use_graph):
     from cgs_amd import nets
     from cgs_amd.engine import RefineEngine
@@ -169,7 +172,8 @@ def run_topology(seed, use_graph):
         close(lm, lm_o, 2e-4, "mean logit")
         g, go = grad.cpu().double(), grad_o.double()
         keep = torch.ones(B, dtype=torch.bool)       # samples whose refinement is compared below (all but the kink-excused ones)
-        if go.abs().max().item() < 1e-12:          # degenerate draw (e.g. instance norm over a 1x1 map): the gradient is exactly 0
+        LAST["degenerate"] = go.abs().max().item() < 1e-12
+        if LAST["degenerate"]:                     # degenerate draw (e.g. instance norm over a 1x1 map): the gradient is exactly 0
             assert g.abs().max().item() < 1e-6, f"grad should vanish, max {g.abs().max().item():.3e}"
         else:
             # per sample: the bulk of the entries within 2e-3 of max|grad| and none off by 30 % ...
@@ -227,5 +231,10 @@ def test_a_wrong_lrelu_backward_slope_is_caught_on_every_seed(seed, monkeypatch)
     monkeypatch.setattr(K, "conv2d_bwd_data", contraction("conv2d_bwd_data"))
     monkeypatch.setattr(K, "deconv2d_bwd_data", contraction("deconv2d_bwd_data"))
     monkeypatch.setattr(K, "lrelu_bwd", lrelu_bwd)
-    with pytest.raises(AssertionError):
+    try:
         run_topology(seed, False)
+    except AssertionError:
+        return                                   # caught
+    if LAST["degenerate"]:
+        pytest.skip("this topology's gradient is identically zero (an instance norm over a 1x1 map): no slope can show in it")
+    pytest.fail("the spoiled lrelu gradient passed the topology check")
