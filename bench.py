@@ -55,6 +55,10 @@ HBM_OPS = {
 # 24 -> 26.1 k, 32 -> 26.3 k, 40 -> 27.1 k samples/s; dcgan32 4 -> 26.5 k, 6 -> 27.5 k, 8 -> 28.6 k): the tails and the per-launch
 # fixed costs of the ~13-27 GFLOP layers amortise over more rows
 FUSE = {"dcgan32": 8, "mnist": 32}
+# engine calls in flight per GPU (one engine + HIP stream each).  dcgan64's 700-us launches: 1 -> 6258, 2 -> 6640..6720, 3 -> +0.5 %,
+# 4 -> -0.7 % (round 2).  The small configurations' short launches gain from more (round 3, same session: cyclegan256 2 -> 155.3,
+# 3 -> 163.8, 4 -> 166.5, 6 -> 164.2 samples/s; mnist 28.1 / 29.4 / 29.8 / 29.1 k; dcgan32 28.7 / 29.4 / 29.6 / 29.1 k)
+IN_FLIGHT = {"dcgan64": 2, "dcgan32": 4, "mnist": 4, "cyclegan256": 4}
 THREE_CHANNEL = ("convt_rows_kernel", "conv_patch2_kernel", "conv_patch_kernel", "convt_quad", "convt_taps_kernel", "conv_taps_kernel")
 
 
@@ -256,27 +260,29 @@ def other_configs(dev, skip, want_cpu):
     from cgs_amd import nets
     from cgs_amd.engine import RefineEngine
     out = {}
-    for arch, B, Ksteps, G, steps in (("mnist", 64, 50, FUSE["mnist"], 6), ("dcgan32", 256, 20, FUSE["dcgan32"], 6)):
+    for arch, B, Ksteps, G, steps in (("mnist", 64, 50, FUSE["mnist"], 8), ("dcgan32", 256, 20, FUSE["dcgan32"], 8)):
         if arch == skip:
             continue
         A = nets.ARCHS[arch]
         P = nets.init_params(arch, dev, seed=2019)
-        engines = [RefineEngine(arch, P, B * G, dev, use_graph=True, bn_groups=G) for _ in range(2)]
+        nf = IN_FLIGHT[arch]
+        engines = [RefineEngine(arch, P, B * G, dev, use_graph=True, bn_groups=G) for _ in range(nf)]
         streams = [torch.cuda.Stream(dev) for _ in engines]
-        z = torch.from_numpy(np.random.RandomState(2019).uniform(-1, 1, (steps + 2, B * G) + nets.g_input_shape(A)).astype(np.float32)).to(dev)
+        z = torch.from_numpy(np.random.RandomState(2019).uniform(-1, 1, (steps + nf, B * G) + nets.g_input_shape(A)).astype(np.float32)).to(dev)
 
         def step(i):
-            with torch.cuda.stream(streams[i % 2]):
-                engines[i % 2].refine_from_z(z[i], Ksteps, 0.1)
-        step(0); step(1)
+            with torch.cuda.stream(streams[i % nf]):
+                engines[i % nf].refine_from_z(z[i], Ksteps, 0.1)
+        for i in range(nf):
+            step(i)
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
-        for i in range(2, steps + 2):
+        for i in range(nf, steps + nf):
             step(i)
         torch.cuda.synchronize(dev)
         dt = time.perf_counter() - t0
         out[arch] = {"samples_per_s": round(B * G * steps / dt, 1), "batch": B, "refine_steps": Ksteps, "fused_per_launch": G,
-                     "batches_in_flight": 2 * G, "steps": steps, "hipgraph": True,
+                     "batches_in_flight": nf * G, "steps": steps, "hipgraph": True,
                      "algorithmic_tflops": round(B * G * steps / dt * nets.refine_flops_per_sample(arch, Ksteps) / 1e12, 2)}
         del engines
         prof, prof_ms = profile_one_step(arch, P, B, G, Ksteps, 0.1, z[0], dev, streams[0])
@@ -327,8 +333,8 @@ def main():
                          "(config.hipgraph false + config.hipgraph_fallback); with --graph given explicitly a failed capture is an error")
     ap.add_argument("--no-graph", dest="graph", action="store_false", help="launch every kernel eagerly")
     ap.add_argument("--streams", type=int, default=0,
-                    help="(default 2; 8 for synthetic2d) z-batches in flight per GPU, one engine + HIP stream each: the tail / small kernels of one "
-                         "batch overlap the big kernels of the other (measured: 1 -> 5040, 2 -> 5500, 3 -> 5460 samples/s)")
+                    help="(default: dcgan64 2, the other nets 4, synthetic2d 8) engine calls in flight per GPU, one engine + HIP stream each: the tail "
+                         "/ small kernels of one batch overlap the big kernels of the other (IN_FLIGHT above holds the measurements)")
     ap.add_argument("--fuse", type=int, default=0,
                     help="logical batches fused into one engine batch (conv launches G times larger, batch-norm statistics kept "
                          "per logical batch).  Default: dcgan64 1, dcgan32 8, mnist 32 (~2048 samples per launch; measured sweep in DESIGN.md 6)")
@@ -394,7 +400,7 @@ def main():
         # proxy / watchdog threads may make HIP calls meanwhile); eager only with synchronised batch norm, which has a
         # collective inside the program
         args.graph = not args.sync_bn
-    n_flight = args.streams if args.streams > 0 else 2
+    n_flight = args.streams if args.streams > 0 else IN_FLIGHT.get(args.arch, 2)
     sync = True if args.sync_bn else None
 
     def build_engines(use_graph):
@@ -437,7 +443,6 @@ def main():
         del engines
         engines = build_engines(False)
         prepare(engines)
-    eng = engines[0]
 
     done_ev, gather_ev = [], []                                         # per timed step: completion event; (before, after) the gather
 

@@ -103,15 +103,16 @@ def test_full_size_refinement_matches_the_oracle(arch, B, K, G):
 
 @pytest.mark.parametrize("arch,B,K,G", BENCHED, ids=[case_id(c) + "-hipgraph-2streams" for c in BENCHED])
 def test_the_benched_mode_matches_the_oracle(arch, B, K, G):
-    """What `python bench.py` times: two RefineEngine(use_graph=True) on two HIP streams, both batches in flight, the K-step
-    program REPLAYED (first call captures, second and third replay) -- at the configuration's full batch and K, each engine's
+    """What `python bench.py` times: bench.IN_FLIGHT RefineEngine(use_graph=True) (2 for dcgan64, 4 for the small nets), one HIP stream
+    each, all batches in flight, the K-step program REPLAYED (first call captures, second and third replay) -- at the configuration's full batch and K, each engine's
     third result against the oracle, and bit-equal to the other engine's and to its own second call (replays are deterministic)."""
     from cgs_amd.engine import RefineEngine
     from cgs_amd.nets import to_device
     d = torch.device("cuda:0")
     P, z, f0, want = oracle_case(arch, B, K, G)
     Pd = to_device(P, d)
-    engines = [RefineEngine(arch, Pd, G * B, d, use_graph=True, bn_groups=G) for _ in range(2)]
+    import bench
+    engines = [RefineEngine(arch, Pd, G * B, d, use_graph=True, bn_groups=G) for _ in range(bench.IN_FLIGHT[arch])]      # as many in flight as bench.py keeps
     streams = [torch.cuda.Stream(d) for _ in engines]
     zd = z.to(d)
     torch.cuda.synchronize(d)
@@ -123,9 +124,10 @@ def test_the_benched_mode_matches_the_oracle(arch, B, K, G):
                 outs.append([t.clone() for t in e.refine_from_z(zd, K, 0.1)])
         torch.cuda.synchronize(d)
         results.append(outs)
-    for ei in range(2):
-        compare(f"hipgraph engine {ei}", arch, B, K, G, results[2][ei], want)
+    for ei in range(len(engines)):
+        if ei < 2:
+            compare(f"hipgraph engine {ei}", arch, B, K, G, results[2][ei], want)
         for a, b in zip(results[2][ei], results[1][ei]):
             assert torch.equal(a, b)
-    for a, b in zip(results[2][0], results[2][1]):
-        assert torch.equal(a, b)
+        for a, b in zip(results[2][0], results[2][ei]):
+            assert torch.equal(a, b)

@@ -1,3 +1,4 @@
-python -m pytest tests/test_gpu_ops.py -x -q -m gpu 2>&1 | tail -4
-export LB_ITERS=30
-for V in 0 1 0 1; do echo "== CGS_DIRECT_EPI=$V"; env CGS_LIB=$PWD/collaborative-gan-sampling_amd/libcgs_exp.so CGS_DIRECT_EPI=$V python tools/layer_bench.py dcgan64 1024 2>&1 | grep -E "conv|sum"; done
+for i in 1 2 3; do
+echo -n "HEAD   : "; python bench.py --no-cpu-baseline --no-other-configs 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['avg_launch_us'])"
+echo -n "frozen : "; python tools/bench_frozen_tmp.py --no-cpu-baseline --no-other-configs 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['avg_launch_us'])"
+done
