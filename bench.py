@@ -46,7 +46,7 @@ TRAFFIC_JSON = os.path.join(ROOT, "profiles", "traffic.json")
 # HBM-bound multi-kernel entry points -> the kernels one call launches (rocprofv3 names; the last one runs once per call)
 HBM_OPS = {
     "bn_train_lrelu_fwd_from_partials": ["bn_slice_sums_kernel", "bn_finalize_slices_kernel", "bn_apply_fwd_kernel"],
-    "bn_train_lrelu_bwd_data": ["bn_partial_kernel<1>", "bn_finalize_kernel<1>", "bn_restat_kernel", "bn_apply_bwd_kernel"],
+    "bn_train_lrelu_bwd_data": ["bn_partial_kernel<1>", "bn_finalize_kernel<1>", "bn_apply_bwd_kernel"],
     "refine_update": ["refine_update_kernel"],
     "linear_out1_fwd": ["linear_out1_fwd_kernel"],
     "linear_out1_bwd": ["linear_out1_bwd_kernel"],
@@ -54,6 +54,8 @@ HBM_OPS = {
 # logical batches fused per launch by default (tools/sweep_fuse.sh on MI355X, two launches in flight: mnist 16 -> 24.3 k,
 # 24 -> 26.1 k, 32 -> 26.3 k, 40 -> 27.1 k samples/s; dcgan32 4 -> 26.5 k, 6 -> 27.5 k, 8 -> 28.6 k): the tails and the per-launch
 # fixed costs of the ~13-27 GFLOP layers amortise over more rows
+# (config 5's instance norms have no batch coupling, so any number of samples per launch would be exact, but 8 / 16 / 32 / 64 rows x 4
+# calls in flight gave 170.3 / 172.5 / 172.2 / 169.0 samples/s in one session and 171-174 / 173 / 173-175 in another: it keeps its own 8)
 FUSE = {"dcgan32": 8, "mnist": 32}
 # engine calls in flight per GPU (one engine + HIP stream each).  dcgan64's 700-us launches: 1 -> 6258, 2 -> 6640..6720, 3 -> +0.5 %,
 # 4 -> -0.7 % (round 2).  The small configurations' short launches gain from more (round 3, same session: cyclegan256 2 -> 155.3,

@@ -216,6 +216,62 @@ int cgs_conv_stat_partials(int B, int H, int W, int Cin, int Cout, int kh, int k
     return (int)(2 * ((M + 127) / 128));                             // one partial row per (128-row tile, wave row)
 }
 
+// Where the partial rows of one GROUP of group_images consecutive images lie in the [rows][2][Cout] buffer a *_fwd_stats call fills
+// (one row per 64 GEMM rows; the parity classes of a transposed convolution back to back): group g owns, for every segment
+// s < nseg, the rows_per_seg rows from s * seg_stride + g * rows_per_seg.  Image-major launches: a segment per parity class;
+// pixel-major launches (whole 128-image tiles): a segment per (class, base pixel).  Returns the total row count, 0 = unavailable.
+int cgs_conv_stat_layout(int op, int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int sh, int sw, int group_images,
+                         size_t ws_bytes, int* rows_per_seg, int* nseg, int* seg_stride) {
+    if ((op != CGS_CONV_FWD && op != CGS_DECONV_FWD) || B <= 0 || group_images <= 0 || (B % group_images) || (Cout & 3) || !rows_per_seg || !nseg ||
+        !seg_stride)
+        return 0;
+    const bool dirT = op == CGS_DECONV_FWD;
+    CgsLayer L;
+    if (!dirT) { if (make_layer(L, kh, kw, sh, sw, H, W, Cin, cgs_ceil_div(H, sh > 0 ? sh : 1), cgs_ceil_div(W, sw > 0 ? sw : 1), Cout, "conv_stat_layout")) return 0; }
+    else if (make_layer(L, kh, kw, sh, sw, Ho, Wo, Cout, H, W, Cin, "conv_stat_layout")) return 0;
+    if (dirT && (sh > 2 || sw > 2)) return 0;
+    if (choose_family(L, dirT, B, CGS_EPI_NONE, ws_bytes > 0, ws_bytes, true, true, true) != CGS_FAMILY_IGEMM) return 0;
+    const size_t per = (size_t)(L.Hb * L.Wb * L.Cb > L.Hs * L.Ws * L.Cs ? L.Hb * L.Wb * L.Cb : L.Hs * L.Ws * L.Cs) * 4;
+    if ((size_t)B * per > 0x7fffffffUL) return 0;                    // the entry point would split the batch
+    IgemmParams p;
+    p.B = B; p.stat_part = nullptr; p.sign_out = nullptr; p.sign_plane = 0; p.epilogue = CGS_EPI_NONE;
+    if (dirT) cgs_geom_T(L, p); else cgs_geom_F(L, p);
+    const int RC = p.cls[0].R * p.cls[0].C;
+    for (int i = 1; i < p.nclasses; ++i)
+        if (p.cls[i].R * p.cls[i].C != RC) return 0;                 // (odd output sizes: parity classes of different size)
+    if (RC <= 0) return 0;
+    const long M = (long)B * RC;
+    const long cls_rows = 2 * ((M + 127) / 128);
+    if (cls_rows * p.nclasses > 0x7fffffffL) return 0;
+    const int order = cgs_igemm_row_order(p);
+    if (order == 0) {                                                // rows (image, pixel): a group's rows are contiguous inside every class
+        if (((long)group_images * RC) % 64) return 0;
+        *rows_per_seg = (int)((long)group_images * RC / 64); *nseg = p.nclasses; *seg_stride = (int)cls_rows;
+    } else if (order == 2) {                                         // rows (pixel, image), B % 128 == 0: 64 consecutive images of one pixel per row
+        if (group_images % 64) return 0;
+        *rows_per_seg = group_images / 64; *nseg = p.nclasses * RC; *seg_stride = B / 64;
+    } else {
+        return 0;
+    }
+    return (int)(cls_rows * p.nclasses);
+}
+
+int cgs_deconv2d_nhwc_fwd_stats(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int Cin, int Ho, int Wo,
+                                int Cout, int kh, int kw, int sh, int sw, void* ws, size_t ws_bytes, int ws_prepacked, float* stat_part,
+                                size_t stat_part_bytes, void* stream) {
+    CgsLayer L;
+    int rc = make_layer(L, kh, kw, sh, sw, Ho, Wo, Cout, H, W, Cin, "deconv2d_nhwc_fwd_stats");
+    if (rc) return rc;
+    int a, b, c;
+    const int G = cgs_conv_stat_layout(CGS_DECONV_FWD, B, H, W, Cin, Ho, Wo, Cout, kh, kw, sh, sw, B, ws_bytes, &a, &b, &c);
+    if (G == 0) return cgs_set_error(CGS_EINVAL, "deconv2d_nhwc_fwd_stats: not available for this call (cgs_conv_stat_layout == 0)");
+    if (!stat_part || stat_part_bytes < (size_t)G * 2 * Cout * sizeof(float))
+        return cgs_set_error(CGS_EWORKSPACE, "deconv2d_nhwc_fwd_stats: partials buffer %zu < %zu bytes", stat_part_bytes, (size_t)G * 2 * Cout * sizeof(float));
+    if ((uintptr_t)stat_part & 15) return cgs_set_error(CGS_EINVAL, "deconv2d_nhwc_fwd_stats: partials buffer must be 16-byte aligned");
+    return run_dir(L, true, B, x, w, bias, y, CGS_EPI_NONE, nullptr, nullptr, nullptr, ws, ws_bytes, ws_prepacked, (hipStream_t)stream,
+                   "deconv2d_nhwc_fwd_stats", stat_part);
+}
+
 int cgs_conv2d_nhwc_fwd_stats(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int Cin,
                               int Cout, int kh, int kw, int sh, int sw, void* ws, size_t ws_bytes, int ws_prepacked,
                               float* stat_part, size_t stat_part_bytes, void* stream) {

@@ -34,15 +34,26 @@ size_t cgs_bn_ws_bytes(int M, int C) {
 // MODE 0: a = x, b = x*x.   MODE 1: a = dy', b = dy'*xhat  (dy' = dy * lrelu'(scale*x+shift))
 // 16-byte loads: a thread owns 4 consecutive channels and strides over the block's rows; the row groups of a
 // block are combined through LDS in a fixed order (deterministic).  C % 4 == 0.
+// scale = gamma * invstd, shift = beta - mean * scale of 4 channels, formed where they are used (a separate kernel that wrote them
+// to memory was one more dependent 4-us launch in front of every backward pass); the same expression in both backward kernels
+__device__ __forceinline__ void bn_affine4(const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                           const float* __restrict__ beta, int c, float4& mu, float4& inv, float4& sc, float4& sh) {
+    mu = *(const float4*)(mean + c); inv = *(const float4*)(invstd + c);
+    const float4 g = *(const float4*)(gamma + c), b = *(const float4*)(beta + c);
+    sc.x = g.x * inv.x; sc.y = g.y * inv.y; sc.z = g.z * inv.z; sc.w = g.w * inv.w;
+    sh.x = fmaf(-mu.x, sc.x, b.x); sh.y = fmaf(-mu.y, sc.y, b.y); sh.z = fmaf(-mu.z, sc.z, b.z); sh.w = fmaf(-mu.w, sc.w, b.w);
+}
+
 template <int MODE>
 __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                         const float* __restrict__ stat /* [4][C]: mean, invstd, scale, shift */,
+                                                         const float* __restrict__ mean_p, const float* __restrict__ invstd_p /* [groups][C] */,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          float leak, float* __restrict__ part, int M, int C,
                                                          int rows_per_block) {
     __shared__ float4 red[2][256];
     // blockIdx.y = independent group (instance norm: one per sample; batch norm: a single group)
     x += (size_t)blockIdx.y * M * C;
-    if (MODE == 1) { dy += (size_t)blockIdx.y * M * C; stat += (size_t)blockIdx.y * 4 * C; }
+    if (MODE == 1) { dy += (size_t)blockIdx.y * M * C; mean_p += (size_t)blockIdx.y * C; invstd_p += (size_t)blockIdx.y * C; }
     part += (size_t)blockIdx.y * gridDim.x * 2 * C;
     const int tid = threadIdx.x;
     const int r0 = blockIdx.x * rows_per_block;
@@ -57,10 +68,7 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
         float4 sa = make_float4(0.f, 0.f, 0.f, 0.f), sb = sa;
         if (cq < CQ) {
             float4 mean = sa, invstd = sa, scale = sa, shift = sa;
-            if (MODE == 1) {
-                mean = ((const float4*)stat)[cq]; invstd = ((const float4*)(stat + C))[cq];
-                scale = ((const float4*)(stat + 2 * C))[cq]; shift = ((const float4*)(stat + 3 * C))[cq];
-            }
+            if (MODE == 1) bn_affine4(mean_p, invstd_p, gamma, beta, 4 * cq, mean, invstd, scale, shift);
             for (int r = r0 + rg; r < r1; r += RG) {
                 const float4 xv = ((const float4*)(x + (size_t)r * C))[cq];
                 if (MODE == 0) {
@@ -102,11 +110,12 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
 // the 16x16x128 layer: with 16 channels x 16 slices and C/16 = 8 blocks this kernel took 42 us there).
 #define BNF_CH 8
 #define BNF_SL 32
+// nseg > 1 (statistics left by a convolution, cgs_conv_stat_layout): a group's G rows repeat in nseg segments seg_stride rows apart.
 template <int MODE>
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int G, int M, int C,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           float eps, float* __restrict__ stat, float* __restrict__ mean_out,
-                                                          float* __restrict__ invstd_out) {
+                                                          float* __restrict__ invstd_out, int nseg = 1, int seg_stride = 0) {
     __shared__ double red[2][BNF_SL][BNF_CH + 1];
     part += (size_t)blockIdx.y * G * 2 * C;
     stat += (size_t)blockIdx.y * (MODE == 0 ? 4 : 2) * C;
@@ -115,7 +124,11 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     const int c = blockIdx.x * BNF_CH + cl;
     double a = 0.0, b = 0.0;
     if (c < C)
-        for (int g = sl; g < G; g += BNF_SL) { a += (double)part[((size_t)g * 2 + 0) * C + c]; b += (double)part[((size_t)g * 2 + 1) * C + c]; }
+        for (int q = sl; q < nseg * G; q += BNF_SL) {                   // (fixed order per slice: deterministic)
+            const int sg = q / G, g = q - sg * G;
+            const float* row = part + ((size_t)sg * seg_stride + g) * 2 * C;
+            a += (double)row[c]; b += (double)row[C + c];
+        }
     red[0][sl][cl] = a; red[1][sl][cl] = b;
     __syncthreads();
     if (sl != 0 || c >= C) return;
@@ -192,15 +205,17 @@ __global__ __launch_bounds__(256) void bn_apply_fwd_kernel(const float* __restri
 
 // dx = gamma*invstd*(dy' - m1 - xhat*m2)
 __global__ __launch_bounds__(256) void bn_apply_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
-                                                           const float* __restrict__ stat0, const float* __restrict__ stat20,
+                                                           const float* __restrict__ mean0, const float* __restrict__ invstd0,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           const float* __restrict__ stat20,
                                                            float leak, float* __restrict__ dx, size_t n4, int C, size_t group_n4) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
-        const float* stat = stat0 + (i / group_n4) * 4 * C;
-        const float* stat2 = stat20 + (i / group_n4) * 2 * C;
+        const size_t grp = i / group_n4;
+        const float* stat2 = stat20 + grp * 2 * C;
         const int c = (int)((i * 4) % C);
         const float4 xv = ((const float4*)x)[i], dv = ((const float4*)dy)[i];
-        const float4 mean = *(const float4*)(stat + c), inv = *(const float4*)(stat + C + c);
-        const float4 sc = *(const float4*)(stat + 2 * C + c), sh = *(const float4*)(stat + 3 * C + c);
+        float4 mean, inv, sc, sh;
+        bn_affine4(mean0 + grp * C, invstd0 + grp * C, gamma, beta, c, mean, inv, sc, sh);
         const float4 m1 = *(const float4*)(stat2 + c), m2 = *(const float4*)(stat2 + C + c);
         float4 o;
 #define BWD1(f)                                                       \
@@ -231,7 +246,7 @@ int cgs_bn_train_lrelu_fwd(const float* x, const float* gamma, const float* beta
     const BnGeom g = bn_geom(M, C);
     float* part = (float*)ws;
     float* stat = part + (size_t)BN_MAX_BLOCKS * 2 * C;
-    hipLaunchKernelGGL(bn_partial_kernel<0>, dim3(g.G), dim3(256), 0, s, x, nullptr, nullptr, leak, part, M, C, g.rows_per_block);
+    hipLaunchKernelGGL(bn_partial_kernel<0>, dim3(g.G), dim3(256), 0, s, x, nullptr, nullptr, nullptr, nullptr, nullptr, leak, part, M, C, g.rows_per_block);
     hipLaunchKernelGGL(bn_finalize_kernel<0>, dim3(cgs_ceil_div(C, BNF_CH)), dim3(256), 0, s, part, g.G, M, C, gamma, beta, eps, stat, mean, invstd);
     const size_t n4 = (size_t)M * C / 4;
     hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3(ew_blocks(n4)), dim3(256), 0, s, x, stat, leak, y, n4, C, n4);
@@ -259,15 +274,6 @@ int cgs_bn_train_lrelu_fwd_from_partials(const float* x, const float* part, int 
     return CGS_OK;
 }
 
-__global__ void bn_restat_kernel(const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
-                                 const float* __restrict__ beta, float* __restrict__ stat, int C) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    mean += (size_t)blockIdx.y * C; invstd += (size_t)blockIdx.y * C; stat += (size_t)blockIdx.y * 4 * C;
-    const float scale = gamma[c] * invstd[c];
-    stat[c] = mean[c]; stat[C + c] = invstd[c]; stat[2 * C + c] = scale; stat[3 * C + c] = beta[c] - mean[c] * scale;
-}
-
 int cgs_bn_train_lrelu_bwd_data(const float* dy, const float* x, const float* gamma, const float* beta, const float* mean,
                                 const float* invstd, float leak, float* dx, int M, int C, void* ws, size_t ws_bytes,
                                 void* stream) {
@@ -278,11 +284,10 @@ int cgs_bn_train_lrelu_bwd_data(const float* dy, const float* x, const float* ga
     float* part = (float*)ws;
     float* stat = part + (size_t)BN_MAX_BLOCKS * 2 * C;           // [4][C]
     float* stat2 = stat + 4 * (size_t)C;                          // [2][C]
-    hipLaunchKernelGGL(bn_restat_kernel, dim3(cgs_ceil_div(C, 128)), dim3(128), 0, s, mean, invstd, gamma, beta, stat, C);
-    hipLaunchKernelGGL(bn_partial_kernel<1>, dim3(g.G), dim3(256), 0, s, x, dy, stat, leak, part, M, C, g.rows_per_block);
+    hipLaunchKernelGGL(bn_partial_kernel<1>, dim3(g.G), dim3(256), 0, s, x, dy, mean, invstd, gamma, beta, leak, part, M, C, g.rows_per_block);
     hipLaunchKernelGGL(bn_finalize_kernel<1>, dim3(cgs_ceil_div(C, BNF_CH)), dim3(256), 0, s, part, g.G, M, C, nullptr, nullptr, 0.f, stat2, nullptr, nullptr);
     const size_t n4 = (size_t)M * C / 4;
-    hipLaunchKernelGGL(bn_apply_bwd_kernel, dim3(ew_blocks(n4)), dim3(256), 0, s, dy, x, stat, stat2, leak, dx, n4, C, n4);
+    hipLaunchKernelGGL(bn_apply_bwd_kernel, dim3(ew_blocks(n4)), dim3(256), 0, s, dy, x, mean, invstd, gamma, beta, stat2, leak, dx, n4, C, n4);
     CGS_CHECK_LAUNCH("bn_train_lrelu_bwd_data");
     return CGS_OK;
 }
@@ -341,7 +346,7 @@ int cgs_bn_sync_fwd_sums(const float* x, double* sums, int M, int C, void* ws, s
     hipStream_t s = (hipStream_t)stream;
     const BnGeom g = bn_geom(M, C);
     float* part = (float*)ws;
-    hipLaunchKernelGGL(bn_partial_kernel<0>, dim3(g.G), dim3(256), 0, s, x, nullptr, nullptr, 1.f, part, M, C, g.rows_per_block);
+    hipLaunchKernelGGL(bn_partial_kernel<0>, dim3(g.G), dim3(256), 0, s, x, nullptr, nullptr, nullptr, nullptr, nullptr, 1.f, part, M, C, g.rows_per_block);
     hipLaunchKernelGGL(bn_sums_kernel, dim3(cgs_ceil_div(C, 16)), dim3(256), 0, s, part, g.G, C, sums);
     CGS_CHECK_LAUNCH("bn_sync_fwd_sums");
     return CGS_OK;
@@ -367,9 +372,7 @@ int cgs_bn_sync_bwd_sums(const float* dy, const float* x, const float* gamma, co
     hipStream_t s = (hipStream_t)stream;
     const BnGeom g = bn_geom(M, C);
     float* part = (float*)ws;
-    float* stat = part + (size_t)BN_MAX_BLOCKS * 2 * C;
-    hipLaunchKernelGGL(bn_restat_kernel, dim3(cgs_ceil_div(C, 128)), dim3(128), 0, s, mean, invstd, gamma, beta, stat, C);
-    hipLaunchKernelGGL(bn_partial_kernel<1>, dim3(g.G), dim3(256), 0, s, x, dy, stat, leak, part, M, C, g.rows_per_block);
+    hipLaunchKernelGGL(bn_partial_kernel<1>, dim3(g.G), dim3(256), 0, s, x, dy, mean, invstd, gamma, beta, leak, part, M, C, g.rows_per_block);
     hipLaunchKernelGGL(bn_sums_kernel, dim3(cgs_ceil_div(C, 16)), dim3(256), 0, s, part, g.G, C, sums);
     CGS_CHECK_LAUNCH("bn_sync_bwd_sums");
     return CGS_OK;
@@ -383,10 +386,9 @@ int cgs_bn_sync_bwd_apply(const float* dy, const float* x, const float* gamma, c
     hipStream_t s = (hipStream_t)stream;
     float* stat = (float*)ws + (size_t)BN_MAX_BLOCKS * 2 * C;
     float* stat2 = stat + 4 * (size_t)C;
-    hipLaunchKernelGGL(bn_restat_kernel, dim3(cgs_ceil_div(C, 128)), dim3(128), 0, s, mean, invstd, gamma, beta, stat, C);
     hipLaunchKernelGGL(bn_stat2_from_sums_kernel, dim3(cgs_ceil_div(C, 128)), dim3(128), 0, s, sums, (double)M_total, C, stat2);
     const size_t n4 = (size_t)M * C / 4;
-    hipLaunchKernelGGL(bn_apply_bwd_kernel, dim3(ew_blocks(n4)), dim3(256), 0, s, dy, x, stat, stat2, leak, dx, n4, C, n4);
+    hipLaunchKernelGGL(bn_apply_bwd_kernel, dim3(ew_blocks(n4)), dim3(256), 0, s, dy, x, mean, invstd, gamma, beta, stat2, leak, dx, n4, C, n4);
     CGS_CHECK_LAUNCH("bn_sync_bwd_apply");
     return CGS_OK;
 }
@@ -406,7 +408,7 @@ int cgs_bias_grad(const float* dy, float* db, int M, int C, int accumulate, void
     if (ws_bytes < cgs_bn_ws_bytes(M, C)) return cgs_set_error(CGS_EWORKSPACE, "bias_grad: workspace %zu < %zu", ws_bytes, cgs_bn_ws_bytes(M, C));
     hipStream_t s = (hipStream_t)stream;
     const BnGeom g = bn_geom(M, C);
-    hipLaunchKernelGGL(bn_partial_kernel<0>, dim3(g.G), dim3(256), 0, s, dy, nullptr, nullptr, 0.f, (float*)ws, M, C, g.rows_per_block);
+    hipLaunchKernelGGL(bn_partial_kernel<0>, dim3(g.G), dim3(256), 0, s, dy, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, (float*)ws, M, C, g.rows_per_block);
     hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cgs_ceil_div(C, 128)), dim3(128), 0, s, (const float*)ws, g.G, C, db, accumulate);
     CGS_CHECK_LAUNCH("bias_grad");
     return CGS_OK;
@@ -444,11 +446,31 @@ int cgs_instnorm_lrelu_fwd(const float* x, const float* scale, const float* offs
     const BnGeom g = in_geom(B, HW);
     float* part = (float*)ws;
     float* stat = part + (size_t)B * g.G * 2 * C;
-    hipLaunchKernelGGL(bn_partial_kernel<0>, dim3(g.G, B), dim3(256), 0, s, x, nullptr, nullptr, leak, part, HW, C, g.rows_per_block);
+    hipLaunchKernelGGL(bn_partial_kernel<0>, dim3(g.G, B), dim3(256), 0, s, x, nullptr, nullptr, nullptr, nullptr, nullptr, leak, part, HW, C, g.rows_per_block);
     hipLaunchKernelGGL(bn_finalize_kernel<0>, dim3(cgs_ceil_div(C, BNF_CH), B), dim3(256), 0, s, part, g.G, HW, C, scale, offset, eps, stat, mean, invstd);
     const size_t n4 = (size_t)B * HW * C / 4, gn4 = (size_t)HW * C / 4;
     hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3(ew_blocks(n4)), dim3(256), 0, s, x, stat, leak, y, n4, C, gn4);
     CGS_CHECK_LAUNCH("instnorm_lrelu_fwd");
+    return CGS_OK;
+}
+
+// Norm over GROUPS of rows whose statistics the producing convolution left as partial rows (cgs_conv_stat_layout): instance norm
+// (a group = one sample) and the batch norm of several logical batches fused into one launch (a group = one logical batch).
+// x is [groups][M_group][C]; mean / invstd [groups][C].  ws: >= groups * 4 * C floats (cgs_instnorm_ws_bytes(groups, M_group, C) covers it).
+int cgs_groupnorm_lrelu_fwd_from_partials(const float* x, const float* part, int groups, int rows_per_seg, int nseg, int seg_stride,
+                                          const float* gamma, const float* beta, float eps, float leak, float* y, float* mean, float* invstd,
+                                          int M_group, int C, void* ws, size_t ws_bytes, void* stream) {
+    if (groups <= 0 || groups > 65535 || M_group <= 0 || C <= 0 || (C & 3) || rows_per_seg <= 0 || nseg <= 0 || seg_stride < 0 || !part)
+        return cgs_set_error(CGS_EINVAL, "groupnorm fwd from partials: groups=%d M=%d C=%d rows=%d x %d", groups, M_group, C, rows_per_seg, nseg);
+    if (ws_bytes < (size_t)groups * 4 * C * sizeof(float))
+        return cgs_set_error(CGS_EWORKSPACE, "groupnorm fwd from partials: workspace %zu < %zu", ws_bytes, (size_t)groups * 4 * C * sizeof(float));
+    hipStream_t s = (hipStream_t)stream;
+    float* stat = (float*)ws;                                          // [groups][4][C]
+    hipLaunchKernelGGL(bn_finalize_kernel<0>, dim3(cgs_ceil_div(C, BNF_CH), groups), dim3(256), 0, s, part, rows_per_seg, M_group, C, gamma, beta, eps, stat,
+                       mean, invstd, nseg, seg_stride);
+    const size_t n4 = (size_t)groups * M_group * C / 4, gn4 = (size_t)M_group * C / 4;
+    hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3(ew_blocks(n4)), dim3(256), 0, s, x, stat, leak, y, n4, C, gn4);
+    CGS_CHECK_LAUNCH("groupnorm_lrelu_fwd_from_partials");
     return CGS_OK;
 }
 
@@ -462,11 +484,10 @@ int cgs_instnorm_lrelu_bwd_data(const float* dy, const float* x, const float* sc
     float* part = (float*)ws;
     float* stat = part + (size_t)B * g.G * 2 * C;
     float* stat2 = stat + (size_t)B * 4 * C;
-    hipLaunchKernelGGL(bn_restat_kernel, dim3(cgs_ceil_div(C, 128), B), dim3(128), 0, s, mean, invstd, scale, offset, stat, C);
-    hipLaunchKernelGGL(bn_partial_kernel<1>, dim3(g.G, B), dim3(256), 0, s, x, dy, stat, leak, part, HW, C, g.rows_per_block);
+    hipLaunchKernelGGL(bn_partial_kernel<1>, dim3(g.G, B), dim3(256), 0, s, x, dy, mean, invstd, scale, offset, leak, part, HW, C, g.rows_per_block);
     hipLaunchKernelGGL(bn_finalize_kernel<1>, dim3(cgs_ceil_div(C, BNF_CH), B), dim3(256), 0, s, part, g.G, HW, C, nullptr, nullptr, 0.f, stat2, nullptr, nullptr);
     const size_t n4 = (size_t)B * HW * C / 4, gn4 = (size_t)HW * C / 4;
-    hipLaunchKernelGGL(bn_apply_bwd_kernel, dim3(ew_blocks(n4)), dim3(256), 0, s, dy, x, stat, stat2, leak, dx, n4, C, gn4);
+    hipLaunchKernelGGL(bn_apply_bwd_kernel, dim3(ew_blocks(n4)), dim3(256), 0, s, dy, x, mean, invstd, scale, offset, stat2, leak, dx, n4, C, gn4);
     CGS_CHECK_LAUNCH("instnorm_lrelu_bwd_data");
     return CGS_OK;
 }

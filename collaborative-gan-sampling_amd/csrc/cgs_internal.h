@@ -77,7 +77,8 @@ struct IgemmParams {
     int lpt;             // pixel-major only: m-tiles visit the pixels in perm[] order (most valid taps first)
     unsigned* sign_out;  // != null: sign bitmask of the stored output (layout: cgs_hip.h, "sign masks"); wide epilogue, N % 32 == 0, no split-K
     long sign_plane;     // words per 32-channel plane of the mask = pixels of the WHOLE tensor (a launch may be one batch chunk of it)
-    float* stat_part;    // != null: per-(m-tile, wave row) column sums / sums of squares of the output, [2 * m-tiles][2][N] (fused batch-norm statistics)
+    float* stat_part;    // != null: per-(m-tile, wave row) column sums / sums of squares of the output, [class][2 * m-tiles][2][N] (fused norm statistics)
+    int stat_cls_rows;   // partial rows per parity class = 2 * m-tiles of a class (the launcher sets it)
     int vec;             // the 32-channel-chunk K order / 16-byte row gathers apply: Cred % 32 == 0 and at most 16 taps per axis
     int prio_t[3];       // progress thresholds (1/256 of the block's K tiles) at which a block steps its wave priority down; 0 = off
     int nclasses;
@@ -101,6 +102,7 @@ size_t cgs_packed_floats(const IgemmParams& p);
 int cgs_pack_weights(const IgemmParams& p, const CgsLayer& L, bool dirT, const float* w, float* packed, hipStream_t s);
 int cgs_igemm_launch(const IgemmParams& p, void* slab, size_t slab_bytes, hipStream_t s);
 size_t cgs_igemm_splitk_bytes(const IgemmParams& p);   // slab bytes the launch would like (0 = no split-K)
+int cgs_igemm_row_order(const IgemmParams& p);         // GEMM row order the launcher will pick: 0 (image, pixel); 1 (pixel, image); 2 (pixel, image) in whole 128-image tiles
 size_t cgs_convt_quad_ws_floats_bound(int kh, int kw, int Cs);
 int cgs_convt_taps_ok(const CgsLayer& L);          // 4x4 stride-2 transposed conv to one channel: all 16 taps as MFMA columns (convt_taps.hip)
 int cgs_convt_taps_launch(const CgsLayer& L, int B, const float* in, const float* w, const float* bias, float* out, int epilogue,

@@ -854,7 +854,7 @@ __global__ __launch_bounds__(64 * NW, 2) void igemm_kernel(IgemmParams p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { st_a[e] += __shfl_xor(st_a[e], off); st_b[e] += __shfl_xor(st_b[e], off); }
             if (rsub == 0 && n < p.N) {
-                float* dst = p.stat_part + ((size_t)((m0 / BM) * 2 + wm) * 2) * p.N + n;
+                float* dst = p.stat_part + ((size_t)(cls_i * p.stat_cls_rows + (m0 / BM) * 2 + wm) * 2) * p.N + n;
                 *(f32x4*)dst = st_a;
                 *(f32x4*)(dst + p.N) = st_b;
             }
@@ -1014,18 +1014,12 @@ static int launch_cfg(const IgemmParams& p, hipStream_t s) {
     return CGS_OK;
 }
 
-int cgs_igemm_launch(const IgemmParams& p_in, void* slab, size_t slab_bytes, hipStream_t s) {
-    IgemmParams p = p_in;
-    p.splitk = 1; p.slab = nullptr;
-    p.prio_t[0] = p.prio_t[1] = p.prio_t[2] = 0;
-#ifdef CGS_DIAG_STAMPS
-    if (getenv("CGS_STAMP") && slab && slab_bytes >= 64) p.slab = (float*)slab;
-#endif
-    // pixel-major row order (a tile = ONE base pixel of 128 images, so a tap that falls into the zero padding does so for the
-    // whole tile and is skipped) pays when the batch fills whole tiles and the pixel grid is small enough that the padding is a
-    // visible share of the taps: 28 % of the MACs at 4x4, 14 % at 8x8, 7 % at 16x16 (measured at batch 1024: 16x16 grids
-    // -3..-5.6 % per layer, also for the 268 MB input of the 32x32x64 forward layer, which no longer fits the Infinity Cache:
-    // the ~128 blocks an XCD runs at once are 128 pixels of the SAME image group, so the re-reads meet in its L2)
+// pixel-major row order (a tile = ONE base pixel of 128 images, so a tap that falls into the zero padding does so for the
+// whole tile and is skipped) pays when the batch fills whole tiles and the pixel grid is small enough that the padding is a
+// visible share of the taps: 28 % of the MACs at 4x4, 14 % at 8x8, 7 % at 16x16 (measured at batch 1024: 16x16 grids
+// -3..-5.6 % per layer, also for the 268 MB input of the 32x32x64 forward layer, which no longer fits the Infinity Cache:
+// the ~128 blocks an XCD runs at once are 128 pixels of the SAME image group, so the re-reads meet in its L2)
+static bool igemm_pix_major(const IgemmParams& p) {
     int maxRC = 0;
     for (int i = 0; i < p.nclasses; ++i) maxRC = p.cls[i].R * p.cls[i].C > maxRC ? p.cls[i].R * p.cls[i].C : maxRC;
     const size_t in_bytes = (size_t)p.B * p.Hin * p.Win * p.Cred * 4;
@@ -1035,7 +1029,24 @@ int cgs_igemm_launch(const IgemmParams& p_in, void* slab, size_t slab_bytes, hip
     if (getenv("CGS_PIXMAX")) pix_max = atoi(getenv("CGS_PIXMAX"));
     if (getenv("CGS_PIXBYTES")) pix_bytes = (size_t)atoi(getenv("CGS_PIXBYTES")) << 20;
 #endif
-    p.pix_major = p.vec && p.B >= 128 && maxRC <= pix_max && maxRC > 1 && in_bytes <= pix_bytes;
+    return p.vec && p.B >= 128 && maxRC <= pix_max && maxRC > 1 && in_bytes <= pix_bytes;
+}
+
+int cgs_igemm_row_order(const IgemmParams& p) {
+    if (!igemm_pix_major(p)) return 0;
+    return (p.B % 128) == 0 ? 2 : 1;
+}
+
+int cgs_igemm_launch(const IgemmParams& p_in, void* slab, size_t slab_bytes, hipStream_t s) {
+    IgemmParams p = p_in;
+    p.splitk = 1; p.slab = nullptr;
+    p.prio_t[0] = p.prio_t[1] = p.prio_t[2] = 0;
+#ifdef CGS_DIAG_STAMPS
+    if (getenv("CGS_STAMP") && slab && slab_bytes >= 64) p.slab = (float*)slab;
+#endif
+    int maxRC = 0;
+    for (int i = 0; i < p.nclasses; ++i) maxRC = p.cls[i].R * p.cls[i].C > maxRC ? p.cls[i].R * p.cls[i].C : maxRC;
+    p.pix_major = igemm_pix_major(p);
     p.lpt = p.pix_major && (p.B % 128) == 0;
     if (p.lpt)
         for (int ci = 0; ci < p.nclasses; ++ci) {
@@ -1056,8 +1067,15 @@ int cgs_igemm_launch(const IgemmParams& p_in, void* slab, size_t slab_bytes, hip
         }
     if ((long)p.B * p.Hout * p.Wout * p.N * 4 > 0x7fffffffL || (long)p.B * p.Hin * p.Win * p.Cred * 4 > 0x7fffffffL)
         return cgs_set_error(CGS_EINVAL, "igemm: a tensor of one launch exceeds 2 GiB (the caller splits the batch)");
-    if (p.stat_part && (p.nclasses != 1 || (p.N & 3) || p.epilogue != CGS_EPI_NONE))
-        return cgs_set_error(CGS_EINVAL, "igemm: fused statistics need the forward direction, N %% 4 == 0 and no epilogue");
+    if (p.stat_part && ((p.N & 3) || p.epilogue != CGS_EPI_NONE))
+        return cgs_set_error(CGS_EINVAL, "igemm: fused statistics need N %% 4 == 0 and no epilogue");
+    p.stat_cls_rows = 0;
+    if (p.stat_part) {        // one partial row per (128-row tile, wave row), the parity classes back to back (equal M: cgs_conv_stat_layout)
+        const long M0 = (long)p.B * p.cls[0].R * p.cls[0].C;
+        for (int i = 1; i < p.nclasses; ++i)
+            if ((long)p.B * p.cls[i].R * p.cls[i].C != M0) return cgs_set_error(CGS_EINVAL, "igemm: fused statistics need parity classes of equal size");
+        p.stat_cls_rows = (int)(2 * ((M0 + 127) / 128));
+    }
     if (p.sign_out && !cgs_igemm_signs_ok(p))
         return cgs_set_error(CGS_EINVAL, "igemm: a sign mask needs N %% 32 == 0, the relu / lrelu forward epilogues and a grid that is not split over K");
     {   // split-K for under-filled grids, if the caller's workspace has room for the partial slabs

@@ -55,16 +55,26 @@ class _Conv(_Stage):
         self.out = torch.empty((B, _same_out(H, stride), _same_out(W, stride), w.shape[3]), dtype=torch.float32, device=dev)
         self.dx = torch.empty((B,) + tuple(in_shape), dtype=torch.float32, device=dev)
 
-    part = None          # [G, 2, Cout]: per-block column sums of the output for the batch norm that follows (fused statistics)
+    part = None          # [G, 2, Cout]: per-block column sums of the output for the norm that follows (fused statistics)
+    part_layout = None   # (rows, rows_per_seg, nseg, seg_stride) of the groups the norm asked for (kernels.conv_stat_layout)
 
-    def want_stats(self, B):
-        """Called by the batch-norm stage right above: have this conv leave the statistics partials, if the library can."""
+    def want_stats(self, B, group_images=None):
+        """Called by the norm stage right above: have this conv leave the statistics partials, if the library can.
+        ``group_images``: the norm keeps one set of statistics per that many consecutive images (instance norm: 1; the batch
+        norm of fused logical batches: one batch); None = the whole batch.  Returns the partials buffer or None."""
         import os
-        if os.environ.get("CGS_NO_FUSED_BN_STATS"):       # (A/B switch for measurements)
+        if os.environ.get("CGS_NO_FUSED_BN_STATS") or self.epi != L.EPI_NONE:       # (the first: A/B switch for measurements)
             return None
-        G = K.conv_stat_partials((B,) + tuple(self.dx.shape[1:]), tuple(self.w.shape), self.s, self.s) if self.epi == L.EPI_NONE else 0
-        if G > 0:
-            self.part = torch.empty((G, 2, self.w.shape[3]), dtype=torch.float32, device=self.out.device)
+        H, W, Cin = self.dx.shape[1:]
+        kh, kw, _, Cout = self.w.shape
+        if group_images is None:             # whole-batch statistics: any row order of the launch will do
+            G = K.conv_stat_partials((B, H, W, Cin), tuple(self.w.shape), self.s, self.s)
+            lay = (G, G, 1, 0) if G > 0 else None
+        else:
+            lay = K.conv_stat_layout(L.CONV_FWD, B, H, W, Cin, 0, 0, Cout, kh, kw, self.s, self.s, group_images)
+        if lay is not None:
+            self.part = torch.empty((lay[0], 2, Cout), dtype=torch.float32, device=self.out.device)
+            self.part_layout = lay
         return self.part
 
     def fwd(self, x):
@@ -94,9 +104,22 @@ class _Deconv(_Stage):
 
     signs = None        # int32 [B*Ho*Wo*C/32]: this stage's forward leaves the sign mask of its (relu'd) output there ...
     bwd_signs = None    # ... and this stage's backward-data reads the mask of the stage below instead of its fp32 output
+    part = None         # statistics partials of the output for the (instance) norm that follows, as in _Conv
+    part_layout = None
+
+    def want_stats(self, B, group_images=None):
+        import os
+        if os.environ.get("CGS_NO_FUSED_BN_STATS") or self.epi != L.EPI_NONE:
+            return None
+        lay = K.conv_stat_layout(L.DECONV_FWD, *self.call_dims(), self.s, self.s, group_images or B)
+        if lay is not None:
+            self.part = torch.empty((lay[0], 2, self.w.shape[2]), dtype=torch.float32, device=self.out.device)
+            self.part_layout = lay
+        return self.part
 
     def fwd(self, x):
-        return K.deconv2d_fwd(x, self.w, self.b, self.out_hw, self.s, self.s, self.epi, self.a, self.c, out=self.out, signs=self.signs)
+        return K.deconv2d_fwd(x, self.w, self.b, self.out_hw, self.s, self.s, self.epi, self.a, self.c, out=self.out, signs=self.signs,
+                              part=self.part)
 
     def bwd(self, dy):
         if not self.pre_folded:
@@ -144,10 +167,18 @@ class _BnTrainLrelu(_Stage):
     groups = 1           # > 1: the engine batch is ``groups`` logical batches back to back, each with its OWN statistics
     part = None          # the producing conv's statistics partials (fused: no statistics pass over the tensor here)
 
-    def set_groups(self, groups):
-        """Statistics per group of rows: the instance-norm kernels with one 'sample' = one logical batch."""
+    part_layout = None   # groups > 1: where a group's partial rows lie (the producing conv's part_layout)
+
+    def set_groups(self, groups, producer=None):
+        """Statistics per group of rows: the instance-norm kernels with one 'sample' = one logical batch.  ``producer``: the
+        conv stage right below, asked to leave its statistics partials per logical batch."""
         self.groups = int(groups)
-        self.part = None                 # (whole-batch partials do not apply; the producing conv keeps writing them, unused)
+        self.part = self.part_layout = None
+        if producer is not None:
+            producer.part = producer.part_layout = None
+            B = self.out.shape[0]
+            self.part = producer.want_stats(B, B // self.groups)
+            self.part_layout = producer.part_layout
         C = self.out.shape[-1]
         self.mean = torch.empty((self.groups, C), dtype=torch.float32, device=self.out.device)
         self.invstd = torch.empty((self.groups, C), dtype=torch.float32, device=self.out.device)
@@ -158,7 +189,11 @@ class _BnTrainLrelu(_Stage):
     def fwd(self, x):
         self.x = x
         if self.groups > 1:
-            K.instnorm_lrelu_fwd(self._g(x), self.gamma, self.beta, self.leak, out=self._g(self.out), stats=(self.mean, self.invstd))
+            if self.part is not None:
+                K.groupnorm_lrelu_fwd_from_partials(x, self.part, self.part_layout, self.groups, self.gamma, self.beta, self.leak,
+                                                    out=self.out, stats=(self.mean, self.invstd))
+            else:
+                K.instnorm_lrelu_fwd(self._g(x), self.gamma, self.beta, self.leak, out=self._g(self.out), stats=(self.mean, self.invstd))
             return self.out
         if self.sync is None:
             if self.part is not None:
@@ -230,9 +265,16 @@ class _InstNormAct(_Stage):
         self.invstd = torch.empty((B, shape[-1]), dtype=torch.float32, device=dev)
         self.x = None
 
+    part = None          # the producing conv / deconv's statistics partials (fused: no statistics pass over the tensor here)
+    part_layout = None
+
     def fwd(self, x):
         self.x = x
-        K.instnorm_lrelu_fwd(x, self.scale, self.offset, self.leak, out=self.out, stats=(self.mean, self.invstd))
+        if self.part is not None:
+            K.groupnorm_lrelu_fwd_from_partials(x, self.part, self.part_layout, x.shape[0], self.scale, self.offset, self.leak,
+                                                out=self.out, stats=(self.mean, self.invstd))
+        else:
+            K.instnorm_lrelu_fwd(x, self.scale, self.offset, self.leak, out=self.out, stats=(self.mean, self.invstd))
         return self.out
 
     def bwd(self, dy):
@@ -355,7 +397,11 @@ def compile_layers(layers, in_shape, P, scope, B, k, stride, bn_training, dev, f
         elif t == "instnorm":
             sc = f"{scope}/{Lr[1]}"
             leak, used = (K.LEAK, 2) if kind(i + 1) == "lrelu" else (0.0, 2) if kind(i + 1) == "relu" else (1.0, 1)
-            stages.append(_InstNormAct(B, shape, P[sc + "/scale"], P[sc + "/offset"], leak, dev)); i += used
+            in_stage = _InstNormAct(B, shape, P[sc + "/scale"], P[sc + "/offset"], leak, dev)
+            if stages and isinstance(stages[-1], (_Conv, _Deconv)):       # statistics ride on the producing conv's epilogue, per sample
+                in_stage.part = stages[-1].want_stats(B, 1)
+                in_stage.part_layout = stages[-1].part_layout
+            stages.append(in_stage); i += used
         elif t == "res":
             inner, ishape = compile_layers(Lr[1], shape, P, scope, B, k, stride, bn_training, dev, folds)
             assert tuple(ishape) == tuple(shape)
@@ -460,9 +506,9 @@ class RefineEngine:
                 raise L.CgsError("bn_groups and sync_bn are mutually exclusive")
 
             def walk_g(stages):
-                for st in stages:
+                for below, st in zip([None] + stages[:-1], stages):
                     if isinstance(st, _BnTrainLrelu):
-                        st.set_groups(self.bn_groups)
+                        st.set_groups(self.bn_groups, below if isinstance(below, _Conv) else None)
                     if isinstance(st, _Residual):
                         walk_g(st.inner)
             walk_g(self.d.stages); walk_g(self.g_tail.stages)
@@ -480,10 +526,10 @@ class RefineEngine:
                         walk(st.inner)
             walk(self.d.stages); walk(self.g_tail.stages)
 
-        # per-group / synchronised statistics do not use the fused whole-batch partials: switch them off in the producing convs too
+        # synchronised statistics do not use the fused partials: switch them off in the producing convs too
         def drop_partials(stages):
             for below, st in zip([None] + stages[:-1], stages):
-                if isinstance(st, _BnTrainLrelu) and (st.groups > 1 or st.sync is not None):
+                if isinstance(st, _BnTrainLrelu) and st.sync is not None:
                     st.part = None
                     if isinstance(below, _Conv):
                         below.part = None

@@ -178,6 +178,36 @@ def conv_stat_partials(x_shape, w_shape, sh=2, sw=2):
     return int(L.load().cgs_conv_stat_partials(B, H, W, Cin, Cout, kh, kw, sh, sw, nbytes))
 
 
+def conv_stat_layout(op, B, H, W, Cin, Ho, Wo, Cout, kh, kw, sh, sw, group_images):
+    """Where the partial rows of every group of ``group_images`` consecutive images lie in the buffer ``conv2d_fwd_stats`` /
+    ``deconv2d_fwd(part=...)`` fill: (rows_total, rows_per_seg, nseg, seg_stride), or None when the fused statistics are not
+    available for the call (include/cgs_hip.h, cgs_conv_stat_layout)."""
+    import ctypes as C
+    _, nbytes = WS.plan(op, B, H, W, Cin, Ho, Wo, Cout, kh, kw, sh, sw, L.EPI_NONE)
+    a, b, c = C.c_int(0), C.c_int(0), C.c_int(0)
+    rows = int(L.load().cgs_conv_stat_layout(op, B, H, W, Cin, Ho, Wo, Cout, kh, kw, sh, sw, int(group_images), nbytes,
+                                             C.addressof(a), C.addressof(b), C.addressof(c)))
+    return (rows, a.value, b.value, c.value) if rows > 0 else None
+
+
+def groupnorm_lrelu_fwd_from_partials(x, part, layout, groups, scale, offset, leak=1.0, eps=BN_EPS, out=None, stats=None):
+    """Norm over ``groups`` groups of consecutive rows of x ([groups * M_group, C] flattened; instance norm: one group per sample)
+    whose statistics the producing convolution left in ``part`` (``layout`` = conv_stat_layout(...) of that call)."""
+    _chk(x, "x"); _chk(part, "part")
+    C_ = x.shape[-1]
+    Mg = x.numel() // (groups * C_)
+    y = out if out is not None else torch.empty_like(x)
+    mean, invstd = stats if stats is not None else (torch.empty((groups, C_), dtype=torch.float32, device=x.device),
+                                                     torch.empty((groups, C_), dtype=torch.float32, device=x.device))
+    ws = _in_workspace(groups, Mg, C_, x.device)
+    pr = _Prof(0.0, "", _nb(x, y), op="groupnorm_lrelu_fwd_from_partials") if PROFILE is not None else None
+    L.call("cgs_groupnorm_lrelu_fwd_from_partials", _ptr(x), _ptr(part), groups, layout[1], layout[2], layout[3], _ptr(scale), _ptr(offset),
+           eps, leak, _ptr(y), _ptr(mean), _ptr(invstd), Mg, C_, _ptr(ws), ws.numel() * 4, _stream())
+    if pr is not None:
+        pr.done()
+    return y, mean, invstd
+
+
 def conv2d_fwd_stats(x, w, bias, part, sh=2, sw=2, out=None):
     """conv2d_fwd (no epilogue) that also leaves the per-block column sums / sums of squares of its output in ``part``
     [G, 2, Cout] for the batch norm that follows (``bn_train_lrelu_fwd_from_partials``)."""
@@ -240,9 +270,10 @@ def conv_signs_ok(op, B, H, W, Cin, Ho, Wo, Cout, kh, kw, sh, sw, epilogue):
     return bool(L.load().cgs_conv_signs_ok(op, B, H, W, Cin, Ho, Wo, Cout, kh, kw, sh, sw, epilogue, nbytes))
 
 
-def deconv2d_fwd(x, w, bias, out_hw, sh=2, sw=2, epilogue=L.EPI_NONE, ep_a=None, ep_b=None, out=None, signs=None):
+def deconv2d_fwd(x, w, bias, out_hw, sh=2, sw=2, epilogue=L.EPI_NONE, ep_a=None, ep_b=None, out=None, signs=None, part=None):
     """tf.nn.conv2d_transpose (default 'SAME') + bias (+ fused epilogue).  nsgan/ops.py:55,61-62.
-    ``signs``: int32 [B*Ho*Wo*Cout/32] that receives the sign mask of the output (only where ``conv_signs_ok``)."""
+    ``signs``: int32 [B*Ho*Wo*Cout/32] that receives the sign mask of the output (only where ``conv_signs_ok``).
+    ``part``: [rows, 2, Cout] that receives the statistics partials of the output (no epilogue; rows = conv_stat_layout(...)[0])."""
     _chk(x, "x"); _chk(w, "w")
     B, H, W, Cin = x.shape
     kh, kw, Cout, Cin2 = w.shape
@@ -253,7 +284,12 @@ def deconv2d_fwd(x, w, bias, out_hw, sh=2, sw=2, epilogue=L.EPI_NONE, ep_a=None,
     ws, pre = WS.get(w, L.DECONV_FWD, kh, kw, sh, sw, Cin, Cout, (B, H, W), epilogue, (Ho, Wo),
                      ptrs=(_ptr(x), _ptr(bias), _ptr(y), _ptr(ep_a), _ptr(ep_b)))
     pr = _Prof(2.0 * B * H * W * Cin * kh * kw * Cout, f"deconv_fwd {H}x{W} {Cin}->{Cout}", _nb(x, w, y)) if PROFILE is not None else None
-    if signs is not None:
+    if part is not None:
+        if epilogue != L.EPI_NONE or signs is not None:
+            raise L.CgsError("deconv2d_fwd: the statistics partials are those of the plain output (no epilogue, no sign mask)")
+        L.call("cgs_deconv2d_nhwc_fwd_stats", _ptr(x), _ptr(w), _ptr(bias), _ptr(y), B, H, W, Cin, Ho, Wo, Cout, kh, kw, sh, sw,
+               _ptr(ws), ws.numel() * 4, pre, _ptr(part), part.numel() * 4, _stream())
+    elif signs is not None:
         L.call("cgs_deconv2d_nhwc_fwd_signs", _ptr(x), _ptr(w), _ptr(bias), _ptr(y), B, H, W, Cin, Ho, Wo, Cout, kh, kw, sh, sw,
                epilogue, _ptr(ep_a), _ptr(ep_b), signs.data_ptr(), _ptr(ws), ws.numel() * 4, pre, _stream())
     else:

@@ -107,6 +107,22 @@ int cgs_conv2d_nhwc_fwd_stats(const float* x, const float* w, const float* bias,
                               void* ws, size_t ws_bytes, int ws_prepacked,
                               float* stat_part, size_t stat_part_bytes, void* stream);
 
+/* The same statistics per GROUP of group_images consecutive images, and for the transposed convolution too: what an instance norm
+ * behind a conv / deconv needs (a group = one sample; CycleGAN generator and PatchGAN discriminator of BASELINE config 5 -- the
+ * reference ships no code for them), and D's batch norm (nsgan/GAN.py:65,67 -> nsgan/ops.py:19-26) when several logical batches
+ * share one launch (a group = one logical batch: every batch keeps the statistics the reference computes for it alone).
+ * cgs_conv_stat_layout says where a group's partial rows lie in the [rows][2][Cout] buffer that cgs_conv2d_nhwc_fwd_stats
+ * (op = CGS_CONV_FWD; Ho, Wo ignored) / cgs_deconv2d_nhwc_fwd_stats (op = CGS_DECONV_FWD) fill: group g owns, for every segment
+ * s < *nseg, the *rows_per_seg rows starting at row s * *seg_stride + g * *rows_per_seg.  Returns the buffer's row count; 0 = not
+ * available (another kernel family, Cout % 4 != 0, a split batch, parity classes of unequal size, a group that does not end on
+ * a 64-row boundary of the launch's row order).  cgs_groupnorm_lrelu_fwd_from_partials (below) consumes it. */
+int cgs_conv_stat_layout(int op, int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int sh, int sw,
+                         int group_images, size_t ws_bytes, int* rows_per_seg, int* nseg, int* seg_stride);
+int cgs_deconv2d_nhwc_fwd_stats(const float* x, const float* w, const float* bias, float* y,
+                                int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int sh, int sw,
+                                void* ws, size_t ws_bytes, int ws_prepacked,
+                                float* stat_part, size_t stat_part_bytes, void* stream);
+
 /* conv2d backward-data: dx[B,H,W,Cin] = d/dx of the conv above applied to dy[B,Ho,Wo,Cout].
  * Replaces the Conv2DBackpropInput node tf.gradients emits (sampling/collaborator.py:31).
  * epilogue: CGS_EPI_NONE or one of the *_BWD modes (ep_aux [B,H,W,Cin], ep_a [Cin]). */
@@ -208,6 +224,11 @@ int cgs_instnorm_lrelu_fwd(const float* x, const float* scale, const float* offs
 int cgs_instnorm_lrelu_bwd_data(const float* dy, const float* x, const float* scale, const float* offset,
                                 const float* mean, const float* invstd, float leak, float* dx, int B, int HW, int C,
                                 void* ws, size_t ws_bytes, void* stream);
+/*   fwd of a norm over groups of rows from the partial sums the producing convolution left (cgs_conv_stat_layout): x is
+ *   [groups][M_group][C], mean / invstd [groups][C]; ws >= groups * 4 * C floats.  Instance norm: groups = B, M_group = HW. */
+int cgs_groupnorm_lrelu_fwd_from_partials(const float* x, const float* part, int groups, int rows_per_seg, int nseg, int seg_stride,
+                                          const float* gamma, const float* beta, float eps, float leak, float* y, float* mean,
+                                          float* invstd, int M_group, int C, void* ws, size_t ws_bytes, void* stream);
 /* out = a + b (residual connections). */
 int cgs_add(const float* a, const float* b, float* out, size_t n, void* stream);
 

@@ -48,6 +48,18 @@ int main() {
         }
         const int G = cgs_conv_stat_partials(c.B, c.H, c.H, c.Cin, c.Cout, c.k, c.k, c.s, c.s, WS);
         expect(cgs_conv2d_nhwc_fwd_stats(P, P, P, P, c.B, c.H, c.H, c.Cin, c.Cout, c.k, c.k, c.s, c.s, P, WS, 0, P, (size_t)(G > 0 ? G : 1) * 2 * c.Cout * 4, nullptr), "conv fwd stats");
+        // statistics per group of images (instance norm: 1; a logical batch of 64), forward and transposed direction
+        for (int grp : {1, 64, c.B}) {
+            int a = 0, b = 0, d = 0;
+            const int rows = cgs_conv_stat_layout(CGS_CONV_FWD, c.B, c.H, c.H, c.Cin, 0, 0, c.Cout, c.k, c.k, c.s, c.s, grp, WS, &a, &b, &d);
+            const int rowsT = cgs_conv_stat_layout(CGS_DECONV_FWD, c.B, Ho, Ho, c.Cout, c.H, c.H, c.Cin, c.k, c.k, c.s, c.s, grp, WS, &a, &b, &d);
+            if (rowsT > 0 || c.B == 130)
+                expect(cgs_deconv2d_nhwc_fwd_stats(P, P, P, P, c.B, Ho, Ho, c.Cout, c.H, c.H, c.Cin, c.k, c.k, c.s, c.s, P, WS, 0, P,
+                                                   (size_t)(rowsT > 0 ? rowsT : 1) * 2 * c.Cin * 4, nullptr), "deconv fwd stats");
+            if (rows > 0)
+                expect(cgs_groupnorm_lrelu_fwd_from_partials(P, P, c.B / grp, a > 0 ? a : 1, b > 0 ? b : 1, d, P, P, 1e-5f, 0.2f, P, P, P, grp * Ho * Ho, c.Cout, P,
+                                                             cgs_instnorm_ws_bytes(c.B / grp, grp * Ho * Ho, c.Cout), nullptr), "groupnorm from partials");
+        }
         expect(cgs_conv2d_nhwc_bwd_weight(P, P, P, c.B, c.H, c.H, c.Cin, c.Cout, c.k, c.k, c.s, c.s, 0, P, WS, nullptr), "conv wgrad");
     }
     expect(cgs_linear_fwd(P, P, P, P, 64, 6272, 1024, CGS_EPI_LRELU, P, WS, 0, nullptr), "linear fwd");

@@ -492,6 +492,75 @@ def test_conv_with_fused_bn_statistics(B, H, Cin, Cout, k):
     assert torch.equal(part, part2)
 
 
+@pytest.mark.parametrize("case", [
+    # (op, B, H, Cin, Cout, k, stride, group_images)
+    ("conv", 8, 32, 32, 64, 4, 2, 1),          # image-major, one group per sample (PatchGAN conv + instance norm)
+    ("conv", 8, 32, 32, 64, 4, 1, 1),          # stride 1
+    ("conv", 6, 16, 32, 36, 3, 2, 2),          # groups of two samples, channel count off the 64 grid, ragged last tile
+    ("deconv", 8, 16, 64, 32, 3, 2, 1),        # transposed: four parity classes, a group's rows in four segments
+    ("deconv", 4, 32, 32, 64, 5, 2, 1),
+    ("conv", 256, 16, 32, 64, 5, 2, 64),       # pixel-major whole tiles: four logical batches of 64 (fused batches of D's batch norm)
+    ("conv", 512, 8, 64, 128, 4, 2, 128),
+    ("deconv", 256, 4, 64, 32, 4, 2, 64),      # pixel-major transposed
+], ids=lambda c: "-".join(str(v) for v in c))
+def test_fused_statistics_per_group_of_images(case):
+    """cgs_conv_stat_layout + cgs_conv2d_nhwc_fwd_stats / cgs_deconv2d_nhwc_fwd_stats + cgs_groupnorm_lrelu_fwd_from_partials: the
+    statistics of every group of consecutive images come out of the producing convolution's epilogue (either direction, image- and
+    pixel-major row orders) and give the instance norm / per-logical-batch batch norm of the separate-pass kernels."""
+    from cgs_amd import kernels as K, lib
+    op, B, H, Cin, Cout, k, s_, grp = case
+    d = dev()
+    x = rnd((B, H, H, Cin), 1).to(d)
+    if op == "conv":
+        w, b = rnd((k, k, Cin, Cout), 2, 0.05).to(d), rnd((Cout,), 3, 0.1).to(d)
+        Ho = -(-H // s_)
+        lay = K.conv_stat_layout(lib.CONV_FWD, B, H, H, Cin, 0, 0, Cout, k, k, s_, s_, grp)
+        assert lay is not None
+        part = torch.full((lay[0], 2, Cout), float("nan"), device=d)
+        y = K.conv2d_fwd_stats(x, w, b, part, s_, s_)
+        y_plain = K.conv2d_fwd(x, w, b, s_, s_)
+    else:
+        w, b = rnd((k, k, Cout, Cin), 2, 0.05).to(d), rnd((Cout,), 3, 0.1).to(d)
+        Ho = H * s_
+        lay = K.conv_stat_layout(lib.DECONV_FWD, B, H, H, Cin, Ho, Ho, Cout, k, k, s_, s_, grp)
+        assert lay is not None
+        part = torch.full((lay[0], 2, Cout), float("nan"), device=d)
+        y = K.deconv2d_fwd(x, w, b, (Ho, Ho), s_, s_, part=part)
+        y_plain = K.deconv2d_fwd(x, w, b, (Ho, Ho), s_, s_)
+    assert lib.last_kernel().startswith("igemm_kernel")
+    close(y, y_plain, 2e-6)
+    rows, rps, nseg, stride = lay
+    groups = B // grp
+    # the rows the layout assigns to group g sum to that group's column sums
+    yg = y.double().reshape(groups, -1, Cout)
+    for g in range(groups):
+        idx = torch.tensor([sg * stride + g * rps + i for sg in range(nseg) for i in range(rps)], device=d)
+        sums = part[idx].double().sum(0)
+        assert torch.isfinite(sums).all()
+        close(sums[0].float(), yg[g].sum(0).float(), 3e-5)
+        close(sums[1].float(), (yg[g] * yg[g]).sum(0).float(), 3e-5)
+    scale, offset = (rnd((Cout,), 4, 0.2) + 1).to(d), rnd((Cout,), 5, 0.1).to(d)
+    got = K.groupnorm_lrelu_fwd_from_partials(y, part, lay, groups, scale, offset, 0.2)
+    want = K.instnorm_lrelu_fwd(y.view(groups, -1, Cout), scale, offset, 0.2)
+    close(got[0].reshape(-1), want[0].reshape(-1), 1e-5)
+    close(got[1], want[1], 1e-5)
+    close(got[2], want[2], 1e-5)
+    part2 = torch.empty_like(part)                                 # determinism
+    if op == "conv":
+        K.conv2d_fwd_stats(x, w, b, part2, s_, s_)
+    else:
+        K.deconv2d_fwd(x, w, b, (Ho, Ho), s_, s_, part=part2)
+    assert torch.equal(part, part2)
+
+
+def test_group_statistics_layout_is_refused_where_a_group_does_not_own_whole_rows():
+    from cgs_amd import kernels as K, lib
+    assert K.conv_stat_layout(lib.CONV_FWD, 8, 6, 6, 32, 0, 0, 64, 3, 3, 2, 2, 1) is None          # 9 pixels per sample: not a multiple of 64 rows
+    assert K.conv_stat_layout(lib.CONV_FWD, 256, 16, 16, 32, 0, 0, 64, 5, 5, 2, 2, 32) is None      # pixel-major: a logical batch of 32 shares a row with its neighbour
+    assert K.conv_stat_layout(lib.DECONV_FWD, 8, 5, 5, 32, 9, 9, 64, 3, 3, 2, 2, 8) is None         # odd output: parity classes of different size
+    assert K.conv_stat_layout(lib.CONV_FWD, 8, 32, 32, 3, 0, 0, 64, 5, 5, 2, 2, 1) is None          # another kernel family (3 channels)
+
+
 def test_fused_statistics_not_offered_where_unsupported():
     from cgs_amd import kernels as K
     assert K.conv_stat_partials((8, 64, 64, 3), (5, 5, 3, 64), 2, 2) == 0       # the 3-channel patch kernel serves this conv
