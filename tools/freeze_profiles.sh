@@ -2,7 +2,7 @@
 # kernel stats (one and two batches in flight, eager launches: the profiled runs change no kernel), the two PMC passes behind
 # profiles/traffic.json, the SQ counters of the layer sweep, the small configurations, and the plain default bench line.
 set -x
-T=${1:-r03_e}
+T=${1:-r03_f}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$T
 mkdir -p $O
