@@ -42,14 +42,16 @@ __global__ void pack_patch_weights_kernel(const float* __restrict__ w, float* __
     }
 }
 
+// one 32-row half (row tile tm) of the wave's 64 rows: the staging tile holds 32 rows, so a 7x7x3 layer's 38 KB weight slab leaves room
+// for two blocks per CU (the 64-row staging made it 83 KB per block: one block, four waves per CU)
 template <int EPI>
-__device__ __forceinline__ void patch_rows(const PatchParams& p, const float* E, int b, int oy0, int ox0, int wm, int n, int rsub,
+__device__ __forceinline__ void patch_rows(const PatchParams& p, const float* E, int b, int oy0, int ox0, int wm, int tm, int n, int rsub,
                                            int c4, f32x4 bias, f32x4 ea, f32x4 eb) {
     constexpr int LDE = 32 + 4;
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {                   // 64 rows per wave, 8 rows per pass (8 lanes x float4 per row)
+    for (int it = 0; it < 4; ++it) {                   // 32 rows, 8 rows per pass (8 lanes x float4 per row)
         const int lrow = it * 8 + rsub;
-        const int m = wm * 64 + lrow;
+        const int m = wm * 64 + tm * 32 + lrow;
         const int oy = oy0 + m / TC, ox = ox0 + m % TC;
         const size_t o = ((size_t)(b * p.Hout + oy) * p.Wout + ox) * p.N + n;
         const f32x4 v = *(const f32x4*)(E + lrow * LDE + c4);
@@ -68,6 +70,12 @@ __device__ __forceinline__ void patch_rows(const PatchParams& p, const float* E,
 // staging has its own LDS area, so one barrier per tile is all the synchronisation there is.  (The one-tile-per-block
 // form spent half of every block's life re-loading the 19 KB weight slab and waiting for its own patch: 142 us for the
 // 64x64x3 -> 32x32x64 layer at batch 1024 against an MFMA floor of 65 us.)
+// FK > 0: the geometry of the reduction is fixed at compile time (K = FK = kh * kw * Cred, a tap row's run FRUN = kw * Cred, the
+// LDS patch pitch FPITCH): the lane's weight column lives in registers for the whole persistent block and every patch address is
+// one of two lane bases + an instruction immediate -- one ds_read_b32 per MFMA and nothing else in the loop, where the general
+// form (FK = 0) issues a weight read, a table look-up, two patch reads and an address add per MFMA pair (config 5's 7x7x3 stride-1
+// layers and its 4x4x3 stride-2 PatchGAN stem).
+template <int FK, int FRUN, int FPITCH>
 __global__ __launch_bounds__(256, 2) void conv_patch_kernel(PatchParams p, int tiles_total, int tiles_per_block) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int patch_f = p.PH * p.pitch;
@@ -75,7 +83,7 @@ __global__ __launch_bounds__(256, 2) void conv_patch_kernel(PatchParams p, int t
     float* Ps = smem + (size_t)p.Kp * PBN;               // [2][PH][pitch]
     int* koff_t = (int*)(Ps + (size_t)2 * patch_f);       // [Kp] patch offset of reduction index k
     constexpr int LDE = 32 + 4;
-    float* E = (float*)(koff_t + p.Kp) + (threadIdx.x >> 6) * 64 * LDE;     // this wave's [64 rows][32 cols (+4)] staging tile
+    float* E = (float*)(koff_t + p.Kp) + (threadIdx.x >> 6) * 32 * LDE;     // this wave's [32 rows][32 cols (+4)] staging tile (half its rows at a time)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, h = lane >> 5, j = lane & 31;
 
@@ -155,13 +163,26 @@ __global__ __launch_bounds__(256, 2) void conv_patch_kernel(PatchParams p, int t
     }
     const float* bcol = Bs + wn * 32 + j;
     const int c4 = (lane & 7) * 4, rsub = lane >> 3;
+    constexpr int FKP = (FK + 1) & ~1, FNS = FKP / 2;
+    constexpr bool WREG = FK > 0 && FNS <= 32;           // few steps: the lane's weight column in registers; else from the LDS slab at lane base + immediate
+    float bw[WREG ? FNS : 1];                            // this lane's weight column (k = 2 s + h), all steps
+    const float* bcol_h = bcol + h * PBN;
+    // FK > 0: k = 2 s + h sits at patch offset koff(2 s) + h, except where 2 s + 1 opens the next tap row: a second lane base
+    int rb1[2], rb2[2];
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) { rb1[tm] = rowbase[tm] + h; rb2[tm] = rowbase[tm] + h * (1 + FPITCH - FRUN); }
 
     for (int t = t_begin, it = 0; t < t_end; ++t, ++it) {
         if (n0 != cur_n0) {                              // (re)load the [Kp][PBN] weight slab of this n-tile: once per block when N <= 64
-            if (it > 0) __syncthreads();                 // every wave is done reading the old slab
-            for (int q = tid; q < p.Kp * (PBN / 4); q += 256) {
-                const int k = q / (PBN / 4), c = q - k * (PBN / 4);
-                ((f32x4*)Bs)[q] = *(const f32x4*)(p.wk + (size_t)k * p.Np + n0 + c * 4);
+            if constexpr (WREG) {
+#pragma unroll
+                for (int q = 0; q < FNS; ++q) bw[q] = p.wk[(size_t)(2 * q + h) * p.Np + n0 + wn * 32 + j];
+            } else {
+                if (it > 0) __syncthreads();             // every wave is done reading the old slab
+                for (int q = tid; q < p.Kp * (PBN / 4); q += 256) {
+                    const int k = q / (PBN / 4), c = q - k * (PBN / 4);
+                    ((f32x4*)Bs)[q] = *(const f32x4*)(p.wk + (size_t)k * p.Np + n0 + c * 4);
+                }
             }
             cur_n0 = n0;
         }
@@ -178,6 +199,23 @@ __global__ __launch_bounds__(256, 2) void conv_patch_kernel(PatchParams p, int t
         for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[tm][r] = 0.f;
+        if constexpr (FK > 0) {
+#pragma unroll
+            for (int s = 0; s < FNS; ++s) {
+                const int k0 = 2 * s < FK ? 2 * s : FK - 1;                       // (a padded k: zero weight, any valid patch element)
+                const int k1 = 2 * s + 1 < FK ? 2 * s + 1 : FK - 1;
+                const int ko0 = (k0 / FRUN) * FPITCH + k0 % FRUN;               // compile-time after unrolling
+                const int ko1 = (k1 / FRUN) * FPITCH + k1 % FRUN;
+                // lanes h = 0 read ko0; lanes h = 1 read ko1 = ko0 + 1 (same tap row), ko0 + 1 + FPITCH - FRUN (next row), or ko0 (padded)
+                const bool same = ko1 == ko0 + 1, pad = ko1 == ko0;
+                const float a0 = pad ? P[rowbase[0] + ko0] : same ? P[rb1[0] + ko0] : P[rb2[0] + ko0];
+                const float a1 = pad ? P[rowbase[1] + ko0] : same ? P[rb1[1] + ko0] : P[rb2[1] + ko0];
+                const float bv = WREG ? bw[WREG ? s : 0] : bcol_h[2 * s * PBN];
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv, acc[1], 0, 0, 0);
+                if ((s & 7) == 7) __builtin_amdgcn_sched_barrier(0);             // (bound the scheduler's look-ahead: it hoists every patch read otherwise)
+            }
+        } else {
 #pragma unroll 4
         for (int s = 0; s < p.Kp / 2; ++s) {
             const int k = 2 * s + h;
@@ -187,35 +225,39 @@ __global__ __launch_bounds__(256, 2) void conv_patch_kernel(PatchParams p, int t
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv, acc[0], 0, 0, 0);
             acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv, acc[1], 0, 0, 0);
         }
+        }
         if (more) STORE_PATCH((it + 1) & 1);
 
-        // epilogue through this wave's own staging tile (the same wave wrote it last tile and has finished reading it)
-#pragma unroll
-        for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) E[(tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * LDE + j] = acc[tm][r];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // epilogue through this wave's own staging tile, one 32-row half at a time (the same wave wrote it last and has finished reading it)
         const int n = n0 + wn * 32 + c4;
+        f32x4 bias = {0.f, 0.f, 0.f, 0.f}, ea = {1.f, 1.f, 1.f, 1.f}, eb = {0.f, 0.f, 0.f, 0.f};
         if (n < p.N) {
-            f32x4 bias = {0.f, 0.f, 0.f, 0.f}, ea = {1.f, 1.f, 1.f, 1.f}, eb = {0.f, 0.f, 0.f, 0.f};
             if (p.bias) bias = *(const f32x4*)(p.bias + n);
             if (p.epilogue == CGS_EPI_AFFINE_RELU) { ea = *(const f32x4*)(p.ep_a + n); eb = *(const f32x4*)(p.ep_b + n); }
             if (p.epilogue == CGS_EPI_RELU_BWD_AFFINE) ea = *(const f32x4*)(p.ep_a + n);
-            switch (p.epilogue) {
-                case CGS_EPI_NONE: patch_rows<CGS_EPI_NONE>(p, E, b, oy0, ox0, wm, n, rsub, c4, bias, ea, eb); break;
-                case CGS_EPI_LRELU: patch_rows<CGS_EPI_LRELU>(p, E, b, oy0, ox0, wm, n, rsub, c4, bias, ea, eb); break;
-                case CGS_EPI_AFFINE_RELU: patch_rows<CGS_EPI_AFFINE_RELU>(p, E, b, oy0, ox0, wm, n, rsub, c4, bias, ea, eb); break;
-                case CGS_EPI_TANH: patch_rows<CGS_EPI_TANH>(p, E, b, oy0, ox0, wm, n, rsub, c4, bias, ea, eb); break;
-                case CGS_EPI_RELU_BWD_AFFINE: patch_rows<CGS_EPI_RELU_BWD_AFFINE>(p, E, b, oy0, ox0, wm, n, rsub, c4, bias, ea, eb); break;
-                case CGS_EPI_LRELU_BWD: patch_rows<CGS_EPI_LRELU_BWD>(p, E, b, oy0, ox0, wm, n, rsub, c4, bias, ea, eb); break;
-                default: patch_rows<CGS_EPI_TANH_BWD>(p, E, b, oy0, ox0, wm, n, rsub, c4, bias, ea, eb); break;
-            }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // the next tile's staging writes must not pass these reads
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) E[((r & 3) + 8 * (r >> 2) + 4 * h) * LDE + j] = acc[tm][r];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (n < p.N) {
+                switch (p.epilogue) {
+                    case CGS_EPI_NONE: patch_rows<CGS_EPI_NONE>(p, E, b, oy0, ox0, wm, tm, n, rsub, c4, bias, ea, eb); break;
+                    case CGS_EPI_LRELU: patch_rows<CGS_EPI_LRELU>(p, E, b, oy0, ox0, wm, tm, n, rsub, c4, bias, ea, eb); break;
+                    case CGS_EPI_AFFINE_RELU: patch_rows<CGS_EPI_AFFINE_RELU>(p, E, b, oy0, ox0, wm, tm, n, rsub, c4, bias, ea, eb); break;
+                    case CGS_EPI_TANH: patch_rows<CGS_EPI_TANH>(p, E, b, oy0, ox0, wm, tm, n, rsub, c4, bias, ea, eb); break;
+                    case CGS_EPI_RELU_BWD_AFFINE: patch_rows<CGS_EPI_RELU_BWD_AFFINE>(p, E, b, oy0, ox0, wm, tm, n, rsub, c4, bias, ea, eb); break;
+                    case CGS_EPI_LRELU_BWD: patch_rows<CGS_EPI_LRELU_BWD>(p, E, b, oy0, ox0, wm, tm, n, rsub, c4, bias, ea, eb); break;
+                    default: patch_rows<CGS_EPI_TANH_BWD>(p, E, b, oy0, ox0, wm, tm, n, rsub, c4, bias, ea, eb); break;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // the next staging writes must not pass these reads
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
         if (more) { b = nb_; oy0 = noy0; ox0 = nox0; n0 = nn0; }
     }
 #undef TILE_DECODE
@@ -668,8 +710,8 @@ int cgs_conv_patch_launch(const CgsLayer& L, bool dirT, int B, const float* in, 
             hipLaunchKernelGGL(pack_patch_weights_kernel, dim3(cgs_ceil_div(p.Kp * p.Np, 256)), dim3(256), 0, s, w, ws, p.K, p.Kp, p.N, p.Np);
         CGS_CHECK_LAUNCH("pack_patch_weights");
     }
-    const size_t smem = ((size_t)p.Kp * PBN + (size_t)2 * p.PH * p.pitch + p.Kp + (size_t)4 * 64 * 36) * sizeof(float);
-    CGS_SMEM_ATTR(96 * 1024, "conv_patch", conv_patch_kernel);
+    const size_t smem = ((size_t)p.Kp * PBN + (size_t)2 * p.PH * p.pitch + p.Kp + (size_t)4 * 32 * 36) * sizeof(float);
+    CGS_SMEM_ATTR(96 * 1024, "conv_patch", conv_patch_kernel<0, 1, 1>);
     if (smem > 96 * 1024 || p.PH * p.PW * p.Cred > 10 * 256) return cgs_set_error(CGS_EINVAL, "conv_patch: patch too large");
     const long tiles = (long)B * (p.Hout / TR) * (p.Wout / TC) * (p.Np / PBN);
     if (tiles == 0) return CGS_OK;
@@ -679,8 +721,19 @@ int cgs_conv_patch_launch(const CgsLayer& L, bool dirT, int B, const float* in, 
     long per = (tiles + 511) / 512;
     if (per < 4) per = tiles >= 4 * 256 ? 4 : 1;
     const long blocks = (tiles + per - 1) / per;
-    hipLaunchKernelGGL(conv_patch_kernel, dim3((unsigned)blocks), dim3(256), smem, s, p, (int)tiles, (int)per);
+    // the two fixed geometries of config 5: 7x7x3 stride 1 (RGB stem, and the backward-data of the RGB head), 4x4x3 stride 2 (PatchGAN stem)
+    if (p.K == 147 && p.kw * p.Cred == 21 && p.pitch == 67) {
+        CGS_SMEM_ATTR(96 * 1024, "conv_patch <147>", conv_patch_kernel<147, 21, 67>);
+        hipLaunchKernelGGL((conv_patch_kernel<147, 21, 67>), dim3((unsigned)blocks), dim3(256), smem, s, p, (int)tiles, (int)per);
+        cgs_note_kernel("conv_patch_kernel<147, 21, 67>");
+    } else if (p.K == 48 && p.kw * p.Cred == 12 && p.pitch == 103) {
+        CGS_SMEM_ATTR(96 * 1024, "conv_patch <48>", conv_patch_kernel<48, 12, 103>);
+        hipLaunchKernelGGL((conv_patch_kernel<48, 12, 103>), dim3((unsigned)blocks), dim3(256), smem, s, p, (int)tiles, (int)per);
+        cgs_note_kernel("conv_patch_kernel<48, 12, 103>");
+    } else {
+        hipLaunchKernelGGL((conv_patch_kernel<0, 1, 1>), dim3((unsigned)blocks), dim3(256), smem, s, p, (int)tiles, (int)per);
+        cgs_note_kernel("conv_patch_kernel");
+    }
     CGS_CHECK_LAUNCH("conv_patch");
-    cgs_note_kernel("conv_patch_kernel");
     return CGS_OK;
 }

@@ -71,7 +71,7 @@ def test_stride1_rgb_layers_use_the_patch_kernel():
     d = dev()
     x, w, b = rnd((2, 16, 32, 3), 1), rnd((7, 7, 3, 64), 2, 0.05), rnd((64,), 3, 0.1)
     got = K.conv2d_fwd(x.to(d), w.to(d), b.to(d), 1, 1)
-    assert lib.last_kernel() == "conv_patch_kernel"
+    assert lib.last_kernel() == "conv_patch_kernel<147, 21, 67>"        # the fixed-geometry form of the 7x7x3 stride-1 reduction
     close(got, R.conv2d(x, w, b, 1, 1), 2e-5)
     xs = rnd((2, 16, 32, 64), 4).requires_grad_(True)
     w2 = rnd((7, 7, 64, 3), 5, 0.05)
@@ -79,8 +79,15 @@ def test_stride1_rgb_layers_use_the_patch_kernel():
     dy = rnd(tuple(y.shape), 6)
     (y * dy).sum().backward()
     got = K.conv2d_bwd_data(dy.to(d), w2.to(d), (16, 32), 1, 1)
-    assert lib.last_kernel() == "conv_patch_kernel"
+    assert lib.last_kernel() == "conv_patch_kernel<147, 21, 67>"
     close(got, xs.grad, 2e-5)
+    # the general form (geometry at run time) on a 5x5x3 stride-1 layer, and the PatchGAN stem's 4x4x3 stride-2 form, all fused epilogues
+    for k_, s_, name in ((5, 1, "conv_patch_kernel"), (4, 2, "conv_patch_kernel<48, 12, 103>")):
+        x, w, b = rnd((3, 16, 32, 3), 7), rnd((k_, k_, 3, 64), 8, 0.05), rnd((64,), 9, 0.1)
+        for epi, fn in ((lib.EPI_NONE, lambda t: t), (lib.EPI_LRELU, R.lrelu), (lib.EPI_TANH, torch.tanh)):
+            got = K.conv2d_fwd(x.to(d), w.to(d), b.to(d), s_, s_, epi)
+            assert lib.last_kernel() == name, lib.last_kernel()
+            close(got, fn(R.conv2d(x, w, b, s_, s_)), 2e-5)
 
 
 def test_conv2d_smalln_head_tanh():
