@@ -340,7 +340,7 @@ __device__ __forceinline__ void patch2_store_signs(const PatchParams& p, __amdgp
 // out with two v_readlane straight into a 64-bit lane mask: the epilogue stays in the ACCUMULATOR layout of the plain kernel
 // (no LDS transpose, one v_cndmask per element) and three blocks fit a CU again.
 template <int KH, int RP, int R, int PLD, int AUXM>     // R = kw * Cin floats per tap row (<= RP), PLD = patch floats per thread (ceil(PH * PW * Cin / 256))
-__global__ __launch_bounds__(256, AUXM == 1 ? 2 : 3) void conv_patch2_kernel(PatchParams p, int tiles_total, int tiles_per_block) {
+__global__ __launch_bounds__(256, AUXM == 1 ? 2 : 4) void conv_patch2_kernel(PatchParams p, int tiles_total, int tiles_per_block) {
     constexpr bool AUXP = AUXM != 0;
     constexpr int HALF = RP / 2, NQ = RP / 4, NS = KH * HALF;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -369,20 +369,27 @@ __global__ __launch_bounds__(256, AUXM == 1 ? 2 : 3) void conv_patch2_kernel(Pat
     const int rowf = p.PW * p.Cred;                      // valid floats per patch row
     const int rowlen = p.Win * p.Cred;
     // this thread's patch elements: (patch row, column) -> LDS offset and image offset relative to the tile's patch origin (loop invariant)
-    int l_pr[PLD], l_e[PLD], l_dst[PLD], l_src[PLD];
+    // Which of them fall outside the image depends on the tile only through "first / last tile row / column": four static flags per
+    // element, eight elements in one register (the rows and columns as separate registers were 16 VGPRs of the 21 that kept a fourth
+    // block off the CU).  An element past the patch (the last thread rows) carries all four flags AND no LDS slot.
+    int l_dst[PLD], l_src[PLD];
+    unsigned l_flags = 0;
     {
         const float inv_rowf = 1.0f / (float)rowf;
         const int total = p.PH * rowf;
+        const int row_lo = p.pt, row_hi = p.Hin - (p.S * (p.Hout - TR) - p.pt);            // patch rows < row_lo lie above the image in a first tile row, >= row_hi below it in a last one
+        const int col_lo = p.pl * p.Cred, col_hi = rowlen - (p.S * (p.Wout - TC) - p.pl) * p.Cred;
 #pragma unroll
         for (int u = 0; u < PLD; ++u) {
             const int q = tid + 256 * u;
             int pr = (int)((float)q * inv_rowf);
             if (pr * rowf > q) --pr;
             if ((pr + 1) * rowf <= q) ++pr;
-            l_pr[u] = q < total ? pr : -(1 << 20);       // far out of range: never loaded, never stored
-            l_e[u] = q - pr * rowf;
-            l_dst[u] = q < total ? pr * p.pitch + l_e[u] : -1;
-            l_src[u] = (pr * rowlen + l_e[u]) * 4;
+            const int e = q - pr * rowf;
+            l_dst[u] = q < total ? pr * p.pitch + e : -1;
+            l_src[u] = (pr * rowlen + e) * 4;
+            const unsigned f = q < total ? (unsigned)(pr < row_lo) | ((unsigned)(pr >= row_hi) << 1) | ((unsigned)(e < col_lo) << 2) | ((unsigned)(e >= col_hi) << 3) : 15u;
+            l_flags |= f << (4 * u);
         }
     }
     // the pad floats behind a patch row's rowf valid ones are read by the widened runs: keep them finite (zero) in both buffers
@@ -402,9 +409,11 @@ __global__ __launch_bounds__(256, AUXM == 1 ? 2 : 3) void conv_patch2_kernel(Pat
     do {                                                                                           \
         const int iy0_ = p.S * (oy0_) - p.pt, col0_ = (p.S * (ox0_) - p.pl) * p.Cred;              \
         const int org_ = (((b_) * p.Hin + iy0_) * rowlen + col0_) * 4;        /* scalar */          \
+        const unsigned edge_ = ((oy0_) == 0 ? 0x11111111u : 0u) | ((oy0_) == p.Hout - TR ? 0x22222222u : 0u) |       /* scalar */ \
+                               ((ox0_) == 0 ? 0x44444444u : 0u) | ((ox0_) == p.Wout - TC ? 0x88888888u : 0u) | 0u;   \
+        const unsigned bad_ = (l_flags & edge_) | (l_flags & (l_flags >> 1) & (l_flags >> 2) & (l_flags >> 3) & 0x11111111u);   /* (all four flags: no element) */ \
         _Pragma("unroll") for (int u = 0; u < PLD; ++u) {                                          \
-            const bool ok = (unsigned)(iy0_ + l_pr[u]) < (unsigned)p.Hin && (unsigned)(col0_ + l_e[u]) < (unsigned)rowlen; \
-            const unsigned off = ok ? (unsigned)(org_ + l_src[u]) : 0xFFFFFFF0u;                   \
+            const unsigned off = ((bad_ >> (4 * u)) & 15u) == 0u ? (unsigned)(org_ + l_src[u]) : 0xFFFFFFF0u; \
             pv[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, off, 0, 0)); \
         }                                                                                          \
     } while (0)
@@ -441,6 +450,9 @@ __global__ __launch_bounds__(256, AUXM == 1 ? 2 : 3) void conv_patch2_kernel(Pat
             if (p.epilogue == CGS_EPI_AFFINE_RELU) { ea1 = p.ep_a[nj]; eb1 = p.ep_b[nj]; }
             if (p.epilogue == CGS_EPI_RELU_BWD_AFFINE) ea1 = p.ep_a[nj];
         }
+        // AUXM != 1: the bias is one more k-step instead of the accumulators' start value (a 16-register splat that lived through the whole
+        // block): the first tap row's padding slot (run index R of lane half 1, zero on both operands otherwise) carries A = 1, B = bias
+        if constexpr (AUXM != 1 && R < RP) { if (h) bw[R - HALF] = bias1; }
         const unsigned rowstride = (unsigned)p.Wout * p.N * 4u;
         // lane part of an output offset: channel, the + 4 * h pixel shift of the accumulator layout, the wave's 4 tile rows
         const unsigned obase_l = (unsigned)(nj + 4 * h * p.N) * 4u + (unsigned)(wm * 4) * rowstride;
@@ -496,7 +508,7 @@ __global__ __launch_bounds__(256, AUXM == 1 ? 2 : 3) void conv_patch2_kernel(Pat
 #pragma unroll
             for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[tm][r] = bias1;
+                for (int r = 0; r < 16; ++r) acc[tm][r] = (AUXM != 1 && R < RP) ? 0.f : bias1;
 #pragma unroll
             for (int ky = 0; ky < KH; ++ky) {
                 f32x2 av[2][NQ];
@@ -507,7 +519,10 @@ __global__ __launch_bounds__(256, AUXM == 1 ? 2 : 3) void conv_patch2_kernel(Pat
 #pragma unroll
                 for (int sidx = 0; sidx < HALF; ++sidx) {
                     float a0 = av[0][sidx >> 1][sidx & 1], a1 = av[1][sidx >> 1][sidx & 1];
-                    if (sidx >= R - HALF) { a0 = h ? 0.f : a0; a1 = h ? 0.f : a1; }      // padding element of the run (compile-time sidx: one step per tap row)
+                    if (sidx >= R - HALF) {      // padding element of the run (compile-time sidx: one step per tap row); the first one is the bias step
+                        const float padv = (AUXM != 1 && ky == 0 && sidx == R - HALF) ? 1.f : 0.f;
+                        a0 = h ? padv : a0; a1 = h ? padv : a1;
+                    }
                     acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bw[ky * HALF + sidx], acc[0], 0, 0, 0);
                     acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bw[ky * HALF + sidx], acc[1], 0, 0, 0);
                 }
@@ -691,7 +706,7 @@ int cgs_conv_patch_launch(const CgsLayer& L, bool dirT, int B, const float* in, 
         const long tiles2 = (long)B * (p.Hout / TR) * (p.Wout / TC) * (p.Np / PBN);
         if (tiles2 == 0) return CGS_OK;
         if (tiles2 > 0x7fffffffL) return cgs_set_error(CGS_EINVAL, "conv_patch: grid too large");
-        const long slots = (auxp && !sgn) ? 512 : 768;          // persistent blocks: two (fp32 aux-prefetch form) or three per CU
+        const long slots = (auxp && !sgn) ? 512 : 1024;         // persistent blocks: two (fp32 aux-prefetch form) or four per CU
         long per2 = (tiles2 + slots - 1) / slots;
         if (per2 < 4) per2 = tiles2 >= 4 * 256 ? 4 : 1;
         const unsigned nblk2 = (unsigned)((tiles2 + per2 - 1) / per2);
