@@ -242,16 +242,22 @@ def profile_one_step(arch, P, B, G, Ksteps, rate, z1, dev, stream, by_layer=Fals
     from cgs_amd import kernels as K
     from cgs_amd.engine import RefineEngine
     eng = engine if engine is not None else RefineEngine(arch, P, B * G, dev, use_graph=False, sync_bn=sync_bn, bn_groups=G)
-    with torch.cuda.stream(stream):
-        eng.refine_from_z(z1, Ksteps, rate)                             # (untimed first pass: packs weights, sizes workspaces)
-    torch.cuda.synchronize(dev)
-    K.PROFILE, K.PROFILE_BY_LAYER = {}, by_layer
-    tp = time.perf_counter()
-    with torch.cuda.stream(stream):
-        eng.refine_from_z(z1, Ksteps, rate)
-    torch.cuda.synchronize(dev)
-    ms = (time.perf_counter() - tp) * 1e3
-    prof, K.PROFILE = K.PROFILE, None
+    # an engine of the timed region is launched eagerly here on the SAME buffers its hipGraph replays (a fresh engine's fresh
+    # allocations read the dominant kernel 4-5 % slower than the kernel table of the profiled runs: 702-718 against 678-684 us)
+    was_graph, eng.use_graph = eng.use_graph, False
+    try:
+        with torch.cuda.stream(stream):
+            eng.refine_from_z(z1, Ksteps, rate)                         # (untimed first pass: packs weights, sizes workspaces)
+        torch.cuda.synchronize(dev)
+        K.PROFILE, K.PROFILE_BY_LAYER = {}, by_layer
+        tp = time.perf_counter()
+        with torch.cuda.stream(stream):
+            eng.refine_from_z(z1, Ksteps, rate)
+        torch.cuda.synchronize(dev)
+        ms = (time.perf_counter() - tp) * 1e3
+        prof, K.PROFILE = K.PROFILE, None
+    finally:
+        eng.use_graph = was_graph
     return prof, ms
 
 
@@ -286,8 +292,8 @@ def other_configs(dev, skip, want_cpu):
         out[arch] = {"samples_per_s": round(B * G * steps / dt, 1), "batch": B, "refine_steps": Ksteps, "fused_per_launch": G,
                      "batches_in_flight": nf * G, "steps": steps, "hipgraph": True,
                      "algorithmic_tflops": round(B * G * steps / dt * nets.refine_flops_per_sample(arch, Ksteps) / 1e12, 2)}
+        prof, prof_ms = profile_one_step(arch, P, B, G, Ksteps, 0.1, z[0], dev, streams[0], engine=engines[0])
         del engines
-        prof, prof_ms = profile_one_step(arch, P, B, G, Ksteps, 0.1, z[0], dev, streams[0])
         roof, _, hbm, _ = profile_records(prof, prof_ms, 1e3 * dt / steps, "one extra eager single-stream step", False)
         roof.pop("note"); roof.pop("traffic"); roof.pop("traffic_over_algorithmic")
         out[arch]["roofline"] = roof
@@ -494,7 +500,7 @@ def main():
         # timed region would include the other stream's work; and a replayed hipGraph has no per-launch host hook.
         # Time ONE more step alone on one stream instead, launched eagerly (the same kernels with the same arguments).
         prof, prof_ms = profile_one_step(args.arch, P, B, G, Ksteps, args.rate, z[args.warmup], dev, streams[0], args.by_layer, sync,
-                                         engine=None if args.graph else engines[0])
+                                         engine=engines[0])
         prof_note = "HIP events around every launch of one extra single-stream step right after the timed region" + (" (launched eagerly; the timed region replays hipGraphs)" if args.graph else "")
     dist_rec = None
     if use_dist:
