@@ -494,8 +494,10 @@ def main():
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
     prof, K.PROFILE = K.PROFILE, None
+    # (this rank's last images, summed BEFORE the profiling step below re-uses engine 0 and its output buffer)
+    own_sum = float(last_img.double().sum().item()) if (use_dist and last_img is not None) else 0.0
     prof_ms, prof_note = dt * 1e3, "HIP events around every launch inside the timed region"
-    if rank == 0 and not live_profile:
+    if rank == 0 and not live_profile and not (args.sync_bn and world > 1):      # (synchronised batch norm: a step is a collective of ALL ranks)
         # several batches in flight: kernels of different streams overlap, so a per-launch duration taken inside the
         # timed region would include the other stream's work; and a replayed hipGraph has no per-launch host hook.
         # Time ONE more step alone on one stream instead, launched eagerly (the same kernels with the same arguments).
@@ -505,7 +507,6 @@ def main():
     dist_rec = None
     if use_dist:
         # what the collective layer really saw (all ranks take part in these two small all-gathers)
-        own_sum = float(last_img.double().sum().item()) if last_img is not None else 0.0
         rows = D.all_gather_floats([rank, dt_own, dt, 1.0 if args.graph else 0.0, own_sum], device=dev)
         dt = float(rows[:, 2].max())                                    # MAX over ranks of the barrier-to-barrier time
         if rank == 0:
