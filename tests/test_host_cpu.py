@@ -196,6 +196,34 @@ def test_c_abi_library_exports_every_declared_symbol():
     assert lib.bn_ws_bytes(1000, 128) > 0
 
 
+def test_group_statistics_layout_is_host_arithmetic():
+    """cgs_conv_stat_layout (include/cgs_hip.h): which partial rows of a *_fwd_stats call belong to a group of consecutive images follows
+    from the launch's row order alone -- no GPU call -- for the image-major and the pixel-major (whole 128-image tiles) orders, the
+    forward and the transposed direction; layouts a group does not own whole rows of are refused."""
+    import ctypes as C
+    from cgs_amd import lib
+    l = lib.load()
+    WS = 1 << 30
+
+    def layout(op, B, H, Cin, Ho, Cout, k, s, grp):
+        a, b, c = C.c_int(0), C.c_int(0), C.c_int(0)
+        rows = l.cgs_conv_stat_layout(op, B, H, H, Cin, Ho, Ho, Cout, k, k, s, s, grp, WS, C.addressof(a), C.addressof(b), C.addressof(c))
+        return (rows, a.value, b.value, c.value)
+    # PatchGAN conv at batch 8, one group per sample: rows (image, pixel): 256 pixels = 4 rows of 64 per sample, one segment
+    assert layout(lib.CONV_FWD, 8, 32, 32, 0, 64, 4, 2, 1) == (32, 4, 1, 32)
+    # transposed conv 16x16 -> 32x32: four parity classes of 256 pixels, a sample's 4 rows in each class, classes 32 rows apart
+    assert layout(lib.DECONV_FWD, 8, 16, 64, 32, 32, 3, 2, 1) == (128, 4, 4, 32)
+    # fused logical batches (4 x 64) of D's batch norm, pixel-major whole tiles: a row = 64 images of ONE of the 64 output pixels
+    assert layout(lib.CONV_FWD, 256, 16, 32, 0, 64, 5, 2, 64) == (256, 1, 64, 4)
+    # the whole batch as one group is always a valid grouping of an available layout
+    assert layout(lib.CONV_FWD, 256, 16, 32, 0, 64, 5, 2, 256) == (256, 4, 64, 4)
+    # refused: 9 pixels per sample; a logical batch of 32 under the pixel-major order; odd output (unequal parity classes); 3-channel family
+    assert layout(lib.CONV_FWD, 8, 6, 32, 0, 64, 3, 2, 1)[0] == 0
+    assert layout(lib.CONV_FWD, 256, 16, 32, 0, 64, 5, 2, 32)[0] == 0
+    assert layout(lib.DECONV_FWD, 8, 5, 32, 9, 64, 3, 2, 8)[0] == 0
+    assert layout(lib.CONV_FWD, 8, 32, 3, 0, 64, 5, 2, 1)[0] == 0
+
+
 def test_device_path_fails_loudly_without_gpu():
     if torch.cuda.is_available():
         pytest.skip("GPU present")
