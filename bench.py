@@ -51,7 +51,7 @@ HBM_OPS = {
     "linear_out1_fwd": ["linear_out1_fwd_kernel"],
     "linear_out1_bwd": ["linear_out1_bwd_kernel"],
 }
-# logical batches fused per launch by default (tools/sweep_fuse.sh on MI355X, two launches in flight: mnist 16 -> 24.3 k,
+# logical batches fused per launch by default (tools/sessions/r03_sweep_fuse.sh on MI355X, two launches in flight: mnist 16 -> 24.3 k,
 # 24 -> 26.1 k, 32 -> 26.3 k, 40 -> 27.1 k samples/s; dcgan32 4 -> 26.5 k, 6 -> 27.5 k, 8 -> 28.6 k): the tails and the per-launch
 # fixed costs of the ~13-27 GFLOP layers amortise over more rows
 # (config 5's instance norms have no batch coupling, so any number of samples per launch would be exact, but 8 / 16 / 32 / 64 rows x 4
@@ -209,6 +209,24 @@ def run_synthetic2d(dev, rank, B, Ksteps, rate, steps, warmup, n_streams):
     return time.perf_counter() - t0, (S, Ws, bs, x, real)
 
 
+def cpu_baseline_synthetic2d(S, Ws, bs, x, real, B, Ksteps, rate, reps=20):
+    """BASELINE config 1 on the host: oracle.refine_2d (refiner_cpu.manipulate_sample restated, torch-CPU D) on one of the timed batches."""
+    fake = x[0].cpu().numpy(); rb = real.cpu().numpy().astype(np.float64)
+    d_fn = lambda v: S.mlp_sigmoid_and_saliency(Ws, bs, v)
+    keep = torch.get_num_threads()
+    torch.set_num_threads(min(8, os.cpu_count() or 1))          # 64-wide MLP layers: more threads only add overhead
+    try:
+        S.refine_2d(fake, rb, d_fn, Ksteps, rate, "ladam")
+        t = time.time()
+        for _ in range(reps):
+            S.refine_2d(fake, rb, d_fn, Ksteps, rate, "ladam")
+        c = (time.time() - t) / reps
+        return {"value": round(B / c, 1), "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+                "sample": f"oracle.refine_2d (refiner_cpu.manipulate_sample restated; torch-CPU D), batch {B}, K={Ksteps}, {reps} reps"}
+    finally:
+        torch.set_num_threads(keep)
+
+
 def bench_synthetic2d(args, dev, rank, world):
     """BASELINE config 1: Imbal-8Gaussians MLP-GAN (D: 2 -> 64 x 5 -> 1), batch 512, K = 10, ladam rate 0.1
     (synthetic/main.py:32-62) -- the whole refiner_cpu loop as one launch per batch (cgs_amd.synthetic)."""
@@ -223,16 +241,7 @@ def bench_synthetic2d(args, dev, rank, world):
                                       f"real-batch baseline + fused K-step refine (3 launches per batch, no host synchronisation), {n_streams} batches in flight"},
                "roofline": None}
         if not args.no_cpu_baseline:
-            fake = x[0].cpu().numpy(); rb = real.cpu().numpy().astype(np.float64)
-            d_fn = lambda v: S.mlp_sigmoid_and_saliency(Ws, bs, v)
-            torch.set_num_threads(min(8, os.cpu_count() or 1))          # 64-wide MLP layers: more threads only add overhead
-            S.refine_2d(fake, rb, d_fn, Ksteps, args.rate, "ladam")
-            t = time.time(); reps = 20
-            for _ in range(reps):
-                S.refine_2d(fake, rb, d_fn, Ksteps, args.rate, "ladam")
-            c = (time.time() - t) / reps
-            out["cpu_baseline"] = {"value": round(B / c, 1), "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
-                                   "sample": f"oracle.refine_2d (refiner_cpu.manipulate_sample restated; torch-CPU D), batch {B}, K={Ksteps}, {reps} reps"}
+            out["cpu_baseline"] = cpu_baseline_synthetic2d(S, Ws, bs, x, real, B, Ksteps, args.rate)
         print(json.dumps(out), flush=True)
 
 
@@ -268,7 +277,8 @@ def other_configs(dev, skip, want_cpu):
     from cgs_amd import nets
     from cgs_amd.engine import RefineEngine
     out = {}
-    for arch, B, Ksteps, G, steps in (("mnist", 64, 50, FUSE["mnist"], 8), ("dcgan32", 256, 20, FUSE["dcgan32"], 8)):
+    for arch, B, Ksteps, G, steps in (("mnist", 64, 50, FUSE["mnist"], 8), ("dcgan32", 256, 20, FUSE["dcgan32"], 8),
+                                      ("cyclegan256", 8, 20, 1, 12)):          # (BASELINE config 5's per-GPU share: 64 over 8 GPUs)
         if arch == skip:
             continue
         A = nets.ARCHS[arch]
@@ -303,9 +313,63 @@ def other_configs(dev, skip, want_cpu):
         del z, P
         torch.cuda.empty_cache()
     if skip != "synthetic2d":
-        dt, _ = run_synthetic2d(dev, 0, 512, 10, 0.1, 256, 16, 8)
+        dt, (S, Ws, bs, x, real) = run_synthetic2d(dev, 0, 512, 10, 0.1, 256, 16, 8)
         out["synthetic2d"] = {"samples_per_s": round(512 * 256 / dt, 1), "batch": 512, "refine_steps": 10, "method": "ladam",
                               "batches_in_flight": 8, "steps": 256, "roofline": None}
+        if want_cpu:
+            out["synthetic2d"]["cpu_baseline"] = cpu_baseline_synthetic2d(S, Ws, bs, x, real, 512, 10, 0.1)
+    return out
+
+
+def class_surface(dev, configs=(("dcgan64", 1024, 20, 6, 3), ("mnist", 64, 50, 24, 4))):
+    """What a caller of the reference's CLASS SURFACE gets, as opposed to the engines the headline drives directly:
+    ``model.GAN`` + ``collaborator.Refiner`` wired with the very lines of nsgan/GAN.py:171-181 -- a ``functools.partial`` of the
+    discriminator and a local loss closure -- then per z batch ``input_to_feature`` (operator API) and ``build_refiner``: one batch
+    at a time on one stream, hipGraph replay (Refiner.use_graph's default).  ``generic``: the same wiring with the discriminator
+    wrapped in a lambda, which the engine detection cannot see through: the ops + torch.autograd loop (the same HIP kernels
+    launched one by one, nothing fused across layers).  Timed after and outside the headline's timed region."""
+    from functools import partial
+    from cgs_amd import nets, ops
+    from cgs_amd.model import GAN
+    from cgs_amd.sampling.collaborator import Refiner
+    out = {"wiring": "nsgan/GAN.py:171-181 verbatim: Refiner(K, rate).set_env(partial(gan.discriminator, is_training=True, reuse=True), "
+                     "gan.feature_to_data, <local BCE-vs-ones closure>); per batch gan.input_to_feature(z) + refiner.build_refiner(feature, "
+                     "inputs, 'deterministic'); one batch in flight, one stream"}
+    for arch, B, Ksteps, steps, gsteps in configs:
+        A = nets.ARCHS[arch]
+        ops.reset_variables()
+        self = GAN(arch, batch_size=B, device=dev, params=nets.init_params(arch, dev, seed=2019))
+        rollout_steps, rollout_rate = Ksteps, 0.1
+        discriminator_refine = partial(self.discriminator, is_training=True, reuse=True)
+
+        def loss_refine(logits):
+            return ops.sigmoid_cross_entropy_with_logits(logits=logits, labels=ops.ones_like(logits))
+        refiner = Refiner(rollout_steps=rollout_steps, rollout_rate=rollout_rate)
+        refiner.set_env(discriminator_refine, self.feature_to_data, loss_refine)
+        generic = Refiner(rollout_steps=rollout_steps, rollout_rate=rollout_rate)
+        generic.set_env(lambda x: self.discriminator(x, is_training=True, reuse=True), self.feature_to_data, loss_refine)
+        n = max(steps, gsteps) + 2
+        z = torch.from_numpy(np.random.RandomState(2019).uniform(-1, 1, (n, B) + nets.g_input_shape(A)).astype(np.float32)).to(dev)
+        inputs = torch.empty((B,) + tuple(A["img"]), dtype=torch.float32, device=dev).uniform_(-1, 1)
+        rec = {"batch": B, "refine_steps": Ksteps}
+        for name, r, k in (("engine", refiner, steps), ("generic", generic, gsteps)):
+            with torch.no_grad():
+                for i in range(2):                                   # first call: packs, sizes workspaces, captures the graph
+                    r.build_refiner(self.input_to_feature(z[i]), inputs, mode="deterministic")
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                for i in range(2, 2 + k):
+                    r.build_refiner(self.input_to_feature(z[i]), inputs, mode="deterministic")
+                torch.cuda.synchronize(dev)
+            dt = time.perf_counter() - t0
+            rec[name] = {"samples_per_s": round(B * k / dt, 1), "ms_per_batch": round(1e3 * dt / k, 3), "steps": k, "path": r.path,
+                         "hipgraph": bool(r.use_graph) if r.path == "engine" else False}
+            if r.graph_fallback:
+                rec[name]["hipgraph_fallback"] = r.graph_fallback
+        out[arch] = rec
+        del self, refiner, generic, z, inputs
+        ops.reset_variables()
+        torch.cuda.empty_cache()
     return out
 
 
@@ -496,13 +560,15 @@ def main():
     prof, K.PROFILE = K.PROFILE, None
     # (this rank's last images, summed BEFORE the profiling step below re-uses engine 0 and its output buffer)
     own_sum = float(last_img.double().sum().item()) if (use_dist and last_img is not None) else 0.0
-    prof_ms, prof_note = dt * 1e3, "HIP events around every launch inside the timed region"
+    prof_ms, prof_note, prof_wall_s = dt * 1e3, "HIP events around every launch inside the timed region", None
     if rank == 0 and not live_profile and not (args.sync_bn and world > 1):      # (synchronised batch norm: a step is a collective of ALL ranks)
         # several batches in flight: kernels of different streams overlap, so a per-launch duration taken inside the
         # timed region would include the other stream's work; and a replayed hipGraph has no per-launch host hook.
         # Time ONE more step alone on one stream instead, launched eagerly (the same kernels with the same arguments).
+        t_prof = time.perf_counter()
         prof, prof_ms = profile_one_step(args.arch, P, B, G, Ksteps, args.rate, z[args.warmup], dev, streams[0], args.by_layer, sync,
                                          engine=engines[0])
+        prof_wall_s = time.perf_counter() - t_prof       # (ranks 1.. wait in the all-gather below meanwhile: must stay far below the collective timeout)
         prof_note = "HIP events around every launch of one extra single-stream step right after the timed region" + (" (launched eagerly; the timed region replays hipGraphs)" if args.graph else "")
     dist_rec = None
     if use_dist:
@@ -543,6 +609,8 @@ def main():
         if graph_fallback:
             out["config"]["hipgraph_fallback"] = graph_fallback
         if dist_rec is not None:
+            if prof_wall_s is not None:
+                dist_rec["rank0_profile_step_wall_s"] = round(prof_wall_s, 3)
             out["dist"] = dist_rec
         ns = n_flight
         if len(done_ev) >= 3 * ns:   # SURVEY.md 8d "median of >= 10": median gap between a stream's consecutive step completions
@@ -556,6 +624,7 @@ def main():
         cpu = cpu_baseline(args.arch, Ksteps, args.rate) if world == 1 and not args.no_cpu_baseline else None   # (calibrates the host thread count)
         if world == 1 and not args.no_other_configs:
             out["other_configs"] = other_configs(dev, args.arch, not args.no_cpu_baseline)
+            out["class_surface"] = class_surface(dev)
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)

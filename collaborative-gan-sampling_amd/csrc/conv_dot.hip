@@ -74,7 +74,8 @@ __global__ __launch_bounds__(256) void conv_dot_kernel(DotParams p, long pixels)
 
 // forward direction, <= 4 output channels, whole float4 of input channels, a reduction deep enough that a wave per pixel pays
 int cgs_conv_dot_ok(const CgsLayer& L, int epilogue) {
-    return L.Cs <= 4 && (L.Cb % 4) == 0 && (long)L.kh * L.kw * L.Cb >= 1024 && epilogue < CGS_EPI_RELU_BWD_AFFINE;
+    return L.Cs <= 4 && (L.Cb % 4) == 0 && (long)L.kh * L.kw * L.Cb >= 1024 && epilogue < CGS_EPI_RELU_BWD_AFFINE
+        && L.sh == L.sw;                                              // (the kernel carries one stride for both axes)
 }
 
 int cgs_conv_dot_launch(const CgsLayer& L, int B, const float* in, const float* w, const float* bias, float* out, int epilogue,

@@ -487,7 +487,10 @@ __global__ __launch_bounds__(256, AUXM == 1 ? 2 : 4) void conv_patch2_kernel(Pat
             if constexpr (AUXM == 2) {
                 // lane L <-> pixel (tile row wm * 4 + L / 16, column L % 16) of the wave's 64 pixels, plane of its 32-channel group
                 const unsigned pixw = (unsigned)((b * p.Hout + oy0 + wm * 4 + (lane >> 4)) * p.Wout + ox0 + (lane & 15));
-                sgw = __builtin_amdgcn_raw_buffer_load_b32(sg_rsrc, pixw * 4u, (unsigned)((n0 >> 5) + wn) * sg_plane_b, 0);
+                // (the plane index rides in the s_offset, which the descriptor's range check does not cover: a wave whose 32-channel
+                // group lies in the padding of N -- N = 32, 96 -- must not load, its word would come from past the mask)
+                if ((n0 >> 5) + wn < (p.N >> 5))
+                    sgw = __builtin_amdgcn_raw_buffer_load_b32(sg_rsrc, pixw * 4u, (unsigned)((n0 >> 5) + wn) * sg_plane_b, 0);
             } else if constexpr (AUXM == 1) {
                 const unsigned ab = tile_off + (unsigned)(n0 + wn * 32 + c4) * 4u + (unsigned)(wm * 4) * rowstride;
 #pragma unroll

@@ -638,10 +638,12 @@ int cgs_convt_quad_launch(const CgsLayer& L, int B, const float* in, const float
     quad_range(L.kw, pl, p.dmin_x, hx);
     p.ny = hy - p.dmin_y + 1; p.nx = hx - p.dmin_x + 1;
     if ((long)B * L.Hs * L.Ws * L.Cs * 4 > 0x7fffffffL) return cgs_set_error(CGS_EINVAL, "convt_quad: input exceeds 2 GiB (split the batch)");
+    // the taps kernel reads the raw weights and the input as float4: a view at an unaligned offset keeps the packed rows / quad forms below
+    const bool taps_aligned = !(((uintptr_t)w | (uintptr_t)in) & 15);
 #ifdef CGS_EXPERIMENT
-    if (cgs_convt_taps_ok(L) && !getenv("CGS_NO_TAPS")) return cgs_convt_taps_launch(L, B, in, w, bias, out, epilogue, ep_a, ep_aux, s);
+    if (cgs_convt_taps_ok(L) && taps_aligned && !getenv("CGS_NO_TAPS")) return cgs_convt_taps_launch(L, B, in, w, bias, out, epilogue, ep_a, ep_aux, s);
 #else
-    if (cgs_convt_taps_ok(L)) return cgs_convt_taps_launch(L, B, in, w, bias, out, epilogue, ep_a, ep_aux, s);      // (reads the unpacked weights)
+    if (cgs_convt_taps_ok(L) && taps_aligned) return cgs_convt_taps_launch(L, B, in, w, bias, out, epilogue, ep_a, ep_aux, s);      // (reads the unpacked weights)
 #endif
     if (const int mt = rows_mt(L)) {
         RowsParams r;

@@ -244,7 +244,9 @@ __global__ __launch_bounds__(256) void conv_taps_kernel(TapsFParams p, int tiles
         unsigned sgw = 0;
         if constexpr (AUXM == 2) {       // lane L <-> (tile tn = L >> 5, pixel m0 + (L & 31)): word of that pixel in plane tn
             const unsigned pm = m0 + (unsigned)j;
-            if (h < NT) sgw = __builtin_amdgcn_raw_buffer_load_b32(sg_rsrc, pm * 4u, (unsigned)h * (unsigned)(M * 4), 0);
+            // (the plane offset rides in the s_offset, outside the descriptor's range check: predicate on the plane AND on the pixel
+            // of a ragged last tile, or the last plane's load runs past the mask)
+            if (h < NT && pm < (unsigned)M) sgw = __builtin_amdgcn_raw_buffer_load_b32(sg_rsrc, pm * 4u, (unsigned)h * (unsigned)(M * 4), 0);
         }
         f32x16 acc[NT];
 #pragma unroll
@@ -259,7 +261,8 @@ __global__ __launch_bounds__(256) void conv_taps_kernel(TapsFParams p, int tiles
         unsigned nw[2] = {0u, 0u};       // un-shuffled sign words (bit c <-> channel c): [0] tiles 0 / 1 (lane halves), [1] tiles 2 / 3
         if constexpr (AUXM == 2) {
             unsigned w2 = 0;
-            if (NT > 2) w2 = __builtin_amdgcn_raw_buffer_load_b32(sg_rsrc, (m0 + (unsigned)j) * 4u, (unsigned)(h + 2) * (unsigned)(M * 4), 0);
+            if (h + 2 < NT && m0 + (unsigned)j < (unsigned)M)
+                w2 = __builtin_amdgcn_raw_buffer_load_b32(sg_rsrc, (m0 + (unsigned)j) * 4u, (unsigned)(h + 2) * (unsigned)(M * 4), 0);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 unsigned t8 = (sgw >> (8 * e)) & 0xffu, u8 = (w2 >> (8 * e)) & 0xffu;

@@ -1126,7 +1126,7 @@ int cgs_igemm_launch(const IgemmParams& p_in, void* slab, size_t slab_bytes, hip
     // pipe's gaps; the epilogue stages half a wave tile at a time to fit) win 2.5-9 % when every parity class brings at
     // least two blocks per CU, and lose up to 11 % on smaller grids, where a CU holds one block and the doubled barrier
     // count per FLOP is all that is left of the change (measured per layer, 40 launches each, dcgan64 / dcgan32 / config 5).
-    // Mid-size grids (round 3, measured per layer on config 5's PatchGAN / up-sampling layers at batch 8, tools/ab_tmp.sh): a launch
+    // Mid-size grids (round 3, measured per layer on config 5's PatchGAN / up-sampling layers at batch 8, a same-session A/B of tools/layer_bench.py): a launch
     // of 256..511 blocks of 128x128 leaves half of the 512 block slots of the 32-deep form empty (one block per CU: nobody hides
     // its barrier and load latencies) -- as 128x64 blocks it fills them: 64x64 128<-256 85 -> 75 us, 128x128 64->128 88 -> 77 us,
     // 32x32 256->512 302 -> 265 us (not for grids < 256 blocks, which are split over K instead: 32x32 256<-512 272 -> 295 us)

@@ -377,3 +377,40 @@ def linear(input_, output_size, scope=None, stddev=0.02, bias_start=0.0, with_w=
 def sigmoid_cross_entropy_with_logits_ones(logits):
     """tf.nn.sigmoid_cross_entropy_with_logits(logits, labels=ones), unreduced (nsgan/GAN.py:176-177)."""
     return _BceOnes.apply(logits)
+
+
+class _Constant(object):
+    """``ones_like`` / ``zeros_like`` of the label argument below: a constant that is never materialised."""
+
+    def __init__(self, value, like):
+        self.value, self.shape = float(value), tuple(like.shape)
+
+
+def ones_like(x):
+    """tf.ones_like(x) as a label constant (nsgan/GAN.py:177)."""
+    return _Constant(1.0, x)
+
+
+def zeros_like(x):
+    """tf.zeros_like(x) as a label constant (nsgan/GAN.py:129)."""
+    return _Constant(0.0, x)
+
+
+def sigmoid_cross_entropy_with_logits(_sentinel=None, labels=None, logits=None, name=None):
+    """tf.nn.sigmoid_cross_entropy_with_logits(labels=, logits=), unreduced: max(x, 0) - x z + log(1 + exp(-|x|)).
+    Keyword arguments only, as in TF.  ``labels`` = ``ones_like(logits)`` (the refiner's loss, nsgan/GAN.py:176-177) is one
+    kernel forward and one backward (``cgs_bce_ones_fwd / _bwd``); zeros is the same kernel on -x; a label TENSOR z adds
+    (1 - z) x to the all-ones form (elementwise torch arithmetic: not on the refinement path)."""
+    if _sentinel is not None or labels is None or logits is None:
+        raise ValueError("Only call `sigmoid_cross_entropy_with_logits` with named arguments (labels=..., logits=...)")
+    if isinstance(labels, _Constant):
+        if labels.shape != tuple(logits.shape):
+            raise ValueError(f"logits and labels must have the same shape ({tuple(logits.shape)} vs {labels.shape})")
+        if labels.value == 1.0:
+            return _BceOnes.apply(logits)
+        if labels.value == 0.0:
+            return _BceOnes.apply(-logits)
+        labels = torch.full_like(logits, labels.value)
+    if tuple(labels.shape) != tuple(logits.shape):
+        raise ValueError(f"logits and labels must have the same shape ({tuple(logits.shape)} vs {tuple(labels.shape)})")
+    return _BceOnes.apply(logits) + (1.0 - labels) * logits

@@ -5,19 +5,24 @@ Same constructor, ``set_env`` / ``set_constraints`` / ``compute_forward_logits_a
 ``optimal_step``, ``optimal_feature``).  The reference's ``build_refiner`` emits a K-times unrolled
 TF graph that a later ``sess.run`` executes; here it executes: it returns the refined images.
 
-Execution paths (both all-HIP, no CPU fallback):
-  * engine:  if ``discriminator`` / ``feature_to_data`` are the bound methods of a ``cgs_amd.model.GAN``
-             and ``func_loss`` its ``loss_refine``, the whole loop runs as the fused device program
-             (``engine.RefineEngine``): state resident in HBM, no host sync, optional hipGraph replay.
-  * generic: any callables built from ``cgs_amd.ops``; the loop below differentiates them with
+Execution paths (both all-HIP, no CPU fallback; ``refiner.path`` says which one the last call took):
+  * engine:  if ``discriminator`` / ``feature_to_data`` are a ``cgs_amd.model.GAN``'s own methods -- bound, or wrapped
+             in ``functools.partial`` the way nsgan/GAN.py:174-175 wraps them -- and ``func_loss`` computes the
+             cross entropy against ones (GAN.loss_refine, or any closure that evaluates to softplus(-logit), :176-177),
+             the whole loop runs as the fused device program (``engine.RefineEngine``): state resident in HBM, no host
+             sync, the K-step program replayed as a hipGraph (``use_graph``, default on; eager fallback in-process).
+  * generic: any other callables built from ``cgs_amd.ops``; the loop below differentiates them with
              ``torch.autograd`` (each op's backward-data is a HIP kernel) and applies the fused
              update / select kernels.
 """
+import functools
+
 import numpy as np
 import torch
 
 from .policy import PolicyAdaptive
 from .. import kernels as K
+from .. import lib as L
 
 
 class Refiner():
@@ -27,7 +32,11 @@ class Refiner():
         self.log = False
         self.vmin = None
         self.vmax = None
-        self.use_graph = False          # engine path: capture the K-step program into a hipGraph
+        self.use_graph = True           # engine path: the K-step program is captured into a hipGraph at the first call of a
+                                        # (batch, K, rate, mode) and replayed afterwards; a refused capture falls back to eager
+                                        # launches in the same process (``graph_fallback`` then holds the reason)
+        self.graph_fallback = None
+        self.path = None                # "engine" | "generic": which execution form the last build_refiner took
         self.indices_batch = None       # last probabilistic draw
 
     def set_env(self, discriminator, feature_to_data, func_loss):
@@ -53,18 +62,78 @@ class Refiner():
         return K.bce_ones_grad_rowmean(flat)[1], forward_grad                        # per-sample mean logit (:34-37)
 
     # -- engine detection ------------------------------------------------------------------------
-    def _engine_for(self, batch):
+    @staticmethod
+    def _unwrap(fn, allowed):
+        """A bound method, or a ``functools.partial`` of one with keyword arguments only (nsgan/GAN.py:174-175 hands the refiner
+        ``partial(self.discriminator, is_training=True, reuse=True)``) -> (owner, plain function, keywords); None otherwise."""
+        kw = {}
+        while isinstance(fn, functools.partial):
+            if fn.args:
+                return None
+            kw = dict(fn.keywords or {}, **kw)
+            fn = fn.func
+        owner, func = getattr(fn, "__self__", None), getattr(fn, "__func__", None)
+        if owner is None or func is None or not set(kw) <= set(allowed):
+            return None
+        return owner, func, kw
+
+    _BCE_PROBE = {}            # id(func_loss) -> (weak reference or the function itself, verdict)
+
+    @classmethod
+    def _loss_is_bce_ones(cls, func_loss, device):
+        """Is ``func_loss`` the unreduced cross entropy against all-ones labels, softplus(-logit) (nsgan/GAN.py:176-177)?  The
+        reference passes a local closure, so identity cannot tell: the function is evaluated ONCE on 16 fixed logits and compared
+        with softplus(-l) to 1e-6 (shape kept = no reduction).  Anything else -- another loss, a reduction, an exception -- keeps
+        the generic path, which differentiates whatever it is."""
         from ..model import GAN
-        owner = getattr(self.discriminator, "__self__", None)
-        if not isinstance(owner, GAN) or getattr(self.feature_to_data, "__self__", None) is not owner:
+        if func_loss is GAN.loss_refine:
+            return True
+        hit = cls._BCE_PROBE.get(id(func_loss))
+        if hit is not None and hit[0] is func_loss:
+            return hit[1]
+        ok = False
+        try:
+            l = np.linspace(-12.0, 12.0, 16, dtype=np.float32).reshape(16, 1)
+            with torch.no_grad():
+                got = func_loss(torch.from_numpy(l).to(device))
+            want = np.logaddexp(0.0, -l.astype(np.float64))
+            ok = (torch.is_tensor(got) and tuple(got.shape) == (16, 1)
+                  and bool(np.abs(got.detach().double().cpu().numpy() - want).max() < 1e-6))
+        except Exception:                                   # noqa: BLE001 (a loss that cannot take a [16, 1] tensor is not this one)
+            ok = False
+        cls._BCE_PROBE[id(func_loss)] = (func_loss, ok)
+        return ok
+
+    def _engine_owner(self):
+        """The ``model.GAN`` whose layer lists ARE the three callables of ``set_env`` -- in any of the spellings the reference's
+        wiring allows (the bound methods, ``functools.partial`` of them, a BCE-vs-ones closure) -- or None."""
+        from ..model import GAN
+        d = self._unwrap(self.discriminator, ("is_training", "reuse"))
+        f = self._unwrap(self.feature_to_data, ("is_training",))
+        if d is None or f is None:
             return None
-        if getattr(self.discriminator, "__func__", None) is not GAN.discriminator_refine:
+        owner = d[0]
+        if not isinstance(owner, GAN) or f[0] is not owner:
             return None
-        if getattr(self.feature_to_data, "__func__", None) is not GAN.feature_to_data or self.func_loss is not GAN.loss_refine:
+        if d[1] is GAN.discriminator_refine:
+            if d[2]:
+                return None
+        elif d[1] is GAN.discriminator:
+            if d[2].get("is_training", True) is not True:   # (GAN.discriminator's default; the engine's D runs batch-statistics bn)
+                return None
+        else:
+            return None
+        if f[1] is not GAN.feature_to_data or f[2].get("is_training", False) is not False:
             return None
         if self.optimizer.method not in ("momentum", "sgd"):
             return None
-        return owner.engine(batch, use_graph=self.use_graph)
+        if not self._loss_is_bce_ones(self.func_loss, owner.device):
+            return None
+        return owner
+
+    def _engine_for(self, batch):
+        owner = self._engine_owner()
+        return None if owner is None else owner.engine(batch, use_graph=self.use_graph)
 
     def build_refiner(self, fake_feature, real_batch, mode='deterministic', indices=None):
         """collaborator.py:41-88.  ``real_batch`` only feeds statistics the reference computes and never
@@ -77,11 +146,27 @@ class Refiner():
         elif mode != 'deterministic':
             raise NotImplementedError
 
-        eng = self._engine_for(B)
-        if eng is not None:
-            img, d_l, o_l, o_s, o_f = eng.refine(fake_feature, K_steps, self.optimizer.lambda_, self.optimizer.method,
-                                                 mode, self.indices_batch if mode == 'probabilistic' else None,
-                                                 self.vmin, self.vmax)
+        owner = self._engine_owner()
+        if owner is not None:
+            self.path = "engine"
+            args = (fake_feature, K_steps, self.optimizer.lambda_, self.optimizer.method, mode,
+                    self.indices_batch if mode == 'probabilistic' else None, self.vmin, self.vmax)
+            try:
+                out = owner.engine(B, use_graph=self.use_graph).refine(*args)
+            except L.CgsError:
+                raise                                             # an argument error, not a capture failure
+            except Exception as ex:                               # noqa: BLE001 (hipGraph capture refused: HIP, allocator, another thread's HIP call)
+                if not self.use_graph:
+                    raise
+                # same process, same engine code, launched kernel by kernel instead; the refiner stays eager from here on and says why
+                self.graph_fallback = f"{type(ex).__name__}: {str(ex)[:300]}"
+                self.use_graph = False
+                try:
+                    torch.cuda.synchronize(fake_feature.device)
+                except Exception:                                 # noqa: BLE001
+                    pass
+                out = owner.engine(B, use_graph=False).refine(*args)
+            img, d_l, o_l, o_s, o_f = out
             # the engine returns its own (cached, reused) buffers: hand out copies, so that a second build_refiner -- the
             # reference builds a deterministic and a probabilistic refiner side by side, nsgan/GAN.py:182-183 -- does not
             # overwrite the first one's results in place
@@ -91,6 +176,7 @@ class Refiner():
             return img.clone()
 
         # ---- generic path -----------------------------------------------------------------------
+        self.path = "generic"
         self.current_feature = fake_feature.detach().clone().contiguous()
         self.current_logit, self.forward_grad = self.compute_forward_logits_and_grad(self.current_feature)
         self.default_logit = self.current_logit

@@ -44,9 +44,18 @@ def test_bench_line_small_config():
     assert 0 < r["step_executed_frac"] <= 1.0
     for h in d["hbm"].values():
         assert 0 < h["frac"] <= 1.0 and h["unit"] == "GB/s" and h["algorithmic_bytes"] > 0
+    # every BASELINE workload that fits one GPU is in the line: the headline + dcgan32, dcgan64-or-mnist, cyclegan256, synthetic2d
+    assert set(d["other_configs"]) == {"dcgan32", "cyclegan256", "synthetic2d"}
     for name, o in d["other_configs"].items():
+        assert o["samples_per_s"] > 0 and o["cpu_baseline"]["value"] > 0 and o["cpu_baseline"]["cores"] >= 1
         if name != "synthetic2d":
-            assert 0 < o["roofline"]["frac"] <= 1.0 and o["cpu_baseline"]["value"] > 0
+            assert 0 < o["roofline"]["frac"] <= 1.0 and 0 < o["roofline"]["step_executed_frac"] <= 1.0 and o["hbm"]
+    # the class surface: the reference's verbatim wiring reaches the fused engine; the opaque-callable form stays generic
+    cs = d["class_surface"]
+    for arch in ("dcgan64", "mnist"):
+        e, g = cs[arch]["engine"], cs[arch]["generic"]
+        assert e["path"] == "engine" and e["hipgraph"] is True and "hipgraph_fallback" not in e and g["path"] == "generic"
+        assert e["samples_per_s"] > g["samples_per_s"] > 0
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
 
@@ -127,6 +136,28 @@ def test_two_ranks_on_the_one_gpu_through_the_whole_multi_rank_path():
                           "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--arch", "mnist"],
                          cwd=ROOT, capture_output=True, text=True, timeout=300, env=env)
     assert bad.returncode != 0 and "WORLD_SIZE=1" in (bad.stderr + bad.stdout)
+
+
+def test_two_ranks_on_the_one_gpu_with_the_drivers_own_workload():
+    """the first 8-GPU run is the driver's `bench.py --gpus N` with the dcgan64 DEFAULT workload (batch 1024 per rank,
+    K = 20, hipGraph x 2 in flight).  The same command at world 2 on the one GPU: graphs captured on every rank with RCCL-free gloo
+    threads around, no eager fallback, rank 0's extra profiling step (the other rank waits for it inside an all-gather) far below
+    the collective timeout."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("RANK", None); env.pop("WORLD_SIZE", None); env.pop("MASTER_ADDR", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu",
+                          "--steps", "3", "--warmup", "1", "--no-cpu-baseline"], cwd=ROOT, capture_output=True, text=True, timeout=1200, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and "dcgan64" in d["config"]["workload"] and d["config"]["global_batch"] == 2048 and d["config"]["refine_steps"] == 20
+    assert d["config"]["hipgraph"] is True and "hipgraph_fallback" not in d["config"]
+    x = d["dist"]
+    assert x["world_size"] == 2 and x["ranks_seen"] == 2 and x["hipgraph_ranks"] == 2
+    assert x["pool_bytes"] == 2 * 1024 * 64 * 64 * 3 * 4 and x["pool_rows_match_ranks"] is True and x["pool_rank_sums_distinct"] is True
+    assert 0 < x["rank0_profile_step_wall_s"] < 5.0
+    assert 0 < d["roofline"]["frac"] <= 1.0 and "igemm" in d["roofline"]["kernel"]
 
 
 def test_gather_pool_on_rccl_world1_goes_through_the_collective():

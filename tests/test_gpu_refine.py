@@ -149,6 +149,129 @@ def test_refiner_class_generic_and_engine_paths(path):
     ops.reset_variables()
 
 
+@pytest.mark.parametrize("path", G3, ids=lambda p: os.path.basename(p)[10:-4])
+def test_reference_verbatim_wiring_takes_the_engine(path):
+    """The four lines of nsgan/GAN.py:174-181 written against cgs_amd exactly as the reference writes them -- a
+    ``functools.partial`` of the discriminator and a LOCAL loss closure -- must reach the fused engine, replay its
+    hipGraph from the second call on, and reproduce every reference golden."""
+    from functools import partial
+    from cgs_amd import ops
+    from cgs_amd.model import GAN
+    from cgs_amd.sampling.collaborator import Refiner
+    g, arch, P, vmin, vmax = load_case(path)
+    d = dev()
+    ops.reset_variables()
+    self = GAN(arch, batch_size=len(g["z"]), device=d, params=P)
+    rollout_steps, rollout_rate = int(g["K"][0]), float(g["rate"][0])
+    # ---- nsgan/GAN.py:174-181 ------------------------------------------------------------------
+    discriminator_refine = partial(self.discriminator, is_training=True, reuse=True)
+    def loss_refine(logits):
+        return ops.sigmoid_cross_entropy_with_logits(logits=logits, labels=ops.ones_like(logits))
+    refiner = Refiner(rollout_steps=rollout_steps, rollout_rate=rollout_rate)
+    refiner.set_env(discriminator_refine, self.feature_to_data, loss_refine)
+    # ---------------------------------------------------------------------------------------------
+    if vmin is not None:
+        refiner.set_constraints(vmin, vmax)
+    mode = str(g["mode"][0])
+    idx = g["indices"] if mode == "probabilistic" else None
+    f0 = torch.from_numpy(golden_feature0(g, arch, P)).to(d)
+    real = torch.from_numpy(g["real"]).to(d)
+    for call in range(2):                                                   # the second call replays the captured graph
+        img = refiner.build_refiner(f0, real, mode, indices=idx)
+        assert refiner.path == "engine" and refiner.use_graph and refiner.graph_fallback is None
+        check_against_golden(g, img, refiner.default_logit, refiner.optimal_logit, refiner.optimal_step, refiner.optimal_feature,
+                             oracle_render=lambda f: N.feature_to_data(arch, P, f))
+    assert len(self.engine(len(f0), use_graph=True)._graphs) == 1
+    ops.reset_variables()
+
+
+def test_engine_detection_accepts_only_what_the_engine_computes():
+    """Which set_env arguments select the fused engine: the GAN's own methods in every spelling of the reference's wiring, a loss
+    that IS softplus(-logit); everything else stays on the generic path (and ``path`` says so)."""
+    from functools import partial
+    from cgs_amd import ops
+    from cgs_amd.model import GAN
+    from cgs_amd.sampling.collaborator import Refiner
+    d = dev()
+    ops.reset_variables()
+    gan = GAN("mnist", batch_size=4, device=d, params=N.init_params("mnist", 2019, True))
+    other = GAN("mnist", batch_size=4, device=d)
+    bce = lambda l: ops.sigmoid_cross_entropy_with_logits(labels=ops.ones_like(l), logits=l)
+
+    def owner(dfn, ffn, loss, method="momentum"):
+        r = Refiner(2, 0.1, method)
+        r.set_env(dfn, ffn, loss)
+        return r._engine_owner()
+    D = partial(gan.discriminator, is_training=True, reuse=True)
+    assert owner(D, gan.feature_to_data, bce) is gan
+    assert owner(gan.discriminator_refine, gan.feature_to_data, GAN.loss_refine) is gan
+    assert owner(partial(gan.discriminator, reuse=True), partial(gan.feature_to_data, is_training=False), bce) is gan
+    assert owner(partial(D, reuse=True), gan.feature_to_data, bce) is gan                     # a partial of a partial
+    assert owner(D, gan.feature_to_data, lambda l: torch.nn.functional.softplus(-l)) is gan    # any spelling of the same loss
+    # not the engine's computation:
+    assert owner(partial(gan.discriminator, is_training=False, reuse=True), gan.feature_to_data, bce) is None   # inference-mode bn in D
+    assert owner(D, partial(gan.feature_to_data, is_training=True), bce) is None              # batch statistics in the G tail
+    assert owner(D, other.feature_to_data, bce) is None                                       # two different models
+    assert owner(partial(gan.discriminator, gan), gan.feature_to_data, bce) is None           # positional arguments bound
+    assert owner(lambda x: gan.discriminator(x, True, True), gan.feature_to_data, bce) is None
+    assert owner(D, gan.feature_to_data, lambda l: ops.sigmoid_cross_entropy_with_logits(labels=ops.zeros_like(l), logits=l)) is None
+    assert owner(D, gan.feature_to_data, lambda l: bce(l).mean()) is None                     # a reduction
+    assert owner(D, gan.feature_to_data, lambda l: 2.0 * bce(l)) is None
+    assert owner(D, gan.feature_to_data, lambda l: l.nonexistent_attribute) is None           # a loss the probe cannot evaluate
+    assert owner(D, gan.feature_to_data, bce, "ladam") is None                                # (needs a loss the map refiner never passes)
+    # the generic path reports itself, and a rejected loss is still differentiated as given
+    z = torch.from_numpy(np.random.RandomState(0).uniform(-1, 1, (4, 62)).astype(np.float32)).to(d)
+    f0 = gan.input_to_feature(z)
+    r = Refiner(2, 0.1)
+    r.set_env(D, gan.feature_to_data, lambda l: 2.0 * bce(l))
+    img2 = r.build_refiner(f0, None, "deterministic")
+    assert r.path == "generic"
+    r1 = Refiner(2, 0.2)                                                                        # 2 x loss at rate 0.1 == loss at rate 0.2
+    r1.set_env(D, gan.feature_to_data, bce)
+    img1 = r1.build_refiner(f0, None, "deterministic")
+    assert r1.path == "engine"
+    assert relerr(img2.cpu().numpy(), img1.cpu().numpy()) < 2e-3
+    # the TF-shaped loss entry point itself: ones / zeros / a label tensor, keyword-only
+    l = torch.linspace(-9, 9, 24, device=d).reshape(24, 1)
+    want1 = torch.nn.functional.softplus(-l.double().cpu())
+    assert relerr(ops.sigmoid_cross_entropy_with_logits(labels=ops.ones_like(l), logits=l).cpu().numpy(), want1.numpy()) < 1e-6
+    assert relerr(ops.sigmoid_cross_entropy_with_logits(labels=ops.zeros_like(l), logits=l).cpu().numpy(),
+                  torch.nn.functional.softplus(l.double().cpu()).numpy()) < 1e-6
+    zl = torch.rand(24, 1, device=d)
+    want = torch.nn.functional.binary_cross_entropy_with_logits(l.double().cpu(), zl.double().cpu(), reduction="none")
+    assert relerr(ops.sigmoid_cross_entropy_with_logits(labels=zl, logits=l).cpu().numpy(), want.numpy()) < 1e-6
+    with pytest.raises(ValueError):
+        ops.sigmoid_cross_entropy_with_logits(l, l)
+    ops.reset_variables()
+
+
+def test_refused_graph_capture_falls_back_to_eager_in_process(monkeypatch):
+    """Refiner.use_graph defaults to True; a capture that fails must not fail the call: same engine code launched eagerly, and
+    the refiner records why."""
+    from cgs_amd import ops
+    from cgs_amd.model import GAN
+    d = dev()
+    ops.reset_variables()
+    P = N.init_params("mnist", 2019, True)
+    gan = GAN("mnist", batch_size=4, device=d, params=P)
+    z = torch.from_numpy(np.random.RandomState(0).uniform(-1, 1, (4, 62)).astype(np.float32)).to(d)
+    f0 = gan.input_to_feature(z)
+    good = gan.build_refiner(3, 0.1)
+    img_g = good.build_refiner(f0, None, "deterministic")
+    assert good.path == "engine" and good.use_graph and good.graph_fallback is None
+
+    class _Refused:
+        def __init__(self, *a, **k):
+            raise RuntimeError("hipGraph capture refused (test)")
+    gan._engines.clear()
+    monkeypatch.setattr(torch.cuda, "graph", _Refused)
+    ref = gan.build_refiner(3, 0.1)
+    img_e = ref.build_refiner(f0, None, "deterministic")
+    assert ref.path == "engine" and ref.use_graph is False and "refused" in ref.graph_fallback
+    assert torch.equal(img_e, img_g) and torch.equal(ref.optimal_step, good.optimal_step)   # the same kernels in the same order
+    ops.reset_variables()
+
+
 def test_probabilistic_draw_and_ladam_guard():
     from cgs_amd import ops, lib
     from cgs_amd.model import GAN
