@@ -38,6 +38,14 @@ import torch
 
 PEAK_FP32_MATRIX_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 PEAK_HBM_GBPS = 8000.0              # same guide: HBM3E ~ 8 TB/s
+PEAK_BF16_MATRIX_TFLOPS = 2500.0    # same guide: "Peak BF16/FP16 MFMA ~2.5 PF dense"
+# the opt-in split-bf16 contraction (--contraction bx6, csrc/igemm_bx6.hip) issues SIX bf16 multiply-accumulates per fp32 one: its
+# kernels' fp32-equivalent rate is priced against the dense bf16 peak / 6
+PEAK_BX6_TFLOPS = PEAK_BF16_MATRIX_TFLOPS / 6.0
+
+
+def kernel_peak(name):
+    return PEAK_BX6_TFLOPS if name.startswith("igemm_bx6") else PEAK_FP32_MATRIX_TFLOPS
 # HBM-side bytes per launch from rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in separate runs of this same
 # command, FETCH_SIZE doubled per the gfx950 correction of the guide); collected offline, see profiles/README.md
 TRAFFIC_JSON = os.path.join(ROOT, "profiles", "traffic.json")
@@ -101,10 +109,11 @@ def profile_records(prof, prof_ms, step_ms, timing_note, with_traffic, prof_step
     hbm: the HBM-bound launches (3-channel conv kernels, batch-norm passes, the momentum update): algorithmic bytes (every
     operand once) / launch time against the 8 TB/s peak, and the PMC-measured bytes over the algorithmic ones."""
     table = _traffic_table() if with_traffic else {}
-    per, hbm, ex_total = {}, {}, 0.0
+    per, hbm, ex_total, ideal_ms = {}, {}, 0.0, 0.0
     for name, (fl, evs, ex, nb) in prof.items():
         ms = sum(a.elapsed_time(b) for a, b in evs)
         ex_total += ex
+        ideal_ms += ex / kernel_peak(name) / 1e9            # what this kernel's issued flops take at the peak of the instructions it runs on
         n = len(evs)
         if fl > 0 and name not in ("linear_out1_fwd", "linear_out1_bwd"):
             per[name] = {"launches": n, "avg_us": round(1e3 * ms / n, 2), "tflops": round(ex / ms / 1e9, 2),
@@ -121,17 +130,21 @@ def profile_records(prof, prof_ms, step_ms, timing_note, with_traffic, prof_step
     ms = sum(a.elapsed_time(b) for a, b in evs)
     n = len(evs)
     tr = measured_traffic(name, table)
-    roof = {"kernel": name, "bound": "mfma", "achieved": round(ex / ms / 1e9, 2), "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(ex / ms / 1e9 / PEAK_FP32_MATRIX_TFLOPS, 4),
-            "nominal": round(fl / ms / 1e9, 2), "nominal_frac": round(fl / ms / 1e9 / PEAK_FP32_MATRIX_TFLOPS, 4),
+    peak = kernel_peak(name)
+    roof = {"kernel": name, "bound": "mfma", "achieved": round(ex / ms / 1e9, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+            "frac": round(ex / ms / 1e9 / peak, 4),
+            "nominal": round(fl / ms / 1e9, 2), "nominal_frac": round(fl / ms / 1e9 / peak, 4),
             "traffic": tr, "algorithmic_bytes": int(nb / n), "traffic_over_algorithmic": round(tr / (nb / n), 3) if tr else None,
             "launches": n, "avg_launch_us": round(1e3 * ms / n, 2), "share_of_step": round(ms / prof_ms, 3), "timing": timing_note,
             "flop_per_launch": round(ex / n, 0), "nominal_flop_per_launch": round(fl / n, 0),
             "step_executed_tflops": round(ex_total / prof_steps / step_ms / 1e9, 2),
-            "step_executed_frac": round(ex_total / prof_steps / step_ms / 1e9 / PEAK_FP32_MATRIX_TFLOPS, 4),
+            "step_executed_frac": round(ideal_ms / prof_steps / step_ms, 4),
             "note": "achieved/frac = flops issued to the matrix cores / launch time (padding taps the kernel skips exactly are not "
-                    "counted, so frac <= 1); nominal* = the dense count of SURVEY 8(d), padding taps included; step_executed_* = all "
-                    "contraction launches of one step / the measured ms_per_step"}
+                    "counted, so frac <= 1); nominal* = the dense count of SURVEY 8(d), padding taps included; step_executed_tflops = all "
+                    "contraction launches of one step / the measured ms_per_step; step_executed_frac = the time those launches would take "
+                    "at the peak of the instructions they run on / ms_per_step"}
+    if peak != PEAK_FP32_MATRIX_TFLOPS:
+        roof["peak_note"] = "split-bf16 kernel: fp32-equivalent flops against the dense bf16 MFMA peak / 6 (six bf16 products per fp32 product)"
     return roof, per, hbm, ex_total / prof_steps
 
 
@@ -373,6 +386,42 @@ def class_surface(dev, configs=(("dcgan64", 1024, 20, 6, 3), ("mnist", 64, 50, 2
     return out
 
 
+DTYPE = {"f32": "f32", "bx6": "f32 (3xbf16 split, fp32 accumulate)"}
+
+
+def bx6_line(args, P, B, G, Ksteps, z, dev, n_flight, streams, flops_per_sample):
+    """The headline's workload with RefineEngine(contraction="bx6"): the layers with >= 128 output channels on split-bf16 MFMA
+    (csrc/igemm_bx6.hip).  Same engines-in-flight / hipGraph structure and the same z batches as the f32 region; opt-in, reported
+    beside the headline, priced against the bf16 peak / 6 for its kernels."""
+    from cgs_amd.engine import RefineEngine
+    engines = [RefineEngine(args.arch, P, B * G, dev, use_graph=bool(args.graph), bn_groups=G, contraction="bx6") for _ in range(n_flight)]
+
+    def step(i):
+        j = i % n_flight
+        with torch.cuda.stream(streams[j]):
+            engines[j].refine_from_z(z[i], Ksteps, args.rate)
+    for i in range(max(args.warmup, n_flight)):
+        step(i % len(z))
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i in range(args.warmup, args.warmup + args.steps):
+        step(i)
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    prof, prof_ms = profile_one_step(args.arch, P, B, G, Ksteps, args.rate, z[args.warmup], dev, streams[0], engine=engines[0])
+    roof, kern, _, ex_step = profile_records(prof, prof_ms, 1e3 * dt / args.steps, "one extra eager single-stream step right after this mode's timed steps", False)
+    roof.pop("traffic"); roof.pop("traffic_over_algorithmic")
+    value = B * G * args.steps / dt
+    return {"value": round(value, 2), "unit": "samples/s", "ms_per_step": round(1e3 * dt / args.steps, 3), "steps": args.steps,
+            "dtype": DTYPE["bx6"], "contraction": "bx6", "hipgraph": bool(args.graph), "batches_in_flight": n_flight * G,
+            "algorithmic_tflops": round(value * flops_per_sample / 1e12, 2), "executed_tflops": round(ex_step / (1e3 * dt / args.steps) / 1e9, 2),
+            "roofline": roof, "kernels": {k: v for k, v in kern.items() if k.startswith("igemm")},
+            "selected_by": "python bench.py --contraction bx6   (RefineEngine(..., contraction='bx6'); the C ABI: cgs_set_contraction)",
+            "accuracy": "six of the nine products of an exact three-way bf16 split of both fp32 operands, fp32 accumulate: error of the "
+                        "size of an fp32 fma chain's own; the full parity suite (operator tests at 2e-5, reference goldens, full-size "
+                        "oracle cases) runs in this mode too (tests/conftest.py, `contraction`)"}
+
+
 def self_launch(n_gpus):
     """`python bench.py --gpus N` (N > 1) outside torch.distributed.run: start the N ranks as CHILD processes
     (`python -m torch.distributed.run --nproc-per-node N bench.py <same arguments>`) before this process has touched the
@@ -419,6 +468,11 @@ def main():
     ap.add_argument("--share-gpu", action="store_true",
                     help="every rank uses device 0 (debug: the N-rank control flow on a 1-GPU box; RCCL refuses two ranks on one device, so "
                          "this needs --backend gloo)")
+    ap.add_argument("--contraction", default="f32", choices=["f32", "bx6"],
+                    help="f32 (default, the headline): every contraction on the exact-fp32 matrix instructions.  bx6: opt-in -- the layers with "
+                         ">= 128 output channels run on the bf16 matrix cores with every fp32 operand split exactly into three bf16 pieces "
+                         "(six products, fp32 accumulate: an fp32 chain's accuracy, DESIGN.md); the line's dtype says so.  The default run "
+                         "reports this mode as a second object `bx6` next to the f32 headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the mnist / dcgan32 / synthetic2d samples/s that are measured after the headline's timed region")
@@ -476,7 +530,8 @@ def main():
     sync = True if args.sync_bn else None
 
     def build_engines(use_graph):
-        return [RefineEngine(args.arch, P, B * G, dev, use_graph=use_graph, sync_bn=sync, bn_groups=G) for _ in range(n_flight)]
+        return [RefineEngine(args.arch, P, B * G, dev, use_graph=use_graph, sync_bn=sync, bn_groups=G, contraction=args.contraction)
+                for _ in range(n_flight)]
 
     streams = [torch.cuda.Stream(dev) for _ in range(n_flight)] if n_flight > 1 else [torch.cuda.current_stream(dev)]
     n_batches = args.steps + args.warmup                                # a step = one engine call = G logical batches
@@ -597,13 +652,14 @@ def main():
         out = {
             "metric": f"refined samples/sec @ {Ksteps} refinement steps", "value": round(value, 2), "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE[args.contraction], "data": "synthetic",
             "config": {"workload": f"{args.arch} collaborative refinement (propose + K-step refine + render), "
                                    f"batch {B}/GPU{f' (x{G} logical batches per launch, batch-norm statistics per logical batch)' if G > 1 else ''}, "
                                    f"K={Ksteps}, momentum rate {args.rate}, refine at feature "
                                    f"{list(A['feature'])}, random-init weights, z~U(-1,1) seed 2019+rank",
                        "global_batch": world * B * G, "refine_steps": Ksteps, "parallelism": f"z-shards x{world} + RCCL all-gather of the pool" if world > 1 else "single GPU",
-                       "hipgraph": all_graph, "batches_in_flight": n_flight * G, "fused_per_launch": G, "sync_bn": bool(args.sync_bn)},
+                       "hipgraph": all_graph, "batches_in_flight": n_flight * G, "fused_per_launch": G, "sync_bn": bool(args.sync_bn),
+                       "contraction": args.contraction},
             "algorithmic_tflops": round(value * flops_per_sample / 1e12, 2),
         }
         if graph_fallback:
@@ -623,6 +679,12 @@ def main():
             out["executed_tflops"] = round(world * ex_step / (1e3 * dt / args.steps) / 1e9, 2)      # whole job, padding taps not counted
         cpu = cpu_baseline(args.arch, Ksteps, args.rate) if world == 1 and not args.no_cpu_baseline else None   # (calibrates the host thread count)
         if world == 1 and not args.no_other_configs:
+            if args.contraction == "f32" and args.arch in ("dcgan64", "cyclegan256"):
+                # the opt-in split-bf16 mode on the SAME workload, engines, batches in flight and z batches, timed right after
+                # (and outside) the headline's region: its own samples/s, dtype and roofline (never the headline)
+                del engines
+                torch.cuda.empty_cache()
+                out["bx6"] = bx6_line(args, P, B, G, Ksteps, z, dev, n_flight, streams, flops_per_sample)
             out["other_configs"] = other_configs(dev, args.arch, not args.no_cpu_baseline)
             out["class_surface"] = class_surface(dev)
         if cpu is not None:

@@ -9,6 +9,8 @@ static thread_local char g_err[512] = "";
 static thread_local const char* g_last_kernel = "";
 
 static thread_local double g_last_flops = 0.0;
+static thread_local int g_contraction = CGS_CONTRACTION_F32;
+int cgs_contraction_mode() { return g_contraction; }
 
 void cgs_note_kernel(const char* name) { g_last_kernel = name; }
 void cgs_note_flops(double f) { g_last_flops = f; }
@@ -28,6 +30,12 @@ int cgs_version(void) { return 100; }
 const char* cgs_last_error(void) { return g_err; }
 const char* cgs_last_kernel(void) { return g_last_kernel; }
 double cgs_last_executed_flops(void) { return g_last_flops; }
+int cgs_set_contraction(int mode) {
+    if (mode < CGS_CONTRACTION_F32 || mode > CGS_CONTRACTION_BX6_ALL) return cgs_set_error(CGS_EINVAL, "set_contraction: mode %d", mode);
+    g_contraction = mode;
+    return CGS_OK;
+}
+int cgs_get_contraction(void) { return g_contraction; }
 
 }  // extern "C"
 
@@ -65,6 +73,9 @@ static int choose_family(const CgsLayer& L, bool dirT, int B, int epilogue, bool
     const bool patch_f = !dirT && cgs_conv_patch_ok(L, epilogue), patch_t = dirT && cgs_conv_patch_T_ok(L);
     if ((patch_f || patch_t) && have_ws && ws_bytes >= cgs_conv_patch_ws_floats(L, dirT) * sizeof(float) && ws_al && rest_al)
         return CGS_FAMILY_PATCH;
+    // the calling thread opted into the split-bf16 contraction (cgs_set_contraction): the calls it serves leave the fp32 kernel
+    if (g_contraction != CGS_CONTRACTION_F32 && cgs_igemm_bx6_ok(L, dirT, B, g_contraction == CGS_CONTRACTION_BX6_ALL))
+        return CGS_FAMILY_IGEMM_BX6;
     return CGS_FAMILY_IGEMM;
 }
 
@@ -83,7 +94,7 @@ static int run_dir(const CgsLayer& L, bool dirT, int B, const float* in, const f
     const bool rest_al = !(((uintptr_t)out & 15) || ((uintptr_t)bias & 15) || ((uintptr_t)ep_a & 15) || ((uintptr_t)ep_b & 15) ||
                            ((uintptr_t)ep_aux & 15));
     const int fam = choose_family(L, dirT, B, epilogue, ws != nullptr, ws_bytes, !((uintptr_t)in & 15), !((uintptr_t)ws & 15), rest_al);
-    if (stat_part && fam != CGS_FAMILY_IGEMM) return cgs_set_error(CGS_EINVAL, "%s: fused statistics are an implicit-GEMM feature (see cgs_conv_stat_partials)", who);
+    if (stat_part && fam != CGS_FAMILY_IGEMM && fam != CGS_FAMILY_IGEMM_BX6) return cgs_set_error(CGS_EINVAL, "%s: fused statistics are an implicit-GEMM feature (see cgs_conv_stat_partials)", who);
     if (sign_out && fam != CGS_FAMILY_IGEMM) return cgs_set_error(CGS_EINVAL, "%s: this call cannot leave a sign mask (see cgs_conv_signs_ok)", who);
     if (aux_signs && fam != CGS_FAMILY_PATCH && fam != CGS_FAMILY_TAPS) return cgs_set_error(CGS_EINVAL, "%s: this call cannot take a sign mask (see cgs_conv_signs_ok)", who);
     if (((uintptr_t)sign_out & 3) || ((uintptr_t)aux_signs & 3)) return cgs_set_error(CGS_EINVAL, "%s: sign mask must be 4-byte aligned", who);
@@ -108,14 +119,15 @@ static int run_dir(const CgsLayer& L, bool dirT, int B, const float* in, const f
     p.sign_out = sign_out;
     p.sign_plane = (long)B * (dirT ? L.Hb * L.Wb : L.Hs * L.Ws);
     if (dirT) cgs_geom_T(L, p); else cgs_geom_F(L, p);
-    const size_t need = cgs_packed_floats(p) * sizeof(float);
+    const bool bx6 = fam == CGS_FAMILY_IGEMM_BX6;
+    const size_t need = bx6 ? cgs_igemm_bx6_packed_bytes(p) : cgs_packed_floats(p) * sizeof(float);
     if (!ws || ws_bytes < need) return cgs_set_error(CGS_EWORKSPACE, "%s: workspace %zu < %zu bytes", who, ws_bytes, need);
     if (((uintptr_t)ws & 15) || ((uintptr_t)in & 15) || ((uintptr_t)out & 15) || ((uintptr_t)bias & 15) ||
         ((uintptr_t)ep_a & 15) || ((uintptr_t)ep_b & 15) || ((uintptr_t)ep_aux & 15))
         return cgs_set_error(CGS_EINVAL, "%s: pointers must be 16-byte aligned", who);
     p.wp = (const float*)ws;
     if (!prepacked) {
-        int rc = cgs_pack_weights(p, L, dirT, w, (float*)ws, s);
+        int rc = bx6 ? cgs_pack_weights_bx6(p, L, dirT, w, ws, s) : cgs_pack_weights(p, L, dirT, w, (float*)ws, s);
         if (rc) return rc;
     }
     // one launch addresses its tensors with 32-bit byte offsets: split the batch so each stays < 2 GiB
@@ -130,7 +142,7 @@ static int run_dir(const CgsLayer& L, bool dirT, int B, const float* in, const f
         p.out = out + (size_t)b0 * (out_img / 4);
         p.ep_aux = ep_aux ? ep_aux + (size_t)b0 * (out_img / 4) : nullptr;
         p.sign_out = sign_out ? sign_out + (size_t)b0 * p.Hout * p.Wout : nullptr;      // (plane-major: the chunk's pixels inside every plane)
-        int rc = cgs_igemm_launch(p, (char*)ws + need, ws_bytes - need, s);
+        int rc = bx6 ? cgs_igemm_bx6_launch(p, s) : cgs_igemm_launch(p, (char*)ws + need, ws_bytes - need, s);
         if (rc) return rc;
     }
     return CGS_OK;
@@ -182,7 +194,11 @@ static size_t conv_packed_bytes(int op, int kh, int kw, int sh, int sw, int Cin,
     const bool deconv = (op == CGS_DECONV_FWD || op == CGS_DECONV_BWD_DATA);
     const bool dirT = (op == CGS_CONV_BWD_DATA || op == CGS_DECONV_FWD);
     const int Cb = deconv ? Cout : Cin, Cs = deconv ? Cin : Cout;
-    if (!dirT) return (size_t)cgs_round_up(kh * kw * Cb, CGS_BK) * cgs_round_up(Cs, 64) * sizeof(float);
+    // (the split-bf16 form keeps three bf16 planes = 6 bytes per weight: sized for it wherever its geometry applies, whatever the
+    // calling thread's contraction mode, so a workspace serves both)
+    const int Cred = dirT ? Cs : Cb, Nn = dirT ? Cb : Cs;
+    const size_t per_w = ((Cred % 32) == 0 && (Nn % 128) == 0 && kh <= 16 && kw <= 16) ? 6 : sizeof(float);
+    if (!dirT) return (size_t)cgs_round_up(kh * kw * Cb, CGS_BK) * cgs_round_up(Cs, 64) * per_w;
     // T: per parity class, taps of that class (independent of the spatial size: pads only permute classes)
     size_t n = 0;
     for (int a = 0; a < sh; ++a)
@@ -194,7 +210,7 @@ static size_t conv_packed_bytes(int op, int kh, int kw, int sh, int sw, int Cin,
         const size_t q = cgs_convt_quad_ws_floats_bound(kh, kw, Cs);
         if (q > n) n = q;
     }
-    return n * sizeof(float);
+    return n * (per_w > sizeof(float) && !(Cb <= 4 && sh == 2 && sw == 2) ? per_w : sizeof(float));
 }
 
 int cgs_conv2d_nhwc_fwd(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int Cin,
@@ -209,7 +225,8 @@ int cgs_conv2d_nhwc_fwd(const float* x, const float* w, const float* bias, float
 int cgs_conv_stat_partials(int B, int H, int W, int Cin, int Cout, int kh, int kw, int sh, int sw, size_t ws_bytes) {
     CgsLayer L;
     if (make_layer(L, kh, kw, sh, sw, H, W, Cin, cgs_ceil_div(H, sh > 0 ? sh : 1), cgs_ceil_div(W, sw > 0 ? sw : 1), Cout, "conv_stat_partials")) return 0;
-    if (B <= 0 || (Cout & 3) || choose_family(L, false, B, CGS_EPI_NONE, ws_bytes > 0, ws_bytes, true, true, true) != CGS_FAMILY_IGEMM) return 0;
+    const int fam = choose_family(L, false, B, CGS_EPI_NONE, ws_bytes > 0, ws_bytes, true, true, true);
+    if (B <= 0 || (Cout & 3) || (fam != CGS_FAMILY_IGEMM && fam != CGS_FAMILY_IGEMM_BX6)) return 0;       // (both leave the same partial rows)
     const size_t per = (size_t)(L.Hb * L.Wb * L.Cb > L.Hs * L.Ws * L.Cs ? L.Hb * L.Wb * L.Cb : L.Hs * L.Ws * L.Cs) * 4;
     if ((size_t)B * per > 0x7fffffffUL) return 0;                    // the entry point would split the batch
     const long M = (long)B * L.Hs * L.Ws;
@@ -230,7 +247,8 @@ int cgs_conv_stat_layout(int op, int B, int H, int W, int Cin, int Ho, int Wo, i
     if (!dirT) { if (make_layer(L, kh, kw, sh, sw, H, W, Cin, cgs_ceil_div(H, sh > 0 ? sh : 1), cgs_ceil_div(W, sw > 0 ? sw : 1), Cout, "conv_stat_layout")) return 0; }
     else if (make_layer(L, kh, kw, sh, sw, Ho, Wo, Cout, H, W, Cin, "conv_stat_layout")) return 0;
     if (dirT && (sh > 2 || sw > 2)) return 0;
-    if (choose_family(L, dirT, B, CGS_EPI_NONE, ws_bytes > 0, ws_bytes, true, true, true) != CGS_FAMILY_IGEMM) return 0;
+    const int fam = choose_family(L, dirT, B, CGS_EPI_NONE, ws_bytes > 0, ws_bytes, true, true, true);
+    if (fam != CGS_FAMILY_IGEMM && fam != CGS_FAMILY_IGEMM_BX6) return 0;
     const size_t per = (size_t)(L.Hb * L.Wb * L.Cb > L.Hs * L.Ws * L.Cs ? L.Hb * L.Wb * L.Cb : L.Hs * L.Ws * L.Cs) * 4;
     if ((size_t)B * per > 0x7fffffffUL) return 0;                    // the entry point would split the batch
     IgemmParams p;

@@ -102,6 +102,14 @@ size_t cgs_packed_floats(const IgemmParams& p);
 int cgs_pack_weights(const IgemmParams& p, const CgsLayer& L, bool dirT, const float* w, float* packed, hipStream_t s);
 int cgs_igemm_launch(const IgemmParams& p, void* slab, size_t slab_bytes, hipStream_t s);
 size_t cgs_igemm_splitk_bytes(const IgemmParams& p);   // slab bytes the launch would like (0 = no split-K)
+void cgs_igemm_row_policy(IgemmParams& p, int BM);     // sets pix_major, lpt, perm (BM = rows of the launch's block tile)
+void cgs_igemm_count_flops(const IgemmParams& p, int BM);
+// split-bf16 implicit GEMM (igemm_bx6.hip): fp32 operands as three bf16 pieces each, six bf16 MFMA products, fp32 accumulate
+int cgs_igemm_bx6_ok(const CgsLayer& L, bool dirT, int B, bool any_size);
+size_t cgs_igemm_bx6_packed_bytes(const IgemmParams& p);
+int cgs_pack_weights_bx6(const IgemmParams& p, const CgsLayer& L, bool dirT, const float* w, void* packed, hipStream_t s);
+int cgs_igemm_bx6_launch(const IgemmParams& p, hipStream_t s);
+int cgs_contraction_mode();                             // thread-local: CGS_CONTRACTION_* (api.hip)
 int cgs_igemm_row_order(const IgemmParams& p);         // GEMM row order the launcher will pick: 0 (image, pixel); 1 (pixel, image); 2 (pixel, image) in whole 128-image tiles
 size_t cgs_convt_quad_ws_floats_bound(int kh, int kw, int Cs);
 int cgs_convt_taps_ok(const CgsLayer& L);          // 4x4 stride-2 transposed conv to one channel: all 16 taps as MFMA columns (convt_taps.hip)

@@ -27,9 +27,9 @@
 #include <stdlib.h>
 
 #include "cgs_internal.h"
+#include "igemm_epilogue.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 static constexpr int BK = CGS_BK;     // K padding granule of the packed weights (the kernels tile K by 32 or 16)
 
@@ -136,63 +136,6 @@ int cgs_pack_weights(const IgemmParams& p, const CgsLayer& L, bool dirT, const f
 // ------------------------------------------------------------------------------------------------
 // main kernel
 // ------------------------------------------------------------------------------------------------
-// Row pass of the wide epilogue for ONE epilogue mode (compile-time): branch-free inner loops and a compact
-// instruction footprint.  (With the mode as a run-time switch inside the unrolled loops the epilogue was ~21k lines
-// of ISA with 1.6k branches and took 20 us per block, 10 % of the block's life.)
-// SG: also leave the SIGN MASK of the stored values (p.sign_out; N % 32 == 0): the activation gradient of the layer above needs
-// one bit per element, not the fp32 tensor.  A row's 4-channel lanes sit in consecutive lanes, so v_cmp of element e over the
-// wave (ballot) holds, in the 8 bits starting at (lane & ~7), channels 4q + e (q = 0..7) of this lane's 32-channel group:
-// word = sum_e byte_e << 8e, i.e. bit 8 * (c % 4) + (c % 32) / 4 <-> channel c; the lane with (lane & 7) == 0 stores it into
-// the group's plane (one word per pixel, pixels contiguous: the consumer reads a tile row's words as one coalesced run).
-template <int EPI, int ROWS, int RPP, int LDE, bool SG>
-__device__ __forceinline__ void epilogue_rows_signs(const IgemmParams& p, const float* E, const int* rowpix_tile, int rsub, int c4,
-                                                    int n, f32x4 bias, f32x4 ea, f32x4 eb) {
-    const int lane = threadIdx.x & 63;
-    unsigned* plane = p.sign_out + (size_t)(n >> 5) * p.sign_plane;
-#pragma unroll
-    for (int it = 0; it < ROWS / RPP; ++it) {
-        const int lrow = it * RPP + rsub;
-        const int pix = rowpix_tile[lrow];
-        const bool live = pix >= 0;
-        const f32x4 v = *(const f32x4*)(E + lrow * LDE + c4);
-        const size_t o = (size_t)(live ? pix : 0) * p.N + n;
-        f32x4 y;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) y[e] = epilogue_apply(v[e] + bias[e], EPI, ea[e], eb[e], 0.f);
-        if (live) *(f32x4*)(p.out + o) = y;
-        unsigned word = 0;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const unsigned long long bal = __builtin_amdgcn_ballot_w64(live && y[e] > 0.f);
-            word |= ((unsigned)(bal >> (lane & ~7)) & 0xffu) << (8 * e);
-        }
-        if (live && (lane & 7) == 0) plane[pix] = word;
-    }
-}
-
-template <int EPI, int ROWS, int RPP, int LDE, bool ST = false>
-__device__ __forceinline__ void epilogue_rows(const IgemmParams& p, const float* E, const int* rowpix_tile, int rsub, int c4,
-                                              int n, f32x4 bias, f32x4 ea, f32x4 eb, f32x4* sa = nullptr, f32x4* sb = nullptr) {
-#pragma unroll
-    for (int it = 0; it < ROWS / RPP; ++it) {
-        const int lrow = it * RPP + rsub;
-        const int pix = rowpix_tile[lrow];
-        if (pix < 0) continue;
-        const f32x4 v = *(const f32x4*)(E + lrow * LDE + c4);
-        const size_t o = (size_t)pix * p.N + n;
-        f32x4 aux = {0.f, 0.f, 0.f, 0.f};
-        if (EPI >= CGS_EPI_RELU_BWD_AFFINE) aux = *(const f32x4*)(p.ep_aux + o);
-        f32x4 y;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) y[e] = epilogue_apply(v[e] + bias[e], EPI, ea[e], eb[e], aux[e]);
-        *(f32x4*)(p.out + o) = y;
-        if (ST) {        // fused batch-norm statistics: this lane's 4 channels, summed over its rows
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { (*sa)[e] += y[e]; (*sb)[e] = fmaf(y[e], y[e], (*sb)[e]); }
-        }
-    }
-}
-
 // NW waves per block, arranged 2 (M) x NW/2 (N); wave tile (BM/2) x (BN/(NW/2)).
 // PAR: parity-first tap order (a compile-time variant: the extra scalar decode slowed the natural-order layers by ~0.8 %
 // when it was a run-time flag).
@@ -1032,22 +975,10 @@ static bool igemm_pix_major(const IgemmParams& p) {
     return p.vec && p.B >= 128 && maxRC <= pix_max && maxRC > 1 && in_bytes <= pix_bytes;
 }
 
-int cgs_igemm_row_order(const IgemmParams& p) {
-    if (!igemm_pix_major(p)) return 0;
-    return (p.B % 128) == 0 ? 2 : 1;
-}
-
-int cgs_igemm_launch(const IgemmParams& p_in, void* slab, size_t slab_bytes, hipStream_t s) {
-    IgemmParams p = p_in;
-    p.splitk = 1; p.slab = nullptr;
-    p.prio_t[0] = p.prio_t[1] = p.prio_t[2] = 0;
-#ifdef CGS_DIAG_STAMPS
-    if (getenv("CGS_STAMP") && slab && slab_bytes >= 64) p.slab = (float*)slab;
-#endif
-    int maxRC = 0;
-    for (int i = 0; i < p.nclasses; ++i) maxRC = p.cls[i].R * p.cls[i].C > maxRC ? p.cls[i].R * p.cls[i].C : maxRC;
+// GEMM row order of a launch and, for whole-tile pixel-major launches, the heaviest-first pixel order (BM = rows of a block tile)
+void cgs_igemm_row_policy(IgemmParams& p, int BM) {
     p.pix_major = igemm_pix_major(p);
-    p.lpt = p.pix_major && (p.B % 128) == 0;
+    p.lpt = p.pix_major && (p.B % BM) == 0;
     if (p.lpt)
         for (int ci = 0; ci < p.nclasses; ++ci) {
             const IgemmClass& c = p.cls[ci];
@@ -1065,6 +996,49 @@ int cgs_igemm_launch(const IgemmParams& p_in, void* slab, size_t slab_bytes, hip
                     unsigned char t = p.perm[ci][j]; p.perm[ci][j] = p.perm[ci][j - 1]; p.perm[ci][j - 1] = t;
                 }
         }
+}
+
+// multiply-accumulates a launch really issues -> cgs_last_executed_flops: the algorithmic count minus the zero-padding taps whose
+// K tiles the kernel skips (pixel-major tiles whose BM rows are one base pixel; exact, see igemm_kernel) -- for honest rooflines
+void cgs_igemm_count_flops(const IgemmParams& p, int BM) {
+    double macs = 0.0;
+    for (int ci = 0; ci < p.nclasses; ++ci) {
+        const IgemmClass& c = p.cls[ci];
+        const long M = (long)p.B * c.R * c.C;
+        const int ntaps = c.nty * c.ntx;
+        if (!(p.vec && p.pix_major)) { macs += (double)M * p.N * p.Cred * ntaps; continue; }
+        for (long m0 = 0; m0 < M; m0 += BM) {
+            const long ml = m0 + BM - 1 < M ? m0 + BM - 1 : M - 1;
+            const int pf = (int)(m0 / p.B), pl = (int)(ml / p.B);
+            int taps = ntaps;
+            if (pf == pl) {
+                const int r = pf / c.C, cc = pf - r * c.C;
+                int ny = 0, nx = 0;
+                for (int ta = 0; ta < c.nty; ++ta) { const int iy = r * p.S + c.dy0 + ta * p.dstep; ny += (iy >= 0 && iy < p.Hin); }
+                for (int tb = 0; tb < c.ntx; ++tb) { const int ix = cc * p.S + c.dx0 + tb * p.dstep; nx += (ix >= 0 && ix < p.Win); }
+                taps = ny * nx;
+            }
+            macs += (double)(ml - m0 + 1) * p.N * p.Cred * taps;
+        }
+    }
+    cgs_add_flops(2.0 * macs);
+}
+
+int cgs_igemm_row_order(const IgemmParams& p) {
+    if (!igemm_pix_major(p)) return 0;
+    return (p.B % 128) == 0 ? 2 : 1;
+}
+
+int cgs_igemm_launch(const IgemmParams& p_in, void* slab, size_t slab_bytes, hipStream_t s) {
+    IgemmParams p = p_in;
+    p.splitk = 1; p.slab = nullptr;
+    p.prio_t[0] = p.prio_t[1] = p.prio_t[2] = 0;
+#ifdef CGS_DIAG_STAMPS
+    if (getenv("CGS_STAMP") && slab && slab_bytes >= 64) p.slab = (float*)slab;
+#endif
+    int maxRC = 0;
+    for (int i = 0; i < p.nclasses; ++i) maxRC = p.cls[i].R * p.cls[i].C > maxRC ? p.cls[i].R * p.cls[i].C : maxRC;
+    cgs_igemm_row_policy(p, 128);
     if ((long)p.B * p.Hout * p.Wout * p.N * 4 > 0x7fffffffL || (long)p.B * p.Hin * p.Win * p.Cred * 4 > 0x7fffffffL)
         return cgs_set_error(CGS_EINVAL, "igemm: a tensor of one launch exceeds 2 GiB (the caller splits the batch)");
     if (p.stat_part && ((p.N & 3) || p.epilogue != CGS_EPI_NONE))
@@ -1090,30 +1064,7 @@ int cgs_igemm_launch(const IgemmParams& p_in, void* slab, size_t slab_bytes, hip
         }
     }
     const bool vec = p.vec != 0;
-    {   // multiply-accumulates this launch really issues: the algorithmic count minus the zero-padding taps whose K tiles the
-        // kernel skips (pixel-major tiles whose 128 rows are one base pixel; exact, see igemm_kernel) -- for honest rooflines
-        double macs = 0.0;
-        for (int ci = 0; ci < p.nclasses; ++ci) {
-            const IgemmClass& c = p.cls[ci];
-            const long M = (long)p.B * c.R * c.C;
-            const int ntaps = c.nty * c.ntx;
-            if (!(vec && p.pix_major)) { macs += (double)M * p.N * p.Cred * ntaps; continue; }
-            for (long m0 = 0; m0 < M; m0 += 128) {
-                const long ml = m0 + 127 < M ? m0 + 127 : M - 1;
-                const int pf = (int)(m0 / p.B), pl = (int)(ml / p.B);
-                int taps = ntaps;
-                if (pf == pl) {
-                    const int r = pf / c.C, cc = pf - r * c.C;
-                    int ny = 0, nx = 0;
-                    for (int ta = 0; ta < c.nty; ++ta) { const int iy = r * p.S + c.dy0 + ta * p.dstep; ny += (iy >= 0 && iy < p.Hin); }
-                    for (int tb = 0; tb < c.ntx; ++tb) { const int ix = cc * p.S + c.dx0 + tb * p.dstep; nx += (ix >= 0 && ix < p.Win); }
-                    taps = ny * nx;
-                }
-                macs += (double)(ml - m0 + 1) * p.N * p.Cred * taps;
-            }
-        }
-        cgs_add_flops(2.0 * macs);
-    }
+    cgs_igemm_count_flops(p, 128);
     bool wide = (p.Np % 128) == 0;
     if (wide && p.lpt && maxRC <= 64) {   // uneven tiles (9..25 valid taps on grids <= 8x8) need >= 2 rounds of blocks over the 512 block slots to balance: halve BN if short
         long blocks = 0;

@@ -468,12 +468,20 @@ class Tape:
 class RefineEngine:
     """K-step collaborative refinement of a batch of G activation maps on one GPU."""
 
-    def __init__(self, arch, params, batch_size, device=None, use_graph=False, sync_bn=None, bn_groups=1):
+    def __init__(self, arch, params, batch_size, device=None, use_graph=False, sync_bn=None, bn_groups=1, contraction="f32"):
         self.A = ARCHS[arch] if isinstance(arch, str) else arch
+        # "f32": every contraction on the exact-fp32 matrix instructions (the reference's precision; default).  "bx6": opt-in, the
+        # layers with >= 128 output channels and GPU-filling grids through split-bf16 MFMA (include/cgs_hip.h, cgs_set_contraction;
+        # csrc/igemm_bx6.hip) -- same results to fp32 rounding, less matrix time.  The mode is a property of the ENGINE: it is put in
+        # force at construction (the layer compilation asks the library which kernel families it will get) and at every entry point.
+        if contraction not in L.CONTRACTIONS:
+            raise L.CgsError(f"contraction {contraction!r}: expected one of {sorted(L.CONTRACTIONS)}")
+        self.contraction = contraction
         self.dev = torch.device(device if device is not None else "cuda:0")
         if self.dev.type != "cuda":
             raise L.CgsError("RefineEngine needs a GPU device (there is no CPU path)")
         L.load()
+        K.set_contraction(self.contraction)
         A, B = self.A, int(batch_size)
         self.B, self.P = B, params
         with torch.cuda.device(self.dev):
@@ -544,6 +552,7 @@ class RefineEngine:
         inference-bn affines; after ``ops.set_variables`` / a shaping step (``K.WS.invalidate()``) the last two are stale, and a
         captured hipGraph would replay a MIX of old and new state.  Any engine -- also one built directly, not through
         ``model.GAN`` -- re-derives them here before its next use."""
+        K.set_contraction(self.contraction)          # (a string compare when it is already in force)
         if self._ws_epoch != K.WS.epoch:
             self._resync()
 

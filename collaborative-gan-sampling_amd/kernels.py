@@ -76,6 +76,22 @@ def same_out(size, stride):
     return int(math.ceil(float(size) / float(stride)))
 
 
+# ---- contraction arithmetic of the implicit-GEMM layers (include/cgs_hip.h, cgs_set_contraction): "f32" = exact fp32 MFMA (default),
+# "bx6" = opt-in split-bf16 MFMA for the big layers, "bx6_all" = the same for every eligible call (test coverage).  The library keeps
+# the mode per host thread; this module mirrors the mode of the thread that drives it (one host thread per process here).
+CONTRACTION = "f32"
+
+
+def set_contraction(mode):
+    """Switch the calling thread's contraction mode; returns the previous one."""
+    global CONTRACTION
+    prev = CONTRACTION
+    if mode != prev:
+        L.set_contraction(mode)
+        CONTRACTION = mode
+    return prev
+
+
 class _WsCache:
     """Packed-weight workspaces, keyed by the weight tensor (identity + version), the op, the call geometry, the HIP
     stream AND the kernel family the library will run (``cgs_conv_family``): every family keeps its own packed layout,
@@ -89,7 +105,7 @@ class _WsCache:
 
     def plan(self, op, B, H, W, cin, ho, wo, cout, kh, kw, sh, sw, epilogue):
         """(kernel family, workspace bytes) of a call; asked of the library once per distinct call signature."""
-        key = (op, B, H, W, cin, ho, wo, cout, kh, kw, sh, sw, epilogue)
+        key = (op, B, H, W, cin, ho, wo, cout, kh, kw, sh, sw, epilogue, CONTRACTION)      # (the family depends on the thread's contraction mode)
         hit = self._family.get(key)
         if hit is None:
             nbytes = max(L.conv_ws_bytes_for(op, B, H, W, cin, cout, kh, kw, sh, sw), 16)

@@ -13,7 +13,9 @@ OK, EINVAL, EWORKSPACE, ELAUNCH = 0, -1, -2, -3
 EPI_NONE, EPI_LRELU, EPI_AFFINE_RELU, EPI_TANH = 0, 1, 2, 3
 EPI_RELU_BWD_AFFINE, EPI_LRELU_BWD, EPI_TANH_BWD = 4, 5, 6
 CONV_FWD, CONV_BWD_DATA, DECONV_FWD, DECONV_BWD_DATA = 0, 1, 2, 3
-FAMILY_IGEMM, FAMILY_QUAD, FAMILY_SMALLN_T, FAMILY_SMALLN_F, FAMILY_PATCH, FAMILY_TAPS, FAMILY_DOT = 0, 1, 2, 3, 4, 5, 6
+FAMILY_IGEMM, FAMILY_QUAD, FAMILY_SMALLN_T, FAMILY_SMALLN_F, FAMILY_PATCH, FAMILY_TAPS, FAMILY_DOT, FAMILY_IGEMM_BX6 = 0, 1, 2, 3, 4, 5, 6, 7
+CONTRACTION_F32, CONTRACTION_BX6, CONTRACTION_BX6_ALL = 0, 1, 2
+CONTRACTIONS = {"f32": CONTRACTION_F32, "bx6": CONTRACTION_BX6, "bx6_all": CONTRACTION_BX6_ALL}
 
 _p, _i, _f, _z = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 _ll = C.c_longlong
@@ -24,6 +26,8 @@ SIGNATURES = {
     "cgs_last_error": (C.c_char_p, []),
     "cgs_last_kernel": (C.c_char_p, []),
     "cgs_last_executed_flops": (C.c_double, []),
+    "cgs_set_contraction": (_i, [_i]),
+    "cgs_get_contraction": (_i, []),
     "cgs_conv_ws_bytes": (_z, [_i] * 7),
     "cgs_conv_ws_bytes_for": (_z, [_i] * 10),
     "cgs_conv_family": (_i, [_i] * 13 + [_z]),
@@ -116,6 +120,21 @@ def call(name, *args):
     rc = getattr(lib, name)(*args)
     if rc != OK:
         raise CgsError(f"{name} failed ({rc}): {lib.cgs_last_error().decode()}")
+
+
+def set_contraction(mode):
+    """The calling thread's contraction arithmetic (include/cgs_hip.h): "f32" (exact fp32 MFMA, the default), "bx6" (opt-in:
+    the big layers through split-bf16 MFMA), "bx6_all" (test coverage); returns the previous mode's name."""
+    lib = load()
+    code = CONTRACTIONS[mode] if isinstance(mode, str) else int(mode)
+    prev = int(lib.cgs_get_contraction())
+    call("cgs_set_contraction", code)
+    return [k for k, v in CONTRACTIONS.items() if v == prev][0]
+
+
+def get_contraction():
+    code = int(load().cgs_get_contraction())
+    return [k for k, v in CONTRACTIONS.items() if v == code][0]
 
 
 def last_kernel():

@@ -62,6 +62,24 @@ const char* cgs_last_kernel(void);
  * of zero-padding taps the kernel skipped).  0 = the kernel skips nothing (executed = algorithmic).  For rooflines. */
 double cgs_last_executed_flops(void);
 
+/* Contraction arithmetic of the implicit-GEMM layers, per calling THREAD (default CGS_CONTRACTION_F32; no process-wide state).
+ * F32: v_mfma_f32_32x32x2_f32 -- exact fp32 products, an fp32 fma chain over K: what tf.nn.conv2d / conv2d_transpose / matmul
+ *      (nsgan/ops.py:41,55,81) compute at the reference's precision.  The headline numbers are measured in this mode.
+ * BX6: opt-in.  Calls with >= 128 output channels, a reduction over whole 32-channel chunks and a grid that fills the GPU run
+ *      on the bf16 matrix cores instead: every fp32 operand is split exactly into three bf16 pieces and six of the nine piece
+ *      products are accumulated in fp32 (the dropped ones are below 3 * 2^-24 of the product): the result differs from the F32
+ *      mode's by rounding errors of the size of an fp32 chain's own (igemm_bx6.hip; error analysis: DESIGN.md), in 6/16 of
+ *      the matrix time.  Everything else (families, epilogues, fused statistics, layouts) is unchanged; the packed-weight
+ *      layout differs, which cgs_conv_family reports as CGS_FAMILY_IGEMM_BX6 (key cached workspaces by it).
+ * BX6_ALL: BX6 for every call whose geometry allows it, whatever its size (test coverage of the kernel on small shapes).
+ * Set it before the thread's calls -- including cgs_conv_family / cgs_conv_signs_ok / cgs_conv_stat_* queries, which answer
+ * for the mode in force.  Returns CGS_OK or CGS_EINVAL. */
+#define CGS_CONTRACTION_F32 0
+#define CGS_CONTRACTION_BX6 1
+#define CGS_CONTRACTION_BX6_ALL 2
+int cgs_set_contraction(int mode);
+int cgs_get_contraction(void);
+
 /* Bytes of workspace a conv-family call needs for its packed copy of the weights
  * (op = one of CGS_CONV_* above; Cin/Cout are those of the LAYER, i.e. of the
  * forward op, for the backward variants too). */
@@ -84,6 +102,7 @@ size_t cgs_conv_ws_bytes_for(int op, int B, int H, int W, int Cin, int Cout, int
 #define CGS_FAMILY_PATCH 4      /* 3-channel strided / stem convs from an LDS patch (conv_patch.hip)      */
 #define CGS_FAMILY_TAPS 5       /* 4x4 stride-2 conv from ONE channel, K = 16 taps (convt_taps.hip); reads the weights unpacked */
 #define CGS_FAMILY_DOT 6        /* forward conv to <= 4 channels over a deep reduction (conv_dot.hip); weights unpacked         */
+#define CGS_FAMILY_IGEMM_BX6 7  /* implicit GEMM through split-bf16 MFMA (igemm_bx6.hip): only after cgs_set_contraction       */
 int cgs_conv_family(int op, int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int sh, int sw,
                     int epilogue, size_t ws_bytes);
 

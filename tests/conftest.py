@@ -34,3 +34,38 @@ def golden_feature0(g, arch, P):
         return g["feature0"]
     with torch.no_grad():
         return N.input_to_feature(arch, P, torch.from_numpy(g["z"])).numpy()
+
+
+def bx6_serves(Cin, Cout):
+    """Does the split-bf16 implicit GEMM (csrc/igemm_bx6.hip) serve a conv / deconv layer with these channel counts in at least
+    one direction?  Forward reduces over Cin into Cout, backward-data over Cout into Cin: a reduction over whole 32-channel chunks
+    into a multiple of 128 channels."""
+    return (Cin % 32 == 0 and Cout % 128 == 0) or (Cout % 32 == 0 and Cin % 128 == 0)
+
+
+@pytest.fixture(params=["f32", "bx6"])
+def contraction(request):
+    """Runs a kernel-level test once per contraction arithmetic of the library (include/cgs_hip.h, cgs_set_contraction): the exact
+    fp32 MFMA default and the opt-in split-bf16 form -- forced for every call whose geometry it can serve ("bx6_all"), so the small
+    test shapes reach it; shape-parametrized cases it cannot serve are skipped in that mode (they would repeat the f32 run).
+    The SAME assertions at the SAME tolerances hold in both modes."""
+    from cgs_amd import kernels as K
+    mode = request.param
+    if mode == "bx6":
+        ps = getattr(getattr(request.node, "callspec", None), "params", {})
+        if "Cin" in ps and "Cout" in ps and not bx6_serves(ps["Cin"], ps["Cout"]):
+            pytest.skip("no direction of this shape is served by the split-bf16 kernel")
+    K.set_contraction("bx6_all" if mode == "bx6" else "f32")
+    try:
+        yield mode
+    finally:
+        K.set_contraction("f32")
+
+
+@pytest.fixture(autouse=True)
+def _default_contraction(request):
+    """Engines put their own contraction mode in force when they run; no test inherits another one's."""
+    yield
+    if request.node.get_closest_marker("gpu") is not None:
+        from cgs_amd import kernels as K
+        K.set_contraction("f32")

@@ -88,21 +88,50 @@ def compare(tag, arch, B, K, G, got, want, eng=None):
             assert torch.equal(eng.feature_to_data(got[4]), got[0])               # returned images ARE G_tail(optimal_feature)
 
 
-@pytest.mark.parametrize("arch,B,K,G", CASES, ids=[case_id(c) for c in CASES])
-def test_full_size_refinement_matches_the_oracle(arch, B, K, G):
+# The opt-in split-bf16 contraction (RefineEngine(contraction="bx6"), `bench.py --contraction bx6`) is held to the SAME oracle cases at
+# the SAME tolerances, in its production mode (only the calls big enough to gain take it) -- for the configurations in which some
+# layer does: dcgan64 (four layers), cyclegan256 (the 256-channel residual and PatchGAN layers), and the fused small-net launches.
+BX6_ARCHS = ("dcgan64", "cyclegan256")
+
+
+def modes(cases_, fused_too=False):
+    out = []
+    for c in cases_:
+        out.append(c + ("f32",))
+        if c[0] in BX6_ARCHS or (fused_too and c[3] >= 8):
+            out.append(c + ("bx6",))
+    return out
+
+
+def count_bx6_launches(eng, fn):
+    """Run fn() under the per-launch profiler hook and return how many launches were igemm_bx6 kernels."""
+    from cgs_amd import kernels as K
+    K.PROFILE = {}
+    try:
+        fn()
+    finally:
+        prof, K.PROFILE = K.PROFILE, None
+    return sum(len(v[1]) for k, v in prof.items() if k.startswith("igemm_bx6_kernel"))
+
+
+@pytest.mark.parametrize("arch,B,K,G,contraction", modes(CASES), ids=[case_id(c[:4]) + ("-bx6" if c[4] == "bx6" else "") for c in modes(CASES)])
+def test_full_size_refinement_matches_the_oracle(arch, B, K, G, contraction):
     from cgs_amd.engine import RefineEngine
     from cgs_amd.nets import to_device
     d = torch.device("cuda:0")
     P, z, f0, want = oracle_case(arch, B, K, G)
-    eng = RefineEngine(arch, to_device(P, d), G * B, d, bn_groups=G)
+    eng = RefineEngine(arch, to_device(P, d), G * B, d, bn_groups=G, contraction=contraction)
+    if contraction == "bx6":      # the mode is not a no-op here: one forward + backward really launches the split-bf16 kernel
+        assert count_bx6_launches(eng, lambda: eng.compute_forward_logits_and_grad(f0.to(d))) >= 2
     f0_dev = eng.input_to_feature(z.to(d)).clone()
     assert relerr(f0_dev.cpu().numpy(), f0.numpy()) < 1e-4                         # propose (G head) at full batch
     got = [t.clone() for t in eng.refine(f0.to(d), K, 0.1)]                        # same theta0 for both arithmetics
     compare("eager", arch, B, K, G, got, want, eng)
 
 
-@pytest.mark.parametrize("arch,B,K,G", BENCHED, ids=[case_id(c) + "-hipgraph-2streams" for c in BENCHED])
-def test_the_benched_mode_matches_the_oracle(arch, B, K, G):
+@pytest.mark.parametrize("arch,B,K,G,contraction", modes(BENCHED, True),
+                         ids=[case_id(c[:4]) + "-hipgraph-2streams" + ("-bx6" if c[4] == "bx6" else "") for c in modes(BENCHED, True)])
+def test_the_benched_mode_matches_the_oracle(arch, B, K, G, contraction):
     """What `python bench.py` times: bench.IN_FLIGHT RefineEngine(use_graph=True) (2 for dcgan64, 4 for the small nets), one HIP stream
     each, all batches in flight, the K-step program REPLAYED (first call captures, second and third replay) -- at the configuration's full batch and K, each engine's
     third result against the oracle, and bit-equal to the other engine's and to its own second call (replays are deterministic)."""
@@ -112,7 +141,7 @@ def test_the_benched_mode_matches_the_oracle(arch, B, K, G):
     P, z, f0, want = oracle_case(arch, B, K, G)
     Pd = to_device(P, d)
     import bench
-    engines = [RefineEngine(arch, Pd, G * B, d, use_graph=True, bn_groups=G) for _ in range(bench.IN_FLIGHT[arch])]      # as many in flight as bench.py keeps
+    engines = [RefineEngine(arch, Pd, G * B, d, use_graph=True, bn_groups=G, contraction=contraction) for _ in range(bench.IN_FLIGHT[arch])]      # as many in flight as bench.py keeps
     streams = [torch.cuda.Stream(d) for _ in engines]
     zd = z.to(d)
     torch.cuda.synchronize(d)

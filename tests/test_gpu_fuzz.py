@@ -61,8 +61,29 @@ def cases(seed, n):
     return out
 
 
-@pytest.mark.parametrize("B,H,W,Cin,Cout,k,s", cases(11 + SEED, N_CASES))
-def test_conv_random_shapes(B, H, W, Cin, Cout, k, s):
+def wide_cases(seed, n):
+    """Channel counts the split-bf16 kernel serves (a reduction over whole 32-channel chunks into a multiple of 128 channels, in at
+    least one direction): 128 x 256 and 256 x 128 block tiles, ragged and one-pixel tiles, every kernel size and both strides."""
+    rs = np.random.RandomState(seed)
+    out = []
+    while len(out) < n:
+        B = int(rs.choice([1, 3, 130, 256]))
+        k, s = int(rs.choice([1, 3, 4, 5, 7])), int(rs.choice([1, 2]))
+        H, W = int(rs.randint(1, 13)), int(rs.randint(1, 13))
+        cin, cout = int(rs.choice([32, 64, 96, 128, 256])), int(rs.choice([128, 256, 384]))
+        if rs.randint(2):
+            cin, cout = cout, cin
+        if B * H * W * max(cin, cout) > 3_000_000 or B * H * W * cin * cout * k * k > 6e9:
+            continue
+        out.append((B, H, W, cin, cout, k, s))
+    return out
+
+
+N_WIDE = max(8, N_CASES // 2)
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,s", cases(11 + SEED, N_CASES) + wide_cases(111 + SEED, N_WIDE))
+def test_conv_random_shapes(B, H, W, Cin, Cout, k, s, contraction):
     from cgs_amd import kernels as K, lib
     d = dev()
     x = rnd((B, H, W, Cin), 1).requires_grad_(True)
@@ -77,8 +98,8 @@ def test_conv_random_shapes(B, H, W, Cin, Cout, k, s):
     close(K.conv2d_bwd_data(dy.to(d), w.to(d), (H, W), s, s), x.grad, ktol(k, Cout))
 
 
-@pytest.mark.parametrize("B,H,W,Cin,Cout,k,s", cases(23 + SEED, N_CASES))
-def test_deconv_random_shapes(B, H, W, Cin, Cout, k, s):
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,s", cases(23 + SEED, N_CASES) + wide_cases(123 + SEED, N_WIDE))
+def test_deconv_random_shapes(B, H, W, Cin, Cout, k, s, contraction):
     """conv2d_transpose from [B,H,W,Cin] to an output whose SAME conv maps back to (H, W): both admissible output sizes
     for stride 2 (2H and 2H-1) are drawn."""
     from cgs_amd import kernels as K, lib
@@ -181,17 +202,38 @@ def big_cases(seed, n):
     return out
 
 
-@pytest.mark.parametrize("B,H,Cin,Cout,k", big_cases(77 + SEED, max(6, N_CASES // 4)))
-def test_many_block_launch_equals_its_small_batch_pieces(B, H, Cin, Cout, k):
+def big_wide_cases(seed, n):
+    rs = np.random.RandomState(seed)
+    out = []
+    for _ in range(n):
+        H = int(rs.choice([4, 8, 16]))
+        cin, cout = int(rs.choice([64, 128])), int(rs.choice([128, 256]))
+        if rs.randint(2):
+            cin, cout = cout, cin
+        out.append((1024 if H <= 8 else 256, H, cin, cout, int(rs.choice([3, 4, 5]))))
+    return out
+
+
+@pytest.mark.parametrize("B,H,Cin,Cout,k", big_cases(77 + SEED, max(6, N_CASES // 4)) + big_wide_cases(177 + SEED, max(6, N_CASES // 4)))
+def test_many_block_launch_equals_its_small_batch_pieces(B, H, Cin, Cout, k, contraction):
     """Large grids take other code paths than small ones (16-deep K tiles at four blocks per CU, per-XCD block decode, pixel-major
     rows with zero-tap skipping, parity-first taps) and are too big for the CPU oracle.  A convolution is independent per sample,
     so the big launch must agree with the same op run on 64-sample pieces -- which take the small-grid paths the oracle tests
-    pin.  (Same tolerance as against the oracle: the pieces may split K and so add in another order.)"""
+    pin.  (Same tolerance as against the oracle: the pieces may split K and so add in another order.)
+    (In the split-bf16 mode the big launch runs igemm_bx6 and the pieces stay on the exact-fp32 kernels: the same comparison pins
+    the new kernel's large-grid paths to the oracle-tested ones.)"""
     from cgs_amd import kernels as K
     d = dev()
     x = rnd((B, H, H, Cin), 1).to(d)
     w, b = rnd((k, k, Cin, Cout), 2, 0.1).to(d), rnd((Cout,), 3, 0.2).to(d)
-    pieces = lambda fn, *ts: torch.cat([fn(*[t[i:i + 64].contiguous() for t in ts]) for i in range(0, B, 64)])
+    mode = K.CONTRACTION
+
+    def pieces(fn, *ts):
+        K.set_contraction("f32")
+        try:
+            return torch.cat([fn(*[t[i:i + 64].contiguous() for t in ts]) for i in range(0, B, 64)])
+        finally:
+            K.set_contraction(mode)
     y = K.conv2d_fwd(x, w, b, 2, 2)
     assert torch.allclose(y, pieces(lambda xx: K.conv2d_fwd(xx, w, b, 2, 2), x), rtol=0, atol=2e-5 * y.abs().max().item())
     dy = rnd(tuple(y.shape), 4).to(d)

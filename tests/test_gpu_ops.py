@@ -48,12 +48,15 @@ CONV_CASES = [  # B,H,W,Cin,Cout,k,s
     (3, 8, 16, 4, 32, 3, 1),         # LDS-patch, stride 1, 4 input channels
     (2, 64, 32, 1, 32, 4, 2),        # 1 channel, 4x4 kernel, 32x16 quads -> global-load quad kernel (Ws % 32 != 0)
     (2, 16, 64, 2, 16, 5, 2),        # 2 channels, 8x32 quads: LDS-patch kernel with a single 16-channel chunk
+    (9, 16, 16, 128, 256, 5, 2),     # N = 256 (split-bf16: 128 x 256 tiles, ragged last tile), both directions eligible
+    (256, 8, 8, 128, 256, 5, 2),     # the same pixel-major: whole one-pixel tiles, zero-tap skipping, heaviest-first order
+    (3, 9, 7, 96, 384, 3, 1),        # N = 384 (split-bf16: 256 x 128 tiles), 3 chunks of 32 channels, stride 1, odd sizes
 ]
 
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout,k,s", CONV_CASES)
 @pytest.mark.parametrize("epi", ["none", "lrelu"])
-def test_conv2d_fwd(B, H, W, Cin, Cout, k, s, epi):
+def test_conv2d_fwd(B, H, W, Cin, Cout, k, s, epi, contraction):
     from cgs_amd import kernels as K, lib
     x, w, b = rnd((B, H, W, Cin), 1), rnd((k, k, Cin, Cout), 2, 0.05), rnd((Cout,), 3, 0.1)
     want = R.conv2d(x, w, b, s, s)
@@ -62,6 +65,8 @@ def test_conv2d_fwd(B, H, W, Cin, Cout, k, s, epi):
     got = K.conv2d_fwd(x.to(dev()), w.to(dev()), b.to(dev()), s, s, lib.EPI_LRELU if epi == "lrelu" else lib.EPI_NONE)
     assert got.shape == want.shape
     close(got, want, 2e-5)
+    if contraction == "bx6":
+        assert lib.last_kernel().startswith("igemm_bx6_kernel") == (Cin % 32 == 0 and Cout % 128 == 0 and k <= 16), lib.last_kernel()
 
 
 def test_stride1_rgb_layers_use_the_patch_kernel():
@@ -101,8 +106,8 @@ def test_conv2d_smalln_head_tanh():
 
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout,k,s", CONV_CASES)
-def test_conv2d_bwd_data(B, H, W, Cin, Cout, k, s):
-    from cgs_amd import kernels as K
+def test_conv2d_bwd_data(B, H, W, Cin, Cout, k, s, contraction):
+    from cgs_amd import kernels as K, lib
     x = rnd((B, H, W, Cin), 1).requires_grad_(True)
     w = rnd((k, k, Cin, Cout), 2, 0.05)
     y = R.conv2d(x, w, torch.zeros(Cout), s, s)
@@ -110,6 +115,8 @@ def test_conv2d_bwd_data(B, H, W, Cin, Cout, k, s):
     (y * dy).sum().backward()
     got = K.conv2d_bwd_data(dy.to(dev()), w.to(dev()), (H, W), s, s)
     close(got, x.grad, 2e-5)
+    if contraction == "bx6":
+        assert lib.last_kernel().startswith("igemm_bx6_kernel") == (Cout % 32 == 0 and Cin % 128 == 0 and s <= 2), lib.last_kernel()
 
 
 DECONV_CASES = [  # B,H,W,Cin,Ho,Wo,Cout,k,s
@@ -129,12 +136,14 @@ DECONV_CASES = [  # B,H,W,Cin,Ho,Wo,Cout,k,s
     (2, 8, 32, 32, 16, 64, 4, 4, 2),      # N = 4, 4x4 kernel, LDS-patch
     (3, 20, 12, 32, 40, 24, 3, 5, 2),     # LDS-patch, 16x16 tiles hanging over both edges
     (2, 40, 40, 16, 80, 80, 2, 5, 2),     # LDS-patch, 16x16 tiles, 2.5 tiles per side
+    (130, 4, 4, 128, 8, 8, 256, 5, 2),    # N = 256 forward / 128 backward, pixel-major 4x4 class grids straddling tiles (split-bf16 both ways)
+    (3, 6, 5, 128, 11, 10, 128, 4, 2),    # odd output: parity classes of different size, 4x4 kernel, both directions eligible
 ]
 
 
 @pytest.mark.parametrize("B,H,W,Cin,Ho,Wo,Cout,k,s", DECONV_CASES)
 @pytest.mark.parametrize("epi", ["none", "affine_relu", "tanh"])
-def test_deconv2d_fwd(B, H, W, Cin, Ho, Wo, Cout, k, s, epi):
+def test_deconv2d_fwd(B, H, W, Cin, Ho, Wo, Cout, k, s, epi, contraction):
     from cgs_amd import kernels as K, lib
     x, w, b = rnd((B, H, W, Cin), 1), rnd((k, k, Cout, Cin), 2, 0.05), rnd((Cout,), 3, 0.1)
     a, c = rnd((Cout,), 5).abs() + 0.5, rnd((Cout,), 6, 0.3)
@@ -149,11 +158,13 @@ def test_deconv2d_fwd(B, H, W, Cin, Ho, Wo, Cout, k, s, epi):
     else:
         got = K.deconv2d_fwd(x.to(d), w.to(d), b.to(d), (Ho, Wo), s, s)
     close(got, want, 2e-5)
+    if contraction == "bx6":
+        assert lib.last_kernel().startswith("igemm_bx6_kernel") == (Cin % 32 == 0 and Cout % 128 == 0), lib.last_kernel()
 
 
 @pytest.mark.parametrize("B,H,W,Cin,Ho,Wo,Cout,k,s", DECONV_CASES)
-def test_deconv2d_bwd_data(B, H, W, Cin, Ho, Wo, Cout, k, s):
-    from cgs_amd import kernels as K
+def test_deconv2d_bwd_data(B, H, W, Cin, Ho, Wo, Cout, k, s, contraction):
+    from cgs_amd import kernels as K, lib
     x = rnd((B, H, W, Cin), 1).requires_grad_(True)
     w = rnd((k, k, Cout, Cin), 2, 0.05)
     y = R.deconv2d(x, w, torch.zeros(Cout), (B, Ho, Wo, Cout), s, s)
@@ -161,6 +172,8 @@ def test_deconv2d_bwd_data(B, H, W, Cin, Ho, Wo, Cout, k, s):
     (y * dy).sum().backward()
     got = K.deconv2d_bwd_data(dy.to(dev()), w.to(dev()), (H, W), s, s)
     close(got, x.grad, 2e-5)
+    if contraction == "bx6":
+        assert lib.last_kernel().startswith("igemm_bx6_kernel") == (Cout % 32 == 0 and Cin % 128 == 0), lib.last_kernel()
 
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout,k,name", [
@@ -212,11 +225,14 @@ def test_rows_form_of_small_channel_transposed_conv(B, H, W, Cin, Cout, k, name)
 
 @pytest.mark.parametrize("mode", ["relu_affine", "lrelu", "tanh"])
 @pytest.mark.parametrize("case", [(3, 16, 16, 64, 128, 5, 2), (3, 32, 32, 3, 64, 5, 2), (5, 28, 28, 1, 64, 4, 2), (2, 7, 9, 32, 40, 5, 2),
-                                  (2, 64, 64, 3, 64, 5, 2)])
-def test_bwd_data_epilogues(case, mode):
+                                  (2, 64, 64, 3, 64, 5, 2), (5, 12, 12, 128, 128, 5, 2)])
+def test_bwd_data_epilogues(case, mode, contraction):
     """The folded activation-gradient epilogues of both backward-data directions (and of the quad small-N kernel)."""
     from cgs_amd import kernels as K, lib
+    from conftest import bx6_serves
     B, H, W, Cin, Cout, k, s = case
+    if contraction == "bx6" and not bx6_serves(Cin, Cout):
+        pytest.skip("no direction of this shape is served by the split-bf16 kernel")
     d = dev()
     w = rnd((k, k, Cin, Cout), 2, 0.05)
     Ho, Wo = -(-H // s), -(-W // s)
@@ -467,8 +483,9 @@ def test_many_block_grids_use_the_16_deep_variant(case):
         assert name == "igemm_kernel<128, 128, 4, true, 16, true>", name
 
 
-@pytest.mark.parametrize("B,H,Cin,Cout,k", [(64, 16, 32, 128, 5), (1024, 8, 64, 64, 5), (5, 6, 32, 64, 3), (130, 8, 32, 68, 4)])
-def test_conv_with_fused_bn_statistics(B, H, Cin, Cout, k):
+@pytest.mark.parametrize("B,H,Cin,Cout,k", [(64, 16, 32, 128, 5), (1024, 8, 64, 64, 5), (5, 6, 32, 64, 3), (130, 8, 32, 68, 4), (512, 8, 64, 256, 5),
+                                            (3, 10, 32, 384, 3)])
+def test_conv_with_fused_bn_statistics(B, H, Cin, Cout, k, contraction):
     """cgs_conv2d_nhwc_fwd_stats: the conv's output is unchanged, its per-block partial sums reduce to the per-channel sum and sum
     of squares of that output, and cgs_bn_train_lrelu_fwd_from_partials gives the batch norm of the plain two-kernel path -- also on
     pixel-major / balanced tile orders (B = 1024) and with ragged last tiles / channel counts off the 64 grid."""
@@ -479,7 +496,7 @@ def test_conv_with_fused_bn_statistics(B, H, Cin, Cout, k):
     assert G == 2 * ((B * (H // 2) ** 2 + 127) // 128)
     part = torch.full((G, 2, Cout), float("nan"), device=d)
     y = K.conv2d_fwd_stats(x, w, b, part, 2, 2)
-    assert lib.last_kernel().startswith("igemm_kernel")
+    assert lib.last_kernel().startswith("igemm_bx6_kernel" if contraction == "bx6" else "igemm_kernel")
     y_plain = K.conv2d_fwd(x, w, b, 2, 2)
     close(y, y_plain, 2e-6)          # (not bit-equal in general: small grids take the split-K path without the statistics)
     close(y, R.conv2d(x.cpu(), w.cpu(), b.cpu(), 2, 2), 2e-5)
@@ -509,13 +526,20 @@ def test_conv_with_fused_bn_statistics(B, H, Cin, Cout, k):
     ("conv", 256, 16, 32, 64, 5, 2, 64),       # pixel-major whole tiles: four logical batches of 64 (fused batches of D's batch norm)
     ("conv", 512, 8, 64, 128, 4, 2, 128),
     ("deconv", 256, 4, 64, 32, 4, 2, 64),      # pixel-major transposed
+    ("conv", 8, 16, 64, 128, 3, 1, 1),         # 128 / 256 output channels: the shapes the split-bf16 kernel serves too
+    ("deconv", 4, 16, 64, 256, 3, 2, 1),
+    ("conv", 256, 8, 32, 128, 5, 2, 128),      # ... pixel-major whole tiles
+    ("deconv", 256, 4, 64, 128, 4, 2, 64),
 ], ids=lambda c: "-".join(str(v) for v in c))
-def test_fused_statistics_per_group_of_images(case):
+def test_fused_statistics_per_group_of_images(case, contraction):
     """cgs_conv_stat_layout + cgs_conv2d_nhwc_fwd_stats / cgs_deconv2d_nhwc_fwd_stats + cgs_groupnorm_lrelu_fwd_from_partials: the
     statistics of every group of consecutive images come out of the producing convolution's epilogue (either direction, image- and
     pixel-major row orders) and give the instance norm / per-logical-batch batch norm of the separate-pass kernels."""
     from cgs_amd import kernels as K, lib
     op, B, H, Cin, Cout, k, s_, grp = case
+    bx6 = contraction == "bx6"
+    if bx6 and not (Cin % 32 == 0 and Cout % 128 == 0):
+        pytest.skip("the forward direction of this shape is not served by the split-bf16 kernel")
     d = dev()
     x = rnd((B, H, H, Cin), 1).to(d)
     if op == "conv":
@@ -534,7 +558,7 @@ def test_fused_statistics_per_group_of_images(case):
         part = torch.full((lay[0], 2, Cout), float("nan"), device=d)
         y = K.deconv2d_fwd(x, w, b, (Ho, Ho), s_, s_, part=part)
         y_plain = K.deconv2d_fwd(x, w, b, (Ho, Ho), s_, s_)
-    assert lib.last_kernel().startswith("igemm_kernel")
+    assert lib.last_kernel().startswith("igemm_bx6_kernel" if bx6 else "igemm_kernel")
     close(y, y_plain, 2e-6)
     rows, rps, nseg, stride = lay
     groups = B // grp

@@ -85,12 +85,18 @@ def load_case(path):
 
 @pytest.mark.parametrize("path", G3, ids=lambda p: os.path.basename(p)[10:-4])
 @pytest.mark.parametrize("use_graph", [False, True], ids=["eager", "hipgraph"])
-def test_engine_matches_reference_golden(path, use_graph):
+@pytest.mark.parametrize("contraction", ["f32", "bx6_all"])
+def test_engine_matches_reference_golden(path, use_graph, contraction):
+    """Every golden captured from the reference's own collaborator.Refiner, on the exact-fp32 contraction and with every layer the
+    split-bf16 kernel can serve running on it ("bx6_all": at these small batches the production mode "bx6" would keep them all on
+    fp32) -- the same assertions at the same tolerances."""
     from cgs_amd.engine import RefineEngine
     from cgs_amd.nets import to_device
     g, arch, P, vmin, vmax = load_case(path)
+    if contraction != "f32" and "cyclegan_tiny" in path:
+        pytest.skip("no layer of this net has >= 128 output channels")
     d = dev()
-    eng = RefineEngine(arch, to_device(P, d), len(g["z"]), d, use_graph=use_graph)
+    eng = RefineEngine(arch, to_device(P, d), len(g["z"]), d, use_graph=use_graph, contraction=contraction)
     f0 = eng.input_to_feature(torch.from_numpy(g["z"]).to(d))
     feature0 = golden_feature0(g, arch, P)
     assert relerr(f0.cpu().numpy(), feature0) < 1e-4                  # the propose step (G head)

@@ -192,8 +192,41 @@ def test_c_abi_library_exports_every_declared_symbol():
     for name in declared:
         assert getattr(l, name) is not None
     assert l.cgs_version() >= 100
-    assert lib.conv_ws_bytes(lib.CONV_FWD, 5, 5, 2, 2, 64, 128) == 25 * 64 * 128 * 4
+    assert lib.conv_ws_bytes(lib.CONV_FWD, 5, 5, 2, 2, 64, 96) == 25 * 64 * 128 * 4     # (96 columns padded to 128)
+    # a layer the split-bf16 form can serve (reduction over whole 32-channel chunks into a multiple of 128 channels): room for its
+    # three bf16 planes, 6 bytes per weight, whatever the calling thread's contraction mode
+    assert lib.conv_ws_bytes(lib.CONV_FWD, 5, 5, 2, 2, 64, 128) == 25 * 64 * 128 * 6
     assert lib.bn_ws_bytes(1000, 128) > 0
+
+
+def test_contraction_mode_is_per_thread_host_state():
+    """cgs_set_contraction (include/cgs_hip.h): thread-local, validated, and the family query answers for the mode in force --
+    host arithmetic only (no launch)."""
+    import threading
+    from cgs_amd import lib
+    l = lib.load()
+    assert lib.get_contraction() == "f32"
+    big = (lib.CONV_FWD, 1024, 16, 16, 128, 0, 0, 256, 5, 5, 2, 2, lib.EPI_NONE, 1 << 26)        # dcgan64 d_h2 at the headline's batch
+    small = (lib.CONV_FWD, 4, 16, 16, 128, 0, 0, 256, 5, 5, 2, 2, lib.EPI_NONE, 1 << 26)
+    narrow = (lib.CONV_FWD, 1024, 32, 32, 64, 0, 0, 64, 5, 5, 2, 2, lib.EPI_NONE, 1 << 26)        # 64 output channels: never
+    assert l.cgs_conv_family(*big) == lib.FAMILY_IGEMM
+    try:
+        assert lib.set_contraction("bx6") == "f32" and lib.get_contraction() == "bx6"
+        assert l.cgs_conv_family(*big) == lib.FAMILY_IGEMM_BX6
+        assert l.cgs_conv_family(*small) == lib.FAMILY_IGEMM                 # too small to gain: stays on the exact-fp32 kernel
+        assert l.cgs_conv_family(*narrow) == lib.FAMILY_IGEMM
+        seen = []
+        t = threading.Thread(target=lambda: seen.append(int(l.cgs_get_contraction())))     # another host thread keeps its own default
+        t.start(); t.join()
+        assert seen == [lib.CONTRACTION_F32]
+        lib.set_contraction("bx6_all")
+        assert l.cgs_conv_family(*small) == lib.FAMILY_IGEMM_BX6 and l.cgs_conv_family(*narrow) == lib.FAMILY_IGEMM
+        assert l.cgs_set_contraction(7) == lib.EINVAL and lib.get_contraction() == "bx6_all"
+        # the fused-statistics queries answer for both implicit-GEMM families alike (same partial rows)
+        assert l.cgs_conv_stat_partials(1024, 16, 16, 128, 256, 5, 5, 2, 2, 1 << 26) == 2 * (1024 * 64 // 128)
+    finally:
+        lib.set_contraction("f32")
+    assert l.cgs_conv_stat_partials(1024, 16, 16, 128, 256, 5, 5, 2, 2, 1 << 26) == 2 * (1024 * 64 // 128)
 
 
 def test_group_statistics_layout_is_host_arithmetic():

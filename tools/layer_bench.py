@@ -7,6 +7,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from cgs_amd import kernels as K, lib
 
+K.set_contraction(os.environ.get("CGS_CONTRACTION", "f32"))      # f32 | bx6 | bx6_all (include/cgs_hip.h, cgs_set_contraction)
+
 arch = sys.argv[1] if len(sys.argv) > 1 else "dcgan64"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 d = torch.device("cuda:0")
@@ -45,14 +47,16 @@ for H, Ci, Co in convs:
     y = K.conv2d_fwd(x, w, b, out=alloc(B, H // 2, H // 2, Co)); dy = alloc(*y.shape).normal_()
     fl = 2.0 * B * (H // 2) ** 2 * Co * 25 * Ci
     t1 = timeit(lambda: K.conv2d_fwd(x, w, b, out=y)); t2 = timeit(lambda: K.conv2d_bwd_data(dy, w, (H, H), out=x))
-    print(f"conv   {H:3d}x{H:<3d} {Ci:4d}->{Co:<4d} fwd {t1:8.3f} ms {fl/t1/1e9:7.1f} TF | bwd {t2:8.3f} ms {fl/t2/1e9:7.1f} TF")
+    K.conv2d_fwd(x, w, b, out=y); kf = lib.last_kernel(); K.conv2d_bwd_data(dy, w, (H, H), out=x); kb = lib.last_kernel()
+    print(f"conv   {H:3d}x{H:<3d} {Ci:4d}->{Co:<4d} fwd {t1:8.3f} ms {fl/t1/1e9:7.1f} TF | bwd {t2:8.3f} ms {fl/t2/1e9:7.1f} TF   {kf.split('<')[0]} | {kb.split('<')[0]}")
     tot += t1 + t2
 for H, Ci, Co in deconvs:
     x = alloc(B, H, H, Ci).normal_(); w = torch.randn(5, 5, Co, Ci, device=d) * 0.02; b = torch.zeros(Co, device=d)
     y = K.deconv2d_fwd(x, w, b, (2 * H, 2 * H), out=alloc(B, 2 * H, 2 * H, Co)); dy = alloc(*y.shape).normal_()
     fl = 2.0 * B * H * H * Ci * 25 * Co
     t1 = timeit(lambda: K.deconv2d_fwd(x, w, b, (2 * H, 2 * H), out=y)); t2 = timeit(lambda: K.deconv2d_bwd_data(dy, w, (H, H), out=x))
-    print(f"deconv {H:3d}x{H:<3d} {Ci:4d}->{Co:<4d} fwd {t1:8.3f} ms {fl/t1/1e9:7.1f} TF | bwd {t2:8.3f} ms {fl/t2/1e9:7.1f} TF")
+    K.deconv2d_fwd(x, w, b, (2 * H, 2 * H), out=y); kf = lib.last_kernel(); K.deconv2d_bwd_data(dy, w, (H, H), out=x); kb = lib.last_kernel()
+    print(f"deconv {H:3d}x{H:<3d} {Ci:4d}->{Co:<4d} fwd {t1:8.3f} ms {fl/t1/1e9:7.1f} TF | bwd {t2:8.3f} ms {fl/t2/1e9:7.1f} TF   {kf.split('<')[0]} | {kb.split('<')[0]}")
     tot += t1 + t2
 print(f"sum fwd+bwd of all conv-family layers: {tot:.2f} ms for B={B}")
 if os.environ.get("LB_EPI"):
