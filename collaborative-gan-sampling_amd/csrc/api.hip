@@ -197,7 +197,7 @@ static size_t conv_packed_bytes(int op, int kh, int kw, int sh, int sw, int Cin,
     // (the split-bf16 form keeps three bf16 planes = 6 bytes per weight: sized for it wherever its geometry applies, whatever the
     // calling thread's contraction mode, so a workspace serves both)
     const int Cred = dirT ? Cs : Cb, Nn = dirT ? Cb : Cs;
-    const size_t per_w = ((Cred % 32) == 0 && (Nn % 128) == 0 && kh <= 16 && kw <= 16) ? 6 : sizeof(float);
+    const size_t per_w = ((Cred % 32) == 0 && (Nn % 64) == 0 && kh <= 16 && kw <= 16) ? 6 : sizeof(float);
     if (!dirT) return (size_t)cgs_round_up(kh * kw * Cb, CGS_BK) * cgs_round_up(Cs, 64) * per_w;
     // T: per parity class, taps of that class (independent of the spatial size: pads only permute classes)
     size_t n = 0;

@@ -1086,6 +1086,10 @@ int cgs_igemm_launch(const IgemmParams& p_in, void* slab, size_t slab_bytes, hip
     if (wide && vec && p.splitk == 1) {
         const long wb = igemm_blocks(p, 128);
         if (wb >= 256 && wb < 512) { wide = false; mid = true; }
+        // a launch that leaves norm statistics or a sign mask comes out of the one-pass epilogue and cannot be split over K: under
+        // 256 blocks of 128x128 it would leave most CUs idle (config 5's PatchGAN 4x4 128->256 layer: 128 blocks, 54 TFLOP/s) --
+        // as 128x64 blocks at least every CU gets one
+        else if (wb < 256 && (p.stat_part || p.sign_out)) { wide = false; mid = true; }
     }
     bool deep = true;
     if (vec && p.splitk == 1 && !mid) {

@@ -38,6 +38,15 @@ __device__ __forceinline__ void bx6_split2(float x0, float x1, unsigned& p0, uns
     p2 = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, q1), __builtin_bit_cast(unsigned, q0), 0x07060302);
 }
 
+// buffer_load_dwordx4 ... lds: lane l's 16 bytes at (voffset_l + soffset) land at lds_base + 16 l (wave-uniform base in M0; an
+// out-of-range lane writes zeros).  The host pass of a kernel TEMPLATE cannot take this builtin (the instantiation is dropped
+// without a diagnostic and the launch stub stays undefined), hence the device-only body.
+__device__ __forceinline__ void bx6_dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned char* lds_base, unsigned voffset, int soffset) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_base, 16, voffset, soffset, 0, 0);
+#endif
+}
+
 // ------------------------------------------------------------------------------------------------
 // weight packing: w[kh][kw][Cb][Cs] -> per class [K/16][plane][Np][16] bf16 (K in igemm.hip's VEC order: 32-channel chunk, tap,
 // channel; a 16-deep tile is one half of a (chunk, tap))
@@ -95,15 +104,20 @@ int cgs_pack_weights_bx6(const IgemmParams& p, const CgsLayer& L, bool dirT, con
 // ------------------------------------------------------------------------------------------------
 // main kernel
 // ------------------------------------------------------------------------------------------------
+#ifndef BX6_V
+#define BX6_V 1          // bit 0: the weight tile goes global -> LDS directly (buffer_load ... lds), no register staging
+#endif
+// waves per SIMD the register budget is sized for: the four-wave blocks run two per CU (256 registers per lane); the two-wave
+// 256 x 64 block's LDS lets two blocks = four waves share a CU, one per SIMD (512 registers: its eight staged float4 fit)
 template <int BM, int BN, bool PAR>
-__global__ __launch_bounds__(BM* BN / 128, BM* BN > 128 * 256 ? 1 : 2) void igemm_bx6_kernel(IgemmParams p) {
+__global__ __launch_bounds__(BM* BN / 128, BM* BN == 128 * 256 ? 2 : 1) void igemm_bx6_kernel(IgemmParams p) {
     constexpr int WNN = BN / 64;                       // waves along N; wave tile 128 x 64
     constexpr int NW = (BM / 128) * WNN, NT = 64 * NW;
     constexpr int PITCH = 32;                          // bytes of an LDS row: 16 bf16 = one K stage of one plane
     constexpr int PLA = BM * PITCH, PLB = BN * PITCH;  // bytes of an A / B plane
     constexpr int BUF = 3 * (PLA + PLB);               // one stage: A planes [3][BM][16], then B planes [3][BN][16]
     constexpr int AI = BM * 4 / NT, AR = NT / 4;       // float4 of A per thread and stage; rows per staging pass
-    constexpr int NB = BN * 6 / NT;                    // 16-byte pieces of B per thread and stage (3 planes x BN columns x 2 halves)
+    [[maybe_unused]] constexpr int NB = BN * 6 / NT;   // 16-byte pieces of B per thread and stage when staged through registers (3 planes x BN columns x 2 halves)
     constexpr int ER = 32, LDE = 64 + 4;               // epilogue staging: 32 rows of the wave tile at a time
     constexpr int STAGE_B = NW * ER * LDE * 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -181,7 +195,6 @@ __global__ __launch_bounds__(BM* BN / 128, BM* BN > 128 * 256 ? 1 : 2) void igem
     }
 #undef DECODE_ROW
     const int nk = (c.K + 15) / 16;                     // 16-deep K tiles (K % 32 == 0)
-    const int ntaps = c.nty * c.ntx;
     // zero-tap skipping: every row of a one-pixel tile sees the same taps outside the image -> their K tiles are never executed
     const bool skip_ok = one_pix;
     const int u_iy = t_r * p.S + c.dy0, u_ix = t_cc * p.S + c.dx0;
@@ -243,6 +256,18 @@ __global__ __launch_bounds__(BM* BN / 128, BM* BN > 128 * 256 ? 1 : 2) void igem
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void*)((const unsigned short*)p.wp + (size_t)c.w_off * 3), 0, 0x7ffffff0, 0x00020000);
     const int b_tile_bytes = 3 * p.Np * PITCH;
+#if BX6_V & 1
+    // LDS-DMA: a wave-instruction copies 1 KB = 32 columns of one plane (lane l -> bytes [16 l, 16 l + 16) of the piece, in global
+    // memory and in LDS alike: the packed tile and its LDS image are the same linear array); piece = wave + NW * u
+    constexpr int PPP = BN / 32;                       // pieces per plane
+    constexpr int PB = 3 * PPP / NW;                   // pieces per wave and stage
+    unsigned b_voff[PB];
+#pragma unroll
+    for (int u = 0; u < PB; ++u) {
+        const int piece = wave + NW * u, plane = piece / PPP, sub = piece - plane * PPP;
+        b_voff[u] = (unsigned)(plane * p.Np * PITCH + n0 * PITCH + sub * 1024 + lane * 16);
+    }
+#else
     unsigned b_voff[NB], b_lds[NB];
 #pragma unroll
     for (int u = 0; u < NB; ++u) {
@@ -251,9 +276,10 @@ __global__ __launch_bounds__(BM* BN / 128, BM* BN > 128 * 256 ? 1 : 2) void igem
         b_voff[u] = (unsigned)(plane * p.Np * PITCH + n0 * PITCH + rem * 16);
         b_lds[u] = (unsigned)(3 * PLA + plane * PLB + rem * 16);
     }
+    u32x4 rb[NB];
+#endif
     unsigned a_off[AI];
     f32x4 ra[AI];
-    u32x4 rb[NB];
 #define ADDR_TILE(s_)                                                                                           \
     do {                                                                                                        \
         const int ta_ = cgs_tap_order((s_).ia, c.nty, PAR), tb_ = cgs_tap_order((s_).ib, c.ntx, PAR);           \
@@ -263,7 +289,21 @@ __global__ __launch_bounds__(BM* BN / 128, BM* BN > 128 * 256 ? 1 : 2) void igem
         _Pragma("unroll") for (int i = 0; i < AI; ++i)                                                          \
             a_off[i] = (tapmask[i] & need_) == need_ ? rowoff[i] + soff_ : 0xFFFFFFF0u;                         \
     } while (0)
-#define ISSUE_TILE(s_)                                                                                          \
+#if BX6_V & 1
+    // (the weight tile of stage s_ goes straight into LDS buffer DST_: free since the barrier that ended the stage before, complete
+    // before the one that ends this stage -- the barrier's fence waits for the DMA)
+#define ISSUE_TILE(s_, DST_)                                                                                    \
+    do {                                                                                                        \
+        _Pragma("unroll") for (int i = 0; i < AI; ++i)                                                          \
+            ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, a_off[i], 0, 0));  \
+        const int b_soff_ = (s_).kt * b_tile_bytes;                                                             \
+        _Pragma("unroll") for (int u = 0; u < PB; ++u) {                                                        \
+            const int piece_ = wave + NW * u, plane_ = piece_ / PPP, sub_ = piece_ - plane_ * PPP;              \
+            bx6_dma16(w_rsrc, lds + (DST_) * BUF + 3 * PLA + plane_ * PLB + sub_ * 1024, b_voff[u], b_soff_);   \
+        }                                                                                                       \
+    } while (0)
+#else
+#define ISSUE_TILE(s_, DST_)                                                                                    \
     do {                                                                                                        \
         _Pragma("unroll") for (int i = 0; i < AI; ++i)                                                          \
             ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, a_off[i], 0, 0));  \
@@ -271,6 +311,7 @@ __global__ __launch_bounds__(BM* BN / 128, BM* BN > 128 * 256 ? 1 : 2) void igem
         _Pragma("unroll") for (int u = 0; u < NB; ++u)                                                          \
             rb[u] = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, b_voff[u], b_soff_, 0);                       \
     } while (0)
+#endif
     const unsigned a_lds = (unsigned)(ar * PITCH + aq * 8);
 #define STORE_TILE(BUF_)                                                                                        \
     do {                                                                                                        \
@@ -284,8 +325,13 @@ __global__ __launch_bounds__(BM* BN / 128, BM* BN > 128 * 256 ? 1 : 2) void igem
             *(u32x2*)(d_ + PLA) = u32x2{q1_[0], q1_[1]};                                                        \
             *(u32x2*)(d_ + 2 * PLA) = u32x2{q2_[0], q2_[1]};                                                    \
         }                                                                                                       \
-        _Pragma("unroll") for (int u = 0; u < NB; ++u) *(u32x4*)(base_ + b_lds[u]) = rb[u];                     \
+        STORE_B(base_);                                                                                         \
     } while (0)
+#if BX6_V & 1
+#define STORE_B(base_)
+#else
+#define STORE_B(base_) _Pragma("unroll") for (int u = 0; u < NB; ++u) *(u32x4*)((base_) + b_lds[u]) = rb[u];
+#endif
 
     f32x16 acc[4][2];
 #pragma unroll
@@ -324,7 +370,7 @@ __global__ __launch_bounds__(BM* BN / 128, BM* BN > 128 * 256 ? 1 : 2) void igem
         KIt ld;                                                                                                 \
         KIT_SEL(ld, (NXT_).kt < nk, NXT_, cur);                                                                 \
         ADDR_TILE(ld);                                                                                          \
-        ISSUE_TILE(ld);                                                                                         \
+        ISSUE_TILE(ld, (BUF_) ^ 1);                                                                             \
         __builtin_amdgcn_sched_barrier(0);                                                                      \
         COMPUTE(BUF_);                                                                                          \
         STORE_TILE((BUF_) ^ 1);                                                                                 \
@@ -335,7 +381,7 @@ __global__ __launch_bounds__(BM* BN / 128, BM* BN > 128 * 256 ? 1 : 2) void igem
     KIt cur = kit_first();
     if (cur.kt < nk) {
         ADDR_TILE(cur);
-        ISSUE_TILE(cur);
+        ISSUE_TILE(cur, 0);
         STORE_TILE(0);
     }
     __syncthreads();
@@ -358,6 +404,7 @@ __global__ __launch_bounds__(BM* BN / 128, BM* BN > 128 * 256 ? 1 : 2) void igem
 #undef COMPUTE
 #undef MM
 #undef STORE_TILE
+#undef STORE_B
 #undef ISSUE_TILE
 #undef ADDR_TILE
 
@@ -409,7 +456,7 @@ __global__ __launch_bounds__(BM* BN / 128, BM* BN > 128 * 256 ? 1 : 2) void igem
             for (int off = 16; off < 64; off <<= 1)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { st_a[e] += __shfl_xor(st_a[e], off); st_b[e] += __shfl_xor(st_b[e], off); }
-            if (rsub == 0 && n < p.N && m0 + wm * 128 + (tm >> 1) * 64 < M) {      // (no partial row exists for 64-row groups past M)
+            if (rsub == 0 && n < p.N && m0 + wm * 128 < M) {      // (a 128-row tile wholly past M has no partial rows; a half past M writes its zeros)
                 float* dst = p.stat_part + ((size_t)(cls_i * p.stat_cls_rows + (m0 / 128 + wm) * 2 + (tm >> 1)) * 2) * p.N + n;
                 *(f32x4*)dst = st_a;
                 *(f32x4*)(dst + p.N) = st_b;
@@ -419,18 +466,18 @@ __global__ __launch_bounds__(BM* BN / 128, BM* BN > 128 * 256 ? 1 : 2) void igem
     }
 }
 
-// which calls the split-bf16 form serves: the 32-channel-chunk K order (Cred % 32 == 0, <= 16 taps per axis), whole 128-column
-// n-tiles; unless any_size, grids that fill the GPU (>= 256 blocks) over a reduction deep enough to amortise the 128-register
+// which calls the split-bf16 form serves: the 32-channel-chunk K order (Cred % 32 == 0, <= 16 taps per axis), whole 64-column
+// wave tiles; unless any_size, grids that fill the GPU (>= 256 blocks) over a reduction deep enough to amortise the 128-register
 // epilogue -- smaller calls keep the exact-fp32 kernel with its split-K forms
 int cgs_igemm_bx6_ok(const CgsLayer& L, bool dirT, int B, bool any_size) {
     const int Cred = dirT ? L.Cs : L.Cb, N = dirT ? L.Cb : L.Cs;
-    if ((Cred % 32) || (N % 128) || L.kh > 16 || L.kw > 16) return 0;
+    if ((Cred % 32) || (N % 64) || L.kh > 16 || L.kw > 16) return 0;
     if (dirT && (L.sh > 2 || L.sw > 2)) return 0;
     if (any_size) return 1;
     const long M = (long)B * (dirT ? (long)L.Hb * L.Wb : (long)L.Hs * L.Ws);
-    const long blocks = (M / 128) * (N / 128) / ((N % 256) == 0 ? 2 : 1);
+    const long blocks = (N % 256) == 0 ? (M / 128) * (N / 256) : (N % 128) == 0 ? (M / 256) * (N / 128) : (M / 256) * (N / 64);
     const long K = (long)L.kh * L.kw * Cred / (dirT ? L.sh * L.sw : 1);
-    return blocks >= 256 && K >= 1024;
+    return blocks >= 256 && K >= 512;
 }
 
 template <int BM, int BN, bool PAR>
@@ -463,7 +510,7 @@ int cgs_igemm_bx6_launch(const IgemmParams& p_in, hipStream_t s) {
     p.splitk = 1; p.slab = nullptr;
     p.prio_t[0] = p.prio_t[1] = p.prio_t[2] = 0;
     p.uni = 0;
-    if (!p.vec || (p.N % 128) || p.Np != p.N) return cgs_set_error(CGS_EINVAL, "igemm_bx6: needs Cred %% 32 == 0 and N %% 128 == 0");
+    if (!p.vec || (p.N % 64) || p.Np != p.N) return cgs_set_error(CGS_EINVAL, "igemm_bx6: needs Cred %% 32 == 0 and N %% 64 == 0");
     if (p.sign_out) return cgs_set_error(CGS_EINVAL, "igemm_bx6: sign masks are a feature of the fp32 kernel");
     const bool n256 = (p.N % 256) == 0;
     const int BM = n256 ? 128 : 256;
@@ -480,5 +527,6 @@ int cgs_igemm_bx6_launch(const IgemmParams& p_in, hipStream_t s) {
     }
     cgs_igemm_count_flops(p, BM);
     if (n256) return p.tap_parity ? launch_bx6<128, 256, true>(p, s) : launch_bx6<128, 256, false>(p, s);
-    return p.tap_parity ? launch_bx6<256, 128, true>(p, s) : launch_bx6<256, 128, false>(p, s);
+    if ((p.N % 128) == 0) return p.tap_parity ? launch_bx6<256, 128, true>(p, s) : launch_bx6<256, 128, false>(p, s);
+    return p.tap_parity ? launch_bx6<256, 64, true>(p, s) : launch_bx6<256, 64, false>(p, s);
 }

@@ -39,8 +39,8 @@ def golden_feature0(g, arch, P):
 def bx6_serves(Cin, Cout):
     """Does the split-bf16 implicit GEMM (csrc/igemm_bx6.hip) serve a conv / deconv layer with these channel counts in at least
     one direction?  Forward reduces over Cin into Cout, backward-data over Cout into Cin: a reduction over whole 32-channel chunks
-    into a multiple of 128 channels."""
-    return (Cin % 32 == 0 and Cout % 128 == 0) or (Cout % 32 == 0 and Cin % 128 == 0)
+    into whole 64-column wave tiles."""
+    return (Cin % 32 == 0 and Cout % 64 == 0) or (Cout % 32 == 0 and Cin % 64 == 0)
 
 
 @pytest.fixture(params=["f32", "bx6"])

