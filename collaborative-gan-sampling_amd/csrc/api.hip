@@ -142,7 +142,7 @@ static int run_dir(const CgsLayer& L, bool dirT, int B, const float* in, const f
         p.out = out + (size_t)b0 * (out_img / 4);
         p.ep_aux = ep_aux ? ep_aux + (size_t)b0 * (out_img / 4) : nullptr;
         p.sign_out = sign_out ? sign_out + (size_t)b0 * p.Hout * p.Wout : nullptr;      // (plane-major: the chunk's pixels inside every plane)
-        int rc = bx6 ? cgs_igemm_bx6_launch(p, s) : cgs_igemm_launch(p, (char*)ws + need, ws_bytes - need, s);
+        int rc = bx6 ? cgs_igemm_bx6_launch(p, s, (char*)ws + need, ws_bytes - need) : cgs_igemm_launch(p, (char*)ws + need, ws_bytes - need, s);
         if (rc) return rc;
     }
     return CGS_OK;

@@ -108,7 +108,7 @@ void cgs_igemm_count_flops(const IgemmParams& p, int BM);
 int cgs_igemm_bx6_ok(const CgsLayer& L, bool dirT, int B, bool any_size);
 size_t cgs_igemm_bx6_packed_bytes(const IgemmParams& p);
 int cgs_pack_weights_bx6(const IgemmParams& p, const CgsLayer& L, bool dirT, const float* w, void* packed, hipStream_t s);
-int cgs_igemm_bx6_launch(const IgemmParams& p, hipStream_t s);
+int cgs_igemm_bx6_launch(const IgemmParams& p, hipStream_t s, void* dbg = nullptr, size_t dbg_bytes = 0);   // (dbg: stamps of a diagnostic build)
 int cgs_contraction_mode();                             // thread-local: CGS_CONTRACTION_* (api.hip)
 int cgs_igemm_row_order(const IgemmParams& p);         // GEMM row order the launcher will pick: 0 (image, pixel); 1 (pixel, image); 2 (pixel, image) in whole 128-image tiles
 size_t cgs_convt_quad_ws_floats_bound(int kh, int kw, int Cs);

@@ -18,6 +18,7 @@
 // store (5.5 vector-ALU operations per element, once per block and K stage).  LDS rows are 32 bytes (one 16-deep K stage of
 // one plane), so a fragment read of the 32 x 32 x 16 MFMA is a linear 1 KB per wave.
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "cgs_internal.h"
 #include "igemm_epilogue.h"
@@ -292,10 +293,16 @@ __global__ __launch_bounds__(BM* BN / 128, BM* BN == 128 * 256 ? 2 : 1) void ige
 #if BX6_V & 1
     // (the weight tile of stage s_ goes straight into LDS buffer DST_: free since the barrier that ended the stage before, complete
     // before the one that ends this stage -- the barrier's fence waits for the DMA)
+#define ISSUE_A(RA_)                                                                                            \
+    _Pragma("unroll") for (int i = 0; i < AI; ++i)                                                              \
+        RA_[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, a_off[i], 0, 0));
 #define ISSUE_TILE(s_, DST_)                                                                                    \
     do {                                                                                                        \
-        _Pragma("unroll") for (int i = 0; i < AI; ++i)                                                          \
-            ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, a_off[i], 0, 0));  \
+        ISSUE_A(ra);                                                                                            \
+        ISSUE_B(s_, DST_);                                                                                      \
+    } while (0)
+#define ISSUE_B(s_, DST_)                                                                                       \
+    do {                                                                                                        \
         const int b_soff_ = (s_).kt * b_tile_bytes;                                                             \
         _Pragma("unroll") for (int u = 0; u < PB; ++u) {                                                        \
             const int piece_ = wave + NW * u, plane_ = piece_ / PPP, sub_ = piece_ - plane_ * PPP;              \
@@ -303,23 +310,30 @@ __global__ __launch_bounds__(BM* BN / 128, BM* BN == 128 * 256 ? 2 : 1) void ige
         }                                                                                                       \
     } while (0)
 #else
-#define ISSUE_TILE(s_, DST_)                                                                                    \
+#define ISSUE_A(RA_)                                                                                            \
+    _Pragma("unroll") for (int i = 0; i < AI; ++i)                                                              \
+        RA_[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, a_off[i], 0, 0));
+#define ISSUE_B(s_, DST_)                                                                                       \
     do {                                                                                                        \
-        _Pragma("unroll") for (int i = 0; i < AI; ++i)                                                          \
-            ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, a_off[i], 0, 0));  \
         const int b_soff_ = (s_).kt * b_tile_bytes;                                                             \
         _Pragma("unroll") for (int u = 0; u < NB; ++u)                                                          \
             rb[u] = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, b_voff[u], b_soff_, 0);                       \
     } while (0)
+#define ISSUE_TILE(s_, DST_)                                                                                    \
+    do {                                                                                                        \
+        ISSUE_A(ra);                                                                                            \
+        ISSUE_B(s_, DST_);                                                                                      \
+    } while (0)
 #endif
     const unsigned a_lds = (unsigned)(ar * PITCH + aq * 8);
-#define STORE_TILE(BUF_)                                                                                        \
+#define STORE_TILE(BUF_) STORE_TILE_R(BUF_, ra)
+#define STORE_TILE_R(BUF_, RA_)                                                                                 \
     do {                                                                                                        \
         unsigned char* base_ = lds + (BUF_) * BUF;                                                              \
         _Pragma("unroll") for (int i = 0; i < AI; ++i) {                                                        \
             unsigned q0_[2], q1_[2], q2_[2];                                                                    \
-            bx6_split2(ra[i][0], ra[i][1], q0_[0], q1_[0], q2_[0]);                                             \
-            bx6_split2(ra[i][2], ra[i][3], q0_[1], q1_[1], q2_[1]);                                             \
+            bx6_split2(RA_[i][0], RA_[i][1], q0_[0], q1_[0], q2_[0]);                                           \
+            bx6_split2(RA_[i][2], RA_[i][3], q0_[1], q1_[1], q2_[1]);                                           \
             unsigned char* d_ = base_ + a_lds + i * AR * PITCH;                                                 \
             *(u32x2*)(d_) = u32x2{q0_[0], q0_[1]};                                                              \
             *(u32x2*)(d_ + PLA) = u32x2{q1_[0], q1_[1]};                                                        \
@@ -362,9 +376,19 @@ __global__ __launch_bounds__(BM* BN / 128, BM* BN == 128 * 256 ? 2 : 1) void ige
         const bool c__ = (c_);                                                                                  \
         d_.kt = c__ ? a_.kt : b_.kt; d_.sub = c__ ? a_.sub : b_.sub; d_.ia = c__ ? a_.ia : b_.ia;               \
         d_.ib = c__ ? a_.ib : b_.ib; d_.chunk = c__ ? a_.chunk : b_.chunk;                                      \
+        /* wave-uniform by construction; say so, or the scalar offsets derived from them get waterfall loops */ \
+        d_.kt = __builtin_amdgcn_readfirstlane(d_.kt); d_.sub = __builtin_amdgcn_readfirstlane(d_.sub);         \
+        d_.ia = __builtin_amdgcn_readfirstlane(d_.ia); d_.ib = __builtin_amdgcn_readfirstlane(d_.ib);           \
+        d_.chunk = __builtin_amdgcn_readfirstlane(d_.chunk);                                                    \
     } while (0)
     // one K stage: issue the next stage's loads, contract this one from LDS buffer BUF_, split + stage the next one into the
     // other buffer, one barrier.  After the last stage the "next" one is a harmless reload of it into the dead buffer.
+#ifdef BX6_STAMPS      // diagnostic build only (tools/bx6_probe.py): cycles per phase of a stage, summed over the block's K loop
+#define STAMP(i_) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_sum[i_] += t_ - st_last; st_last = t_; __builtin_amdgcn_sched_barrier(0); }
+    unsigned long long st_sum[4] = {0, 0, 0, 0}, st_last = 0, st_rt0 = 0;
+#else
+#define STAMP(i_)
+#endif
 #define TILE_BODY(BUF_, NXT_)                                                                                   \
     {                                                                                                           \
         KIt ld;                                                                                                 \
@@ -372,12 +396,20 @@ __global__ __launch_bounds__(BM* BN / 128, BM* BN == 128 * 256 ? 2 : 1) void ige
         ADDR_TILE(ld);                                                                                          \
         ISSUE_TILE(ld, (BUF_) ^ 1);                                                                             \
         __builtin_amdgcn_sched_barrier(0);                                                                      \
+        STAMP(0);                                                                                               \
         COMPUTE(BUF_);                                                                                          \
+        STAMP(1);                                                                                               \
         STORE_TILE((BUF_) ^ 1);                                                                                 \
+        STAMP(2);                                                                                               \
         __syncthreads();                                                                                        \
+        STAMP(3);                                                                                               \
         cur = NXT_;                                                                                             \
     }
 
+    // Measured and not kept (tools/sessions/r04_i.sh, the ten 107-GFLOP layers of the headline, sum of the launches): the activations two
+    // stages ahead in a second register set with their split + LDS stores inside the MFMA stream 5734 us against 5762 us for this
+    // form; that plus the stage's loads one per two MFMAs inside the stream (sched_group_barrier) 5691 us, with spills.  The kernel
+    // does not hang on its per-wave schedule: the matrix pipe is 43-48 % busy in every form ("bx6").
     KIt cur = kit_first();
     if (cur.kt < nk) {
         ADDR_TILE(cur);
@@ -386,6 +418,10 @@ __global__ __launch_bounds__(BM* BN / 128, BM* BN == 128 * 256 ? 2 : 1) void ige
     }
     __syncthreads();
     __builtin_amdgcn_s_setprio(0);
+#ifdef BX6_STAMPS
+    st_rt0 = __builtin_amdgcn_s_memrealtime();
+    st_last = __builtin_amdgcn_s_memtime();
+#endif
     {
         KIt n1 = cur;
         if (cur.kt < nk) n1 = kit_next(cur);
@@ -399,6 +435,17 @@ __global__ __launch_bounds__(BM* BN / 128, BM* BN == 128 * 256 ? 2 : 1) void ige
         }
         if (cur.kt < nk) TILE_BODY(0, n1);               // an odd last stage
     }
+
+#ifdef BX6_STAMPS
+    if (p.slab && tid == 0) {
+        unsigned long long* dbg = (unsigned long long*)p.slab + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8;
+        dbg[0] = st_rt0; dbg[1] = __builtin_amdgcn_s_memrealtime();
+        dbg[2] = st_sum[0]; dbg[3] = st_sum[1]; dbg[4] = st_sum[2]; dbg[5] = st_sum[3];
+        dbg[6] = (unsigned long long)nk;
+        dbg[7] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
+    }
+#endif
+#undef STAMP
 #undef TILE_BODY
 #undef KIT_SEL
 #undef COMPUTE
@@ -406,6 +453,9 @@ __global__ __launch_bounds__(BM* BN / 128, BM* BN == 128 * 256 ? 2 : 1) void ige
 #undef STORE_TILE
 #undef STORE_B
 #undef ISSUE_TILE
+#undef ISSUE_A
+#undef ISSUE_B
+#undef STORE_TILE_R
 #undef ADDR_TILE
 
     // ---- epilogue: the wave tile 32 rows at a time through LDS (the K-loop buffers are dead: every wave is past the last
@@ -505,9 +555,12 @@ static int launch_bx6(const IgemmParams& p, hipStream_t s) {
     return CGS_OK;
 }
 
-int cgs_igemm_bx6_launch(const IgemmParams& p_in, hipStream_t s) {
+int cgs_igemm_bx6_launch(const IgemmParams& p_in, hipStream_t s, void* dbg, size_t dbg_bytes) {
     IgemmParams p = p_in;
     p.splitk = 1; p.slab = nullptr;
+#ifdef BX6_STAMPS
+    if (getenv("CGS_STAMP") && dbg && dbg_bytes >= 64) p.slab = (float*)dbg;
+#endif
     p.prio_t[0] = p.prio_t[1] = p.prio_t[2] = 0;
     p.uni = 0;
     if (!p.vec || (p.N % 64) || p.Np != p.N) return cgs_set_error(CGS_EINVAL, "igemm_bx6: needs Cred %% 32 == 0 and N %% 64 == 0");
