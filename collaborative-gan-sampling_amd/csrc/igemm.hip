@@ -1034,7 +1034,8 @@ int cgs_igemm_launch(const IgemmParams& p_in, void* slab, size_t slab_bytes, hip
     p.splitk = 1; p.slab = nullptr;
     p.prio_t[0] = p.prio_t[1] = p.prio_t[2] = 0;
 #ifdef CGS_DIAG_STAMPS
-    if (getenv("CGS_STAMP") && slab && slab_bytes >= 64) p.slab = (float*)slab;
+    // (the stamps go to the LAST MiB of the caller's workspace: 16384 blocks x 64 bytes; tools/clock_probe.py sizes it so)
+    if (getenv("CGS_STAMP") && slab && slab_bytes >= (1u << 20)) p.slab = (float*)((char*)slab + slab_bytes - (1u << 20) - ((uintptr_t)((char*)slab + slab_bytes) & 15));
 #endif
     int maxRC = 0;
     for (int i = 0; i < p.nclasses; ++i) maxRC = p.cls[i].R * p.cls[i].C > maxRC ? p.cls[i].R * p.cls[i].C : maxRC;

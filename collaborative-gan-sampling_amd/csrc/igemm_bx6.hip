@@ -559,7 +559,7 @@ int cgs_igemm_bx6_launch(const IgemmParams& p_in, hipStream_t s, void* dbg, size
     IgemmParams p = p_in;
     p.splitk = 1; p.slab = nullptr;
 #ifdef BX6_STAMPS
-    if (getenv("CGS_STAMP") && dbg && dbg_bytes >= 64) p.slab = (float*)dbg;
+    if (getenv("CGS_STAMP") && dbg && dbg_bytes >= (1u << 20)) p.slab = (float*)((char*)dbg + dbg_bytes - (1u << 20) - ((uintptr_t)((char*)dbg + dbg_bytes) & 15));   // (the last MiB of the workspace)
 #endif
     p.prio_t[0] = p.prio_t[1] = p.prio_t[2] = 0;
     p.uni = 0;

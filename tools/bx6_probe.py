@@ -8,7 +8,7 @@ from cgs_amd import kernels as K, lib as L
 L.set_contraction("bx6")
 d = torch.device("cuda:0")
 B = 1024
-NBLK = 8192
+NBLK = 16384          # the library's diagnostic builds stamp into the last MiB of the workspace: 16384 blocks x 64 bytes
 
 
 def probe(kind, H, Ci, Co):
@@ -17,6 +17,7 @@ def probe(kind, H, Ci, Co):
     w = torch.randn((5, 5, Co, Ci) if deconv else (5, 5, Ci, Co), device=d) * 0.02
     nb = L.conv_ws_bytes(op, 5, 5, 2, 2, Ci, Co)
     ws = torch.zeros(nb // 4 + NBLK * 16 + 64, device=d)
+    tail = (ws.numel() * 4 - (1 << 20) - ((ws.data_ptr() + ws.numel() * 4) & 15)) // 4      # float offset of the stamp area: the last MiB of the workspace
     s = torch.cuda.current_stream().cuda_stream
     if kind == "conv_fwd":
         x = torch.randn(B, H, H, Ci, device=d); y = torch.empty(B, H // 2, H // 2, Co, device=d); b = torch.zeros(Co, device=d)
@@ -35,7 +36,7 @@ def probe(kind, H, Ci, Co):
     torch.cuda.synchronize()
     ws[nb // 4:].zero_()
     run(1); torch.cuda.synchronize()
-    raw = ws[nb // 4: nb // 4 + NBLK * 16].view(torch.int64).cpu().numpy().reshape(NBLK, 8)
+    raw = ws[tail: tail + NBLK * 16].view(torch.int64).cpu().numpy().reshape(NBLK, 8)
     raw = raw[raw[:, 1] != 0]
     loop_us = (raw[:, 1] - raw[:, 0]) / 100.0
     ph = raw[:, 2:6].astype(np.float64)

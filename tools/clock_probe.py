@@ -1,42 +1,43 @@
 """Diagnostic: per-block timeline of one igemm launch (prologue / K loop / epilogue, which CU ran it, how many K tiles it
 executed) from in-kernel s_memrealtime stamps.  Needs a DIAGNOSTIC build of the library (never the shipped one), e.g.
     hipcc ... -DCGS_DIAG_STAMPS -c igemm.hip ; link as libcgs_hip_diag.so ; CGS_LIB=.../libcgs_hip_diag.so python tools/clock_probe.py
-Layers: conv_fwd H Cin Cout | conv_bwd H Cin Cout | deconv_fwd H Cin Cout | deconv_bwd H Cin Cout   (B = 1024, k5 s2)."""
+Layers: kind:H:Cin:Cout[:k] with kind in conv_fwd | conv_bwd | deconv_fwd | deconv_bwd   (stride 2, k = 5 by default; PROBE_B images, default 1024)."""
 import os, sys, torch, numpy as np
 os.environ["CGS_STAMP"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cgs_amd import kernels as K, lib as L
 d = torch.device("cuda:0")
 B = int(os.environ.get("PROBE_B", "1024"))
-NBLK = 16384
+NBLK = 16384          # the library's diagnostic builds stamp into the last MiB of the workspace: 16384 blocks x 64 bytes
 
 
-def probe(kind, H, Ci, Co):
+def probe(kind, H, Ci, Co, KS=5):
     op = {"conv_fwd": L.CONV_FWD, "conv_bwd": L.CONV_BWD_DATA, "deconv_fwd": L.DECONV_FWD, "deconv_bwd": L.DECONV_BWD_DATA}[kind]
     deconv = kind.startswith("deconv")
-    wshape = (5, 5, Co, Ci) if deconv else (5, 5, Ci, Co)
+    wshape = (KS, KS, Co, Ci) if deconv else (KS, KS, Ci, Co)
     w = torch.randn(wshape, device=d) * 0.02
-    nb = L.conv_ws_bytes(op, 5, 5, 2, 2, Ci, Co)
+    nb = L.conv_ws_bytes(op, KS, KS, 2, 2, Ci, Co)
     ws = torch.zeros(nb // 4 + NBLK * 16 + 64, device=d)
+    tail = (ws.numel() * 4 - (1 << 20) - ((ws.data_ptr() + ws.numel() * 4) & 15)) // 4      # float offset of the stamp area: the last MiB of the workspace
     s = torch.cuda.current_stream().cuda_stream
     if kind == "conv_fwd":
         x = torch.randn(B, H, H, Ci, device=d); y = torch.empty(B, H // 2, H // 2, Co, device=d); b = torch.zeros(Co, device=d)
-        run = lambda pre: L.call("cgs_conv2d_nhwc_fwd", x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), B, H, H, Ci, Co, 5, 5, 2, 2, 0, None, None, ws.data_ptr(), ws.numel() * 4, pre, s)
+        run = lambda pre: L.call("cgs_conv2d_nhwc_fwd", x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), B, H, H, Ci, Co, KS, KS, 2, 2, 0, None, None, ws.data_ptr(), ws.numel() * 4, pre, s)
     elif kind == "conv_bwd":
         dy = torch.randn(B, H // 2, H // 2, Co, device=d); dx = torch.empty(B, H, H, Ci, device=d)
-        run = lambda pre: L.call("cgs_conv2d_nhwc_bwd_data", dy.data_ptr(), w.data_ptr(), dx.data_ptr(), B, H, H, Ci, Co, 5, 5, 2, 2, 0, None, None, ws.data_ptr(), ws.numel() * 4, pre, s)
+        run = lambda pre: L.call("cgs_conv2d_nhwc_bwd_data", dy.data_ptr(), w.data_ptr(), dx.data_ptr(), B, H, H, Ci, Co, KS, KS, 2, 2, 0, None, None, ws.data_ptr(), ws.numel() * 4, pre, s)
     elif kind == "deconv_fwd":
         x = torch.randn(B, H, H, Ci, device=d); y = torch.empty(B, 2 * H, 2 * H, Co, device=d); b = torch.zeros(Co, device=d)
-        run = lambda pre: L.call("cgs_deconv2d_nhwc_fwd", x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), B, H, H, Ci, 2 * H, 2 * H, Co, 5, 5, 2, 2, 0, None, None, ws.data_ptr(), ws.numel() * 4, pre, s)
+        run = lambda pre: L.call("cgs_deconv2d_nhwc_fwd", x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), B, H, H, Ci, 2 * H, 2 * H, Co, KS, KS, 2, 2, 0, None, None, ws.data_ptr(), ws.numel() * 4, pre, s)
     else:
         dy = torch.randn(B, 2 * H, 2 * H, Co, device=d); dx = torch.empty(B, H, H, Ci, device=d)
-        run = lambda pre: L.call("cgs_deconv2d_nhwc_bwd_data", dy.data_ptr(), w.data_ptr(), dx.data_ptr(), B, H, H, Ci, 2 * H, 2 * H, Co, 5, 5, 2, 2, 0, None, None, ws.data_ptr(), ws.numel() * 4, pre, s)
+        run = lambda pre: L.call("cgs_deconv2d_nhwc_bwd_data", dy.data_ptr(), w.data_ptr(), dx.data_ptr(), B, H, H, Ci, 2 * H, 2 * H, Co, KS, KS, 2, 2, 0, None, None, ws.data_ptr(), ws.numel() * 4, pre, s)
     run(0)
     for _ in range(30): run(1)
     torch.cuda.synchronize()
     ws[nb // 4:].zero_()
     run(1); torch.cuda.synchronize()
-    raw = ws[nb // 4: nb // 4 + NBLK * 16].view(torch.int64).cpu().numpy().reshape(NBLK, 8)
+    raw = ws[tail: tail + NBLK * 16].view(torch.int64).cpu().numpy().reshape(NBLK, 8)
     raw = raw[raw[:, 3] != 0]
     n = len(raw)
     t = raw[:, :4].astype(np.float64)
@@ -67,5 +68,5 @@ def probe(kind, H, Ci, Co):
 
 
 for spec in (sys.argv[1:] or ["conv_fwd:16:128:256", "conv_fwd:32:64:128", "deconv_fwd:16:128:64", "conv_fwd:8:256:512"]):
-    k, H, ci, co = spec.split(":")
-    probe(k, int(H), int(ci), int(co))
+    f = spec.split(":")            # kind:H:Cin:Cout[:kernel size]   (stride 2)
+    probe(f[0], int(f[1]), int(f[2]), int(f[3]), int(f[4]) if len(f) > 4 else 5)
