@@ -110,10 +110,15 @@ int cgs_pack_weights_bx6(const IgemmParams& p, const CgsLayer& L, bool dirT, con
 #endif
 // waves per SIMD the register budget is sized for: the four-wave blocks run two per CU (256 registers per lane); the two-wave
 // 256 x 64 block's LDS lets two blocks = four waves share a CU, one per SIMD (512 registers: its eight staged float4 fit)
+// The one-wave 128 x 64 block ("solo", for layers with 64 output channels per tile): no other wave shares its tile, so it keeps ONE LDS
+// image (the fragments of a stage are all in registers before the image is overwritten), 18.5 KB: eight blocks = two waves per SIMD
+// per CU, no barriers, no lockstep between them.
 template <int BM, int BN, bool PAR>
-__global__ __launch_bounds__(BM* BN / 128, BM* BN == 128 * 256 ? 2 : 1) void igemm_bx6_kernel(IgemmParams p) {
+__global__ __launch_bounds__(BM* BN / 128, BM* BN == 128 * 256 || BM * BN == 128 * 64 ? 2 : 1) void igemm_bx6_kernel(IgemmParams p) {
     constexpr int WNN = BN / 64;                       // waves along N; wave tile 128 x 64
     constexpr int NW = (BM / 128) * WNN, NT = 64 * NW;
+    constexpr bool SOLO = NW == 1;
+    constexpr int NBUF = SOLO ? 1 : 2;                 // LDS images of a stage
     constexpr int PITCH = 32;                          // bytes of an LDS row: 16 bf16 = one K stage of one plane
     constexpr int PLA = BM * PITCH, PLB = BN * PITCH;  // bytes of an A / B plane
     constexpr int BUF = 3 * (PLA + PLB);               // one stage: A planes [3][BM][16], then B planes [3][BN][16]
@@ -122,7 +127,7 @@ __global__ __launch_bounds__(BM* BN / 128, BM* BN == 128 * 256 ? 2 : 1) void ige
     constexpr int ER = 32, LDE = 64 + 4;               // epilogue staging: 32 rows of the wave tile at a time
     constexpr int STAGE_B = NW * ER * LDE * 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    int* rowpix = (int*)(lds + (2 * BUF > STAGE_B ? 2 * BUF : STAGE_B));      // [BM] output pixel of each tile row, -1 = out of range
+    int* rowpix = (int*)(lds + (NBUF * BUF > STAGE_B ? NBUF * BUF : STAGE_B));      // [BM] output pixel of each tile row, -1 = out of range
 
     // block id -> (m-tile, n-tile, class): as igemm_kernel (per-XCD decode, heaviest pixels first)
     const int nblk_n = p.Np / BN;
@@ -262,11 +267,12 @@ __global__ __launch_bounds__(BM* BN / 128, BM* BN == 128 * 256 ? 2 : 1) void ige
     // memory and in LDS alike: the packed tile and its LDS image are the same linear array); piece = wave + NW * u
     constexpr int PPP = BN / 32;                       // pieces per plane
     constexpr int PB = 3 * PPP / NW;                   // pieces per wave and stage
-    unsigned b_voff[PB];
+    const unsigned b_lane = (unsigned)lane * 16u;      // (the only per-lane part; the piece's place in the tile rides in the scalar offset)
+    int b_soff[PB];
 #pragma unroll
     for (int u = 0; u < PB; ++u) {
         const int piece = wave + NW * u, plane = piece / PPP, sub = piece - plane * PPP;
-        b_voff[u] = (unsigned)(plane * p.Np * PITCH + n0 * PITCH + sub * 1024 + lane * 16);
+        b_soff[u] = __builtin_amdgcn_readfirstlane(plane * p.Np * PITCH + n0 * PITCH + sub * 1024);
     }
 #else
     unsigned b_voff[NB], b_lds[NB];
@@ -306,7 +312,7 @@ __global__ __launch_bounds__(BM* BN / 128, BM* BN == 128 * 256 ? 2 : 1) void ige
         const int b_soff_ = (s_).kt * b_tile_bytes;                                                             \
         _Pragma("unroll") for (int u = 0; u < PB; ++u) {                                                        \
             const int piece_ = wave + NW * u, plane_ = piece_ / PPP, sub_ = piece_ - plane_ * PPP;              \
-            bx6_dma16(w_rsrc, lds + (DST_) * BUF + 3 * PLA + plane_ * PLB + sub_ * 1024, b_voff[u], b_soff_);   \
+            bx6_dma16(w_rsrc, lds + (DST_) * BUF + 3 * PLA + plane_ * PLB + sub_ * 1024, b_lane, b_soff_ + b_soff[u]); \
         }                                                                                                       \
     } while (0)
 #else
@@ -422,7 +428,36 @@ __global__ __launch_bounds__(BM* BN / 128, BM* BN == 128 * 256 ? 2 : 1) void ige
     st_rt0 = __builtin_amdgcn_s_memrealtime();
     st_last = __builtin_amdgcn_s_memtime();
 #endif
-    {
+    if constexpr (SOLO) {
+        // one wave, one LDS image: read ALL fragments of the stage, then -- the image is dead -- start the DMA of the next stage's weights
+        // into it and the loads of its activations, contract, split + store the activations, wait for the DMA.  (__syncthreads of a
+        // one-wave block is its fence: vmcnt(0) lgkmcnt(0).)
+        while (cur.kt < nk) {
+            const KIt nxt = kit_next(cur);
+            KIt ld;
+            KIT_SEL(ld, nxt.kt < nk, nxt, cur);
+            bf16x8 a_[4][3], b_[2][3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a_[i][pl] = *(const bf16x8*)(fa + pl * PLA + i * 32 * PITCH);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) b_[j][pl] = *(const bf16x8*)(fb + pl * PLB + j * 32 * PITCH);
+            }
+            ADDR_TILE(ld);
+            ISSUE_A(ra);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // every fragment has left LDS: the image may be overwritten
+            ISSUE_B(ld, 0);
+            STAMP(0);
+            MM(0, 0) MM(0, 1) MM(1, 0) MM(1, 1) MM(0, 2) MM(2, 0)
+            STAMP(1);
+            STORE_TILE(0);
+            STAMP(2);
+            __syncthreads();
+            STAMP(3);
+            cur = nxt;
+        }
+    } else {
         KIt n1 = cur;
         if (cur.kt < nk) n1 = kit_next(cur);
         while (n1.kt < nk) {                             // at least two stages left: cur (in buffer 0) and n1
@@ -525,7 +560,7 @@ int cgs_igemm_bx6_ok(const CgsLayer& L, bool dirT, int B, bool any_size) {
     if (dirT && (L.sh > 2 || L.sw > 2)) return 0;
     if (any_size) return 1;
     const long M = (long)B * (dirT ? (long)L.Hb * L.Wb : (long)L.Hs * L.Ws);
-    const long blocks = (N % 256) == 0 ? (M / 128) * (N / 256) : (N % 128) == 0 ? (M / 256) * (N / 128) : (M / 256) * (N / 64);
+    const long blocks = (N % 256) == 0 ? (M / 128) * (N / 256) : (N % 128) == 0 ? (M / 256) * (N / 128) : (M / 128) * (N / 64) / 2;    // (the one-wave blocks run eight per CU)
     const long K = (long)L.kh * L.kw * Cred / (dirT ? L.sh * L.sw : 1);
     return blocks >= 256 && K >= 512;
 }
@@ -533,8 +568,8 @@ int cgs_igemm_bx6_ok(const CgsLayer& L, bool dirT, int B, bool any_size) {
 template <int BM, int BN, bool PAR>
 static int launch_bx6(const IgemmParams& p, hipStream_t s) {
     constexpr int NT = BM * BN / 128;
-    constexpr size_t buf = 3 * (size_t)(BM + BN) * 32, stage = (size_t)(NT / 64) * 32 * 68 * 4;
-    constexpr size_t smem = (2 * buf > stage ? 2 * buf : stage) + BM * sizeof(int);
+    constexpr size_t buf = (NT == 64 ? 1 : 2) * 3 * (size_t)(BM + BN) * 32, stage = (size_t)(NT / 64) * 32 * 68 * 4;
+    constexpr size_t smem = (buf > stage ? buf : stage) + BM * sizeof(int);
     CGS_SMEM_ATTR(smem, "igemm_bx6", igemm_bx6_kernel<BM, BN, PAR>);
     long maxM = 0;
     for (int i = 0; i < p.nclasses; ++i) {
@@ -565,8 +600,11 @@ int cgs_igemm_bx6_launch(const IgemmParams& p_in, hipStream_t s, void* dbg, size
     p.uni = 0;
     if (!p.vec || (p.N % 64) || p.Np != p.N) return cgs_set_error(CGS_EINVAL, "igemm_bx6: needs Cred %% 32 == 0 and N %% 64 == 0");
     if (p.sign_out) return cgs_set_error(CGS_EINVAL, "igemm_bx6: sign masks are a feature of the fp32 kernel");
+#ifndef BX6_SOLO
+#define BX6_SOLO 1       // N % 128 != 0: one-wave 128 x 64 blocks (1) or the two-wave 256 x 64 block (0)
+#endif
     const bool n256 = (p.N % 256) == 0;
-    const int BM = n256 ? 128 : 256;
+    const int BM = (n256 || (BX6_SOLO && (p.N % 128) != 0)) ? 128 : 256;
     cgs_igemm_row_policy(p, BM);
     if ((long)p.B * p.Hout * p.Wout * p.N * 4 > 0x7fffffffL || (long)p.B * p.Hin * p.Win * p.Cred * 4 > 0x7fffffffL)
         return cgs_set_error(CGS_EINVAL, "igemm_bx6: a tensor of one launch exceeds 2 GiB (the caller splits the batch)");
@@ -581,5 +619,9 @@ int cgs_igemm_bx6_launch(const IgemmParams& p_in, hipStream_t s, void* dbg, size
     cgs_igemm_count_flops(p, BM);
     if (n256) return p.tap_parity ? launch_bx6<128, 256, true>(p, s) : launch_bx6<128, 256, false>(p, s);
     if ((p.N % 128) == 0) return p.tap_parity ? launch_bx6<256, 128, true>(p, s) : launch_bx6<256, 128, false>(p, s);
+#if BX6_SOLO
+    return p.tap_parity ? launch_bx6<128, 64, true>(p, s) : launch_bx6<128, 64, false>(p, s);
+#else
     return p.tap_parity ? launch_bx6<256, 64, true>(p, s) : launch_bx6<256, 64, false>(p, s);
+#endif
 }
