@@ -417,8 +417,8 @@ def bx6_line(args, P, B, G, Ksteps, z, dev, n_flight, streams, flops_per_sample)
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
     prof, prof_ms = profile_one_step(args.arch, P, B, G, Ksteps, args.rate, z[args.warmup], dev, streams[0], engine=engines[0])
-    roof, kern, _, ex_step = profile_records(prof, prof_ms, 1e3 * dt / args.steps, "one extra eager single-stream step right after this mode's timed steps", False)
-    roof.pop("traffic"); roof.pop("traffic_over_algorithmic")
+    roof, kern, _, ex_step = profile_records(prof, prof_ms, 1e3 * dt / args.steps, "one extra eager single-stream step right after this mode's timed steps",
+                                             args.arch == "dcgan64" and B == 1024 and G == 1)
     value = B * G * args.steps / dt
     return {"value": round(value, 2), "unit": "samples/s", "ms_per_step": round(1e3 * dt / args.steps, 3), "steps": args.steps,
             "dtype": DTYPE["bx6"], "contraction": "bx6", "hipgraph": bool(args.graph), "batches_in_flight": n_flight * G,
@@ -687,7 +687,7 @@ def main():
             out["executed_tflops"] = round(world * ex_step / (1e3 * dt / args.steps) / 1e9, 2)      # whole job, padding taps not counted
         cpu = cpu_baseline(args.arch, Ksteps, args.rate) if world == 1 and not args.no_cpu_baseline else None   # (calibrates the host thread count)
         if world == 1 and not args.no_other_configs:
-            if args.contraction == "f32" and args.arch in ("dcgan64", "cyclegan256"):
+            if args.contraction == "f32":
                 # the opt-in split-bf16 mode on the SAME workload, engines, batches in flight and z batches, timed right after
                 # (and outside) the headline's region: its own samples/s, dtype and roofline (never the headline)
                 del engines

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """rocprofv3 PMC passes -> profiles/traffic.json (what bench.py reports as roofline.traffic).
 
-    python tools/make_traffic_json.py <FETCH_SIZE counter_collection.csv> <WRITE_SIZE counter_collection.csv> <tag>
+    python tools/make_traffic_json.py <FETCH_SIZE counter_collection.csv> <WRITE_SIZE counter_collection.csv> <tag> [<FETCH csv 2> <WRITE csv 2>]
+(the optional second pair: the same passes of `bench.py --contraction bx6`, whose igemm_bx6 kernels are added to the table)
 
 Per kernel name: launches, average FETCH_SIZE / WRITE_SIZE (KB, as rocprofv3 prints them) and the HBM-side bytes per launch
 = 2 * FETCH_SIZE + WRITE_SIZE (KB -> bytes; FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md, HBM section:
@@ -14,7 +15,7 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KEEP = ("igemm_kernel", "convt_quad", "convt_rows", "conv_patch", "conv_smalln", "convt_smalln", "bn_", "refine_update", "linear_out1")
+KEEP = ("igemm_kernel", "igemm_bx6", "convt_quad", "convt_rows", "conv_patch", "conv_smalln", "convt_smalln", "bn_", "refine_update", "linear_out1")
 
 
 def short(name):
@@ -37,6 +38,14 @@ def main():
     fpath, wpath, tag = sys.argv[1], sys.argv[2], sys.argv[3]
     F, frows = load(fpath, "FETCH_SIZE")
     W, wrows = load(wpath, "WRITE_SIZE")
+    if len(sys.argv) > 5:            # the split-bf16 run: only its own kernels are taken from it
+        F2, frows2 = load(sys.argv[4], "FETCH_SIZE")
+        W2, wrows2 = load(sys.argv[5], "WRITE_SIZE")
+        for k in F2:
+            if "igemm_bx6" in k:
+                F[k], W[k] = F2[k], W2.get(k, [0.0])
+        frows += [r for r in frows2 if "igemm_bx6" in r["Kernel_Name"]]
+        wrows += [r for r in wrows2 if "igemm_bx6" in r["Kernel_Name"]]
     out = {}
     for k in F:
         if not any(s in k for s in KEEP) and "pack" not in k:
