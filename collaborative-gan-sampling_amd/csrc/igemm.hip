@@ -1090,7 +1090,9 @@ int cgs_igemm_launch(const IgemmParams& p_in, void* slab, size_t slab_bytes, hip
         // a launch that leaves norm statistics or a sign mask comes out of the one-pass epilogue and cannot be split over K: under
         // 256 blocks of 128x128 it would leave most CUs idle (config 5's PatchGAN 4x4 128->256 layer: 128 blocks, 54 TFLOP/s) --
         // as 128x64 blocks at least every CU gets one
+#ifndef CGS_NO_STAT_NARROW
         else if (wb < 256 && (p.stat_part || p.sign_out)) { wide = false; mid = true; }
+#endif
     }
     bool deep = true;
     if (vec && p.splitk == 1 && !mid) {
