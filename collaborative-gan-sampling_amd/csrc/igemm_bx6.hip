@@ -558,6 +558,7 @@ int cgs_igemm_bx6_ok(const CgsLayer& L, bool dirT, int B, bool any_size) {
     const int Cred = dirT ? L.Cs : L.Cb, N = dirT ? L.Cb : L.Cs;
     if ((Cred % 32) || (N % 64) || L.kh > 16 || L.kw > 16) return 0;
     if (dirT && (L.sh > 2 || L.sw > 2)) return 0;
+    if ((long)L.kh * L.kw * Cred * N * 6 > 0x7fffffffL) return 0;      // (the packed planes of a class are addressed with 32-bit byte offsets)
     if (any_size) return 1;
     const long M = (long)B * (dirT ? (long)L.Hb * L.Wb : (long)L.Hs * L.Ws);
     const long blocks = (N % 256) == 0 ? (M / 128) * (N / 256) : (N % 128) == 0 ? (M / 256) * (N / 128) : (M / 128) * (N / 64) / 2;    // (the one-wave blocks run eight per CU)

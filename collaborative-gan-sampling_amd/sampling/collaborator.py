@@ -16,6 +16,7 @@ Execution paths (both all-HIP, no CPU fallback; ``refiner.path`` says which one 
              update / select kernels.
 """
 import functools
+import weakref
 
 import numpy as np
 import torch
@@ -77,7 +78,7 @@ class Refiner():
             return None
         return owner, func, kw
 
-    _BCE_PROBE = {}            # id(func_loss) -> (weak reference or the function itself, verdict)
+    _BCE_PROBE = {}            # id(func_loss) -> (weak reference to it, verdict); an entry dies with its function
 
     @classmethod
     def _loss_is_bce_ones(cls, func_loss, device):
@@ -89,7 +90,7 @@ class Refiner():
         if func_loss is GAN.loss_refine:
             return True
         hit = cls._BCE_PROBE.get(id(func_loss))
-        if hit is not None and hit[0] is func_loss:
+        if hit is not None and hit[0]() is func_loss:
             return hit[1]
         ok = False
         try:
@@ -101,7 +102,11 @@ class Refiner():
                   and bool(np.abs(got.detach().double().cpu().numpy() - want).max() < 1e-6))
         except Exception:                                   # noqa: BLE001 (a loss that cannot take a [16, 1] tensor is not this one)
             ok = False
-        cls._BCE_PROBE[id(func_loss)] = (func_loss, ok)
+        try:       # (the reference makes a new closure per model build: keep no function alive, drop the verdict with it)
+            key = id(func_loss)
+            cls._BCE_PROBE[key] = (weakref.ref(func_loss, lambda _r, key=key: cls._BCE_PROBE.pop(key, None)), ok)
+        except TypeError:                                   # not weak-referenceable (a builtin): probe it again next time
+            pass
         return ok
 
     def _engine_owner(self):

@@ -31,47 +31,49 @@ def dev():
     return torch.device("cuda:0")
 
 
-def random_arch(seed):
+def random_arch(seed, wide=1):
+    """``wide`` multiplies every hidden channel count (1: 16...64 channels; 4: 64...256, the range the split-bf16 kernel serves)."""
     rs = np.random.RandomState(seed)
-    pick = lambda xs: xs[int(rs.randint(len(xs)))]
-    h = pick([4, 6, 8])
+    pick_ = lambda xs: xs[int(rs.randint(len(xs)))]
+    pick = lambda xs: pick_(xs) * (wide if all(isinstance(v, int) and v >= 16 for v in xs) else 1)
+    h = pick_([4, 6, 8])
     c = pick([16, 32, 64])
     feat = (h, h, c)
-    norm_g = pick(["bn", "instnorm"])
+    norm_g = pick_(["bn", "instnorm"])
     tail, shape, idx = [], feat, 0
     if rs.rand() < 0.4:                                      # a residual block in front (CycleGAN trunk style)
         tail.append(("res", [("conv", "g_r_c1", c, 3, 1), ("instnorm", "g_r_n1"), ("relu",),
                              ("conv", "g_r_c2", c, 3, 1), ("instnorm", "g_r_n2")]))
-    n_up = pick([1, 2])
-    img_c = pick([1, 3])
+    n_up = pick_([1, 2])
+    img_c = pick_([1, 3])
     for u in range(n_up):
         last = u == n_up - 1
         co = img_c if last and rs.rand() < 0.6 else pick([16, 32])
-        k = pick([3, 4, 5])
+        k = pick_([3, 4, 5])
         shape = (shape[0] * 2, shape[1] * 2, co)
         tail.append(("deconv", f"g_up{u}", shape, k, 2))
         if not (last and co == img_c):
             tail += [(norm_g, f"g_n{u}"), ("relu",)]
             idx += 1
     if shape[2] != img_c:                                    # an RGB / grey head: stride-1 conv
-        k = pick([3, 5, 7])
+        k = pick_([3, 5, 7])
         tail.append(("conv", "g_head_rgb", img_c, k, 1))
         shape = (shape[0], shape[1], img_c)
     tail.append(("tanh",))
     img = shape
-    norm_d = pick(["bn", "instnorm"])
+    norm_d = pick_(["bn", "instnorm"])
     d, ds = [], img
-    n_d = pick([1, 2, 3])
+    n_d = pick_([1, 2, 3])
     for i in range(n_d):
         co = pick([16, 32, 64])
-        k, s = pick([3, 4, 5]), 2
+        k, s = pick_([3, 4, 5]), 2
         d.append(("conv", f"d_c{i}", co, k, s))
         ds = (-(-ds[0] // s), -(-ds[1] // s), co)
         if i > 0:
             d.append((norm_d, f"d_n{i}"))
         d.append(("lrelu",))
     if rs.rand() < 0.5 and ds[0] > 1:
-        d.append(("conv", "d_patch", 1, pick([3, 4]), 1))     # PatchGAN logit map
+        d.append(("conv", "d_patch", 1, pick_([3, 4]), 1))     # PatchGAN logit map
     else:
         d += [("flatten",), ("linear", "d_fc", 1)]
     return dict(z_dim=8, img=img, k=5, stride=2, feature=feat,
@@ -149,10 +151,10 @@ def kink_flips(name, P, f0_ref, eng, fwd_tol=1e-4):
 LAST = {"degenerate": False}      # set by run_topology: the oracle's gradient of the last topology was identically zero
 
 
-def run_topology(seed, use_graph):
+def run_topology(seed, use_graph, contraction="f32"):
     from cgs_amd import nets
     from cgs_amd.engine import RefineEngine
-    A = random_arch(seed)
+    A = random_arch(seed, wide=1 if contraction == "f32" else 4)
     name = f"fuzz{seed}"
     N.ARCHS[name] = A
     nets.ARCHS[name] = A
@@ -160,7 +162,7 @@ def run_topology(seed, use_graph):
         B, Ksteps = int(np.random.RandomState(seed).choice([3, 8, 16])), 2
         P = N.init_params(name, 7, True)
         d = dev()
-        eng = RefineEngine(name, nets.to_device(P, d), B, d, use_graph=use_graph)
+        eng = RefineEngine(name, nets.to_device(P, d), B, d, use_graph=use_graph, contraction=contraction)
         z = torch.from_numpy(np.random.RandomState(seed + 1).uniform(-1, 1, (B, 8)).astype(np.float32))
         f0 = eng.input_to_feature(z.to(d)).clone()
         with torch.no_grad():
@@ -206,6 +208,22 @@ SEEDS = [1000 + SEED + i for i in range(N_ARCHS)]
 @pytest.mark.parametrize("use_graph", [False, True], ids=["eager", "hipgraph"])
 def test_random_topology_matches_oracle(seed, use_graph):
     run_topology(seed, use_graph)
+
+
+@pytest.mark.parametrize("seed", SEEDS)
+def test_random_topology_on_the_split_bf16_contraction(seed):
+    """The same topologies with four times the channels (64...256: the layers the split-bf16 kernel serves -- 128x256, 256x128 and
+    one-wave 128x64 blocks, both directions, every fused epilogue / norm-statistics form the engine wires) with every eligible layer
+    forced onto it ("bx6_all"), through the same checks at the same tolerances."""
+    from cgs_amd import kernels as K
+    K.PROFILE = {}
+    try:
+        run_topology(seed, False, "bx6_all")
+        used = sum(len(v[1]) for k, v in K.PROFILE.items() if k.startswith("igemm_bx6_kernel"))
+    finally:
+        K.PROFILE = None
+    if used == 0:
+        pytest.skip("no layer of this topology has a direction the split-bf16 kernel serves (e.g. 256 -> 3 -> 64 channels only)")
 
 
 @pytest.mark.parametrize("seed", SEEDS)
