@@ -20,6 +20,10 @@ distinct ranks an all-gather of rank ids returned, pool bytes, per-rank throughp
 `--backend gloo --share-gpu` is the debug transport: all ranks on device 0, the pool staged through the host -- the whole
 N-rank control flow (self-launch, rank-offset seeds, gather, MAX-reduce, one JSON line) on a 1-GPU box.
 
+Besides the driver's keys the line carries: `roofline` (dominant kernel, flops issued / HIP-event launch time / the peak of the instructions it runs on), `kernels`,
+`hbm`, `cpu_baseline`, `other_configs` (mnist, dcgan32, cyclegan256, synthetic2d: samples/s, roofline, cpu_baseline and the bx6 samples/s of each), `class_surface`
+(the reference's verbatim Refiner wiring, engine and generic path) and `bx6` (the opt-in split-bf16 contraction on the headline's workload: never the headline).
+
     python bench.py --gpus 1 --steps 3 --warmup 1
     python -m torch.distributed.run --nproc-per-node 8 ... bench.py --gpus 8 --steps 3 --warmup 1
     python bench.py --gpus 2 --backend gloo --share-gpu --arch mnist --steps 2 --warmup 1      (1-GPU box)
