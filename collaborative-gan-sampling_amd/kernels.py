@@ -105,7 +105,9 @@ class _WsCache:
 
     def plan(self, op, B, H, W, cin, ho, wo, cout, kh, kw, sh, sw, epilogue):
         """(kernel family, workspace bytes) of a call; asked of the library once per distinct call signature."""
-        key = (op, B, H, W, cin, ho, wo, cout, kh, kw, sh, sw, epilogue, CONTRACTION)      # (the family depends on the thread's contraction mode)
+        # (the family depends on the calling thread's contraction mode: asked of the library itself, so a caller that switched it
+        # through lib.set_contraction / the C ABI directly is keyed correctly too)
+        key = (op, B, H, W, cin, ho, wo, cout, kh, kw, sh, sw, epilogue, int(L.load().cgs_get_contraction()))
         hit = self._family.get(key)
         if hit is None:
             nbytes = max(L.conv_ws_bytes_for(op, B, H, W, cin, cout, kh, kw, sh, sw), 16)
