@@ -12,6 +12,7 @@ K.set_contraction(os.environ.get("CGS_CONTRACTION", "bx6"))
 d = torch.device("cuda:0")
 B = int(os.environ.get("BX6_B", "1024"))
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+ZERO = bool(os.environ.get("BX6_ZERO"))      # all-zero activations and weights: same instruction stream, no switching activity (is the kernel clock / power bound?)
 
 
 def timeit(fn):
@@ -29,12 +30,16 @@ for kind, H, Ci, Co in (("conv", 32, 64, 128), ("conv", 16, 128, 256), ("conv", 
     torch.manual_seed(0)
     if kind == "conv":
         x = torch.randn(B, H, H, Ci, device=d); w = torch.randn(5, 5, Ci, Co, device=d) * 0.02; b = torch.zeros(Co, device=d)
+        if ZERO: x.zero_(); w.zero_()
         y = K.conv2d_fwd(x, w, b); dy = torch.randn_like(y)
+        if ZERO: dy.zero_()
         f = lambda: K.conv2d_fwd(x, w, b, out=y)
         g = lambda: K.conv2d_bwd_data(dy, w, (H, H), out=x)
     else:
         x = torch.randn(B, H, H, Ci, device=d); w = torch.randn(5, 5, Co, Ci, device=d) * 0.02; b = torch.zeros(Co, device=d)
+        if ZERO: x.zero_(); w.zero_()
         y = K.deconv2d_fwd(x, w, b, (2 * H, 2 * H)); dy = torch.randn_like(y)
+        if ZERO: dy.zero_()
         f = lambda: K.deconv2d_fwd(x, w, b, (2 * H, 2 * H), out=y)
         g = lambda: K.deconv2d_bwd_data(dy, w, (H, H), out=x)
     for tag, fn in (("fwd", f), ("bwd", g)):
