@@ -399,3 +399,31 @@ def test_tf_checkpoint_converter_runs_against_the_checkpoint_reader_interface(tm
     monkeypatch.setattr(sys, "argv", ["tf_ckpt_to_safetensors.py", "x/model-1", out, "--arch", "dcgan32"])
     with pytest.raises(KeyError):                                        # a checkpoint of another net is refused, not written
         tool.main()
+
+
+def test_refiner_unwraps_the_reference_wiring_without_a_gpu():
+    """collaborator.Refiner._unwrap (host logic of the engine detection): functools.partial objects -- also nested -- of
+    BOUND methods with keyword arguments only resolve to (owner, function, keywords); positional arguments, plain functions,
+    lambdas and unexpected keywords do not.  (The GPU suite checks the whole detection against a real model.)"""
+    from functools import partial
+    from cgs_amd.sampling.collaborator import Refiner
+
+    class M:
+        def discriminator(self, x, is_training=True, reuse=False):
+            return x
+
+        def feature_to_data(self, f, is_training=False):
+            return f
+    m = M()
+    allowed = ("is_training", "reuse")
+    assert Refiner._unwrap(m.discriminator, allowed) == (m, M.discriminator, {})
+    assert Refiner._unwrap(partial(m.discriminator, is_training=True, reuse=True), allowed) == (m, M.discriminator, {"is_training": True, "reuse": True})
+    # nested partials: the OUTER keyword wins, as functools applies them
+    assert Refiner._unwrap(partial(partial(m.discriminator, is_training=False), is_training=True), allowed)[2] == {"is_training": True}
+    assert Refiner._unwrap(partial(m.discriminator, 1.0), allowed) is None                    # positional argument bound
+    assert Refiner._unwrap(partial(m.discriminator, name="d"), allowed) is None               # a keyword the engine does not know
+    assert Refiner._unwrap(lambda x: m.discriminator(x), allowed) is None                     # opaque callable
+    assert Refiner._unwrap(M.discriminator, allowed) is None                                  # unbound function
+    assert Refiner._unwrap(partial(m.feature_to_data, is_training=False), ("is_training",)) == (m, M.feature_to_data, {"is_training": False})
+    r = Refiner(3, 0.1)
+    assert r.use_graph is True and r.path is None and r.graph_fallback is None               # the class-surface defaults (hipGraph on)
