@@ -95,7 +95,7 @@ static int run_dir(const CgsLayer& L, bool dirT, int B, const float* in, const f
                            ((uintptr_t)ep_aux & 15));
     const int fam = choose_family(L, dirT, B, epilogue, ws != nullptr, ws_bytes, !((uintptr_t)in & 15), !((uintptr_t)ws & 15), rest_al);
     if (stat_part && fam != CGS_FAMILY_IGEMM && fam != CGS_FAMILY_IGEMM_BX6) return cgs_set_error(CGS_EINVAL, "%s: fused statistics are an implicit-GEMM feature (see cgs_conv_stat_partials)", who);
-    if (sign_out && fam != CGS_FAMILY_IGEMM) return cgs_set_error(CGS_EINVAL, "%s: this call cannot leave a sign mask (see cgs_conv_signs_ok)", who);
+    if (sign_out && fam != CGS_FAMILY_IGEMM && fam != CGS_FAMILY_IGEMM_BX6) return cgs_set_error(CGS_EINVAL, "%s: this call cannot leave a sign mask (see cgs_conv_signs_ok)", who);
     if (aux_signs && fam != CGS_FAMILY_PATCH && fam != CGS_FAMILY_TAPS) return cgs_set_error(CGS_EINVAL, "%s: this call cannot take a sign mask (see cgs_conv_signs_ok)", who);
     if (((uintptr_t)sign_out & 3) || ((uintptr_t)aux_signs & 3)) return cgs_set_error(CGS_EINVAL, "%s: sign mask must be 4-byte aligned", who);
     switch (fam) {
@@ -347,6 +347,9 @@ int cgs_conv_signs_ok(int op, int B, int H, int W, int Cin, int Ho, int Wo, int 
     else { L.Hs = H; L.Ws = W; L.Cs = Cin; L.Hb = Ho; L.Wb = Wo; L.Cb = Cout; }
     if (epilogue >= CGS_EPI_RELU_BWD_AFFINE)          // consumer: a backward-data whose epilogue applies relu' / lrelu'
         return (fam == CGS_FAMILY_PATCH && cgs_conv_patch_signs_ok(L, dirT, epilogue)) || (fam == CGS_FAMILY_TAPS && cgs_conv_taps_signs_ok(L, epilogue));
+    if (fam == CGS_FAMILY_IGEMM_BX6)            // producer on the split-bf16 kernel: whole 64-column wave tiles, never split over K
+        return (epilogue == CGS_EPI_AFFINE_RELU || epilogue == CGS_EPI_LRELU) &&
+               (size_t)B * ((size_t)L.Hb * L.Wb * L.Cb > (size_t)L.Hs * L.Ws * L.Cs ? (size_t)L.Hb * L.Wb * L.Cb : (size_t)L.Hs * L.Ws * L.Cs) * 4 <= 0x7fffffffUL;
     if (fam != CGS_FAMILY_IGEMM || (dirT && (sh > 2 || sw > 2))) return 0;        // producer: a forward with the relu / lrelu epilogue
     IgemmParams p;
     p.B = B; p.stat_part = nullptr; p.sign_out = nullptr; p.sign_plane = 0; p.epilogue = epilogue;

@@ -507,12 +507,9 @@ __global__ __launch_bounds__(BM* BN / 128, BM* BN == 128 * 256 || BM * BN == 128
         if (p.epilogue == CGS_EPI_RELU_BWD_AFFINE) ea = *(const f32x4*)(p.ep_a + n);
     }
     f32x4 st_a = {0.f, 0.f, 0.f, 0.f}, st_b = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int tm = 0; tm < 4; ++tm) {
-#pragma unroll
-        for (int tn = 0; tn < 2; ++tn)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) E[((r & 3) + 8 * (r >> 2) + 4 * fh) * LDE + tn * 32 + fr] = acc[tm][tn][r];
+    // (the four passes are written out with LITERAL accumulator indices: left to the unroller, the pass loop -- once its body grew by
+    // the sign-mask forms -- stayed a loop, the accumulators were indexed at run time and moved to scratch memory: 4x slower kernels)
+    auto finish_pass = [&](const int tm) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -520,6 +517,9 @@ __global__ __launch_bounds__(BM* BN / 128, BM* BN == 128 * 256 || BM * BN == 128
             const int* rp = rowpix + wm * 128 + tm * ER;
             if (p.stat_part) {
                 epilogue_rows<CGS_EPI_NONE, ER, 4, LDE, true>(p, E, rp, rsub, c4, n, bias, ea, eb, &st_a, &st_b);
+            } else if (p.sign_out) {      // (N % 64 == 0: every lane of the wave is inside N, the ballots see whole rows; same mask layout as igemm.hip)
+                if (p.epilogue == CGS_EPI_AFFINE_RELU) epilogue_rows_signs<CGS_EPI_AFFINE_RELU, ER, 4, LDE, true>(p, E, rp, rsub, c4, n, bias, ea, eb);
+                else epilogue_rows_signs<CGS_EPI_LRELU, ER, 4, LDE, true>(p, E, rp, rsub, c4, n, bias, ea, eb);
             } else
             switch (p.epilogue) {
                 case CGS_EPI_NONE: epilogue_rows<CGS_EPI_NONE, ER, 4, LDE>(p, E, rp, rsub, c4, n, bias, ea, eb); break;
@@ -548,7 +548,16 @@ __global__ __launch_bounds__(BM* BN / 128, BM* BN == 128 * 256 || BM * BN == 128
             }
             st_a = f32x4{0.f, 0.f, 0.f, 0.f}; st_b = f32x4{0.f, 0.f, 0.f, 0.f};
         }
+    };
+#define STAGE_PASS(TM_)                                                                                         \
+    {                                                                                                           \
+        _Pragma("unroll") for (int tn = 0; tn < 2; ++tn)                                                        \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r)                                                      \
+                E[((r & 3) + 8 * (r >> 2) + 4 * fh) * LDE + tn * 32 + fr] = acc[TM_][tn][r];                    \
+        finish_pass(TM_);                                                                                       \
     }
+    STAGE_PASS(0) STAGE_PASS(1) STAGE_PASS(2) STAGE_PASS(3)
+#undef STAGE_PASS
 }
 
 // which calls the split-bf16 form serves: the 32-channel-chunk K order (Cred % 32 == 0, <= 16 taps per axis), whole 64-column
@@ -600,7 +609,8 @@ int cgs_igemm_bx6_launch(const IgemmParams& p_in, hipStream_t s, void* dbg, size
     p.prio_t[0] = p.prio_t[1] = p.prio_t[2] = 0;
     p.uni = 0;
     if (!p.vec || (p.N % 64) || p.Np != p.N) return cgs_set_error(CGS_EINVAL, "igemm_bx6: needs Cred %% 32 == 0 and N %% 64 == 0");
-    if (p.sign_out) return cgs_set_error(CGS_EINVAL, "igemm_bx6: sign masks are a feature of the fp32 kernel");
+    if (p.sign_out && p.epilogue != CGS_EPI_AFFINE_RELU && p.epilogue != CGS_EPI_LRELU)
+        return cgs_set_error(CGS_EINVAL, "igemm_bx6: a sign mask needs the relu / lrelu forward epilogues");
 #ifndef BX6_SOLO
 #define BX6_SOLO 1       // N % 128 != 0: one-wave 128 x 64 blocks (1) or the two-wave 256 x 64 block (0)
 #endif

@@ -617,7 +617,7 @@ def pack_signs(pos):
 
 @pytest.mark.parametrize("epi", ["affine_relu", "lrelu"])
 @pytest.mark.parametrize("B,H,Cin,Cout", [(128, 8, 128, 64), (130, 8, 64, 96), (128, 8, 64, 128)])
-def test_forward_epilogue_leaves_the_sign_mask(B, H, Cin, Cout, epi):
+def test_forward_epilogue_leaves_the_sign_mask(B, H, Cin, Cout, epi, contraction):
     """cgs_deconv2d_nhwc_fwd_signs: the same output, bit for bit, as the plain call, plus the documented bitmask of (y > 0):
     BN = 64 and BN = 128 tiles (8 / 16 lanes per row), a channel count that is not a multiple of 64, a ragged batch."""
     from cgs_amd import kernels as K, lib
@@ -633,12 +633,20 @@ def test_forward_epilogue_leaves_the_sign_mask(B, H, Cin, Cout, epi):
     assert torch.equal(y0, y1)
     got = unpack_signs(signs, B * 4 * H * H, Cout)
     assert np.array_equal(got, (y1 > 0).cpu().numpy().reshape(-1, Cout))
-    # not offered: split-K grids (tiny batch), channel counts off the 32 granule, epilogues without a kink
-    assert not K.conv_signs_ok(lib.DECONV_FWD, 2, H, H, Cin, 2 * H, 2 * H, Cout, 5, 5, 2, 2, e)
+    bx6 = contraction == "bx6" and Cin % 32 == 0 and Cout % 64 == 0          # this forward runs on the split-bf16 kernel (same mask, same layout)
+    assert lib.last_kernel().startswith("igemm_bx6_kernel" if bx6 else "igemm_kernel")
+    # not offered: split-K grids (tiny batch; the split-bf16 kernel never splits over K and does offer it), channel counts off the 32
+    # granule, epilogues without a kink
+    assert bool(K.conv_signs_ok(lib.DECONV_FWD, 2, H, H, Cin, 2 * H, 2 * H, Cout, 5, 5, 2, 2, e)) == bx6
     assert not K.conv_signs_ok(lib.DECONV_FWD, B, H, H, Cin, 2 * H, 2 * H, 40, 5, 5, 2, 2, e)
     assert not K.conv_signs_ok(lib.DECONV_FWD, B, H, H, Cin, 2 * H, 2 * H, Cout, 5, 5, 2, 2, lib.EPI_TANH)
-    with pytest.raises(lib.CgsError):
-        K.deconv2d_fwd(x[:2], w, b, (2 * H, 2 * H), 2, 2, e, ea, ec, signs=signs)
+    if bx6:
+        small = torch.full((2 * 4 * H * H * Cout // 32,), -1, dtype=torch.int32, device=d)
+        y2 = K.deconv2d_fwd(x[:2].contiguous(), w, b, (2 * H, 2 * H), 2, 2, e, ea, ec, signs=small)
+        assert np.array_equal(unpack_signs(small, 2 * 4 * H * H, Cout), (y2 > 0).cpu().numpy().reshape(-1, Cout))
+    else:
+        with pytest.raises(lib.CgsError):
+            K.deconv2d_fwd(x[:2], w, b, (2 * H, 2 * H), 2, 2, e, ea, ec, signs=signs)
 
 
 @pytest.mark.parametrize("mode", ["relu_affine", "lrelu"])

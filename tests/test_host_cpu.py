@@ -427,3 +427,26 @@ def test_refiner_unwraps_the_reference_wiring_without_a_gpu():
     assert Refiner._unwrap(partial(m.feature_to_data, is_training=False), ("is_training",)) == (m, M.feature_to_data, {"is_training": False})
     r = Refiner(3, 0.1)
     assert r.use_graph is True and r.path is None and r.graph_fallback is None               # the class-surface defaults (hipGraph on)
+
+
+def test_contraction_kernels_keep_their_accumulators_in_registers():
+    """A correct-but-4x-slower build is invisible to the parity tests: when an accumulator array is indexed at run time (an epilogue
+    loop the compiler did not unroll) it moves to scratch memory.  Compile the two implicit-GEMM sources for gfx950 with the resource
+    remarks on and require: no scratch, no spilled vector registers in any igemm kernel (hipcc cross-compiles without a GPU)."""
+    import subprocess
+    csrc = os.path.join(ROOT, "collaborative-gan-sampling_amd", "csrc")
+    for src in ("igemm_bx6.hip", "igemm.hip"):
+        out = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-I" + os.path.join(ROOT, "include"), "-I" + csrc,
+                              "-Rpass-analysis=kernel-resource-usage", "--cuda-device-only", "-c", os.path.join(csrc, src), "-o", os.devnull],
+                             capture_output=True, text=True, timeout=1200)
+        assert out.returncode == 0, out.stderr[-2000:]
+        name, seen = None, 0
+        for line in out.stderr.splitlines():
+            m = re.search(r"Function Name: (\S+)", line)
+            if m:
+                name = m.group(1)
+            m = re.search(r"(ScratchSize \[bytes/lane\]|VGPRs Spill): (\d+)", line)
+            if m and name and "igemm" in name and "pack" not in name and "reduce" not in name:
+                seen += 1
+                assert int(m.group(2)) == 0, f"{src}: {name}: {m.group(1)} = {m.group(2)}"
+        assert seen >= 8, (src, seen)
