@@ -10,5 +10,5 @@ print(v, d["value"], d["ms_per_step"])
 for k, x in sorted(d["kernels"].items(), key=lambda kv: -kv[1]["share_of_step"])[:14]:
     print("  %-86s n=%4d %7.1f us %6.1f TF share %.3f" % (k[:86], x["launches"], x["avg_us"], x["tflops"], x["share_of_step"]))
 PY
-  for i in 1 2; do CGS_LIB=$R/collaborative-gan-sampling_amd/libcgs_$v.so python bench.py --arch cyclegan256 --no-cpu-baseline --no-other-configs 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('   default run', d['value'])"; done
+  for i in 1 2; do CGS_LIB=$R/collaborative-gan-sampling_amd/libcgs_$v.so python bench.py --arch cyclegan256 --no-cpu-baseline --no-other-configs 2>>$O/stderr.log | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('   default run', d['value'])"; done
 done
