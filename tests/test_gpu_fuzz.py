@@ -73,7 +73,7 @@ def wide_cases(seed, n):
         cin, cout = int(rs.choice([32, 64, 96, 128, 256])), int(rs.choice([128, 256, 384]))
         if rs.randint(2):
             cin, cout = cout, cin
-        if B * H * W * max(cin, cout) > 3_000_000 or B * H * W * cin * cout * k * k > 6e9:
+        if B * H * W * max(cin, cout) > 3_000_000 or B * H * W * cin * cout * k * k > 1.2e9:      # (the checker's CPU backward takes a minute per 5e9 here)
             continue
         out.append((B, H, W, cin, cout, k, s))
     return out
