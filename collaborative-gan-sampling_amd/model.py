@@ -103,14 +103,15 @@ class GAN(object):
             self.discriminator(self.generator(z, is_training=False, reuse=False), is_training=False, reuse=False)
         return ops.variables()
 
-    def engine(self, batch_size=None, use_graph=False):
-        """The fused device program for this net at a batch size (compiled once, cached)."""
+    def engine(self, batch_size=None, use_graph=False, contraction="f32"):
+        """The fused device program for this net at a batch size (compiled once, cached).  ``contraction``: "f32" (exact fp32 MFMA,
+        the default) or the opt-in "bx6" (include/cgs_hip.h, cgs_set_contraction)."""
         from .engine import RefineEngine
         B = int(batch_size or self.batch_size)
-        key = (B, use_graph)
+        key = (B, use_graph, contraction)
         hit = self._engines.get(key)
         if hit is None or hit[1] != ops.generation():       # a checkpoint was loaded since: re-fold the G bn affines, re-pack
-            hit = self._engines[key] = (RefineEngine(self.A, self.build_variables(), B, self.device, use_graph=use_graph),
+            hit = self._engines[key] = (RefineEngine(self.A, self.build_variables(), B, self.device, use_graph=use_graph, contraction=contraction),
                                         ops.generation())
         return hit[0]
 

@@ -38,6 +38,8 @@ class Refiner():
                                         # launches in the same process (``graph_fallback`` then holds the reason)
         self.graph_fallback = None
         self.path = None                # "engine" | "generic": which execution form the last build_refiner took
+        self.contraction = "f32"        # engine path: "f32" = exact fp32 matrix instructions (the reference's precision); "bx6" opts the big
+                                        # layers into the split-bf16 contraction (include/cgs_hip.h, cgs_set_contraction)
         self.indices_batch = None       # last probabilistic draw
 
     def set_env(self, discriminator, feature_to_data, func_loss):
@@ -138,7 +140,7 @@ class Refiner():
 
     def _engine_for(self, batch):
         owner = self._engine_owner()
-        return None if owner is None else owner.engine(batch, use_graph=self.use_graph)
+        return None if owner is None else owner.engine(batch, use_graph=self.use_graph, contraction=self.contraction)
 
     def build_refiner(self, fake_feature, real_batch, mode='deterministic', indices=None):
         """collaborator.py:41-88.  ``real_batch`` only feeds statistics the reference computes and never
@@ -157,7 +159,7 @@ class Refiner():
             args = (fake_feature, K_steps, self.optimizer.lambda_, self.optimizer.method, mode,
                     self.indices_batch if mode == 'probabilistic' else None, self.vmin, self.vmax)
             try:
-                out = owner.engine(B, use_graph=self.use_graph).refine(*args)
+                out = owner.engine(B, use_graph=self.use_graph, contraction=self.contraction).refine(*args)
             except L.CgsError:
                 raise                                             # an argument error, not a capture failure
             except Exception as ex:                               # noqa: BLE001 (hipGraph capture refused: HIP, allocator, another thread's HIP call)
@@ -170,7 +172,7 @@ class Refiner():
                     torch.cuda.synchronize(fake_feature.device)
                 except Exception:                                 # noqa: BLE001
                     pass
-                out = owner.engine(B, use_graph=False).refine(*args)
+                out = owner.engine(B, use_graph=False, contraction=self.contraction).refine(*args)
             img, d_l, o_l, o_s, o_f = out
             # the engine returns its own (cached, reused) buffers: hand out copies, so that a second build_refiner -- the
             # reference builds a deterministic and a probabilistic refiner side by side, nsgan/GAN.py:182-183 -- does not

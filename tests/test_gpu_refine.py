@@ -193,6 +193,12 @@ def test_reference_verbatim_wiring_takes_the_engine(path):
         check_against_golden(g, img, refiner.default_logit, refiner.optimal_logit, refiner.optimal_step, refiner.optimal_feature,
                              oracle_render=lambda f: N.feature_to_data(arch, P, f))
     assert len(self.engine(len(f0), use_graph=True)._graphs) == 1
+    if "dcgan64_B64" in path:      # the class surface's opt-in: the same wiring with refiner.contraction set (every eligible layer: "bx6_all")
+        refiner.contraction = "bx6_all"
+        img = refiner.build_refiner(f0, real, mode, indices=idx)
+        assert refiner.path == "engine" and self.engine(len(f0), use_graph=True, contraction="bx6_all").contraction == "bx6_all"
+        check_against_golden(g, img, refiner.default_logit, refiner.optimal_logit, refiner.optimal_step, refiner.optimal_feature,
+                             oracle_render=lambda f: N.feature_to_data(arch, P, f), image_drift=60.0)
     ops.reset_variables()
 
 
