@@ -138,26 +138,28 @@ def test_two_ranks_on_the_one_gpu_through_the_whole_multi_rank_path():
     assert bad.returncode != 0 and "WORLD_SIZE=1" in (bad.stderr + bad.stdout)
 
 
-@pytest.mark.parametrize("contraction", ["f32", "bx6"])
-def test_two_ranks_on_the_one_gpu_with_the_drivers_own_workload(contraction):
+@pytest.mark.parametrize("arch,contraction", [("dcgan64", "f32"), ("dcgan64", "bx6"), ("cyclegan256", "f32")])
+def test_two_ranks_on_the_one_gpu_with_the_drivers_own_workload(arch, contraction):
     """the first 8-GPU run is the driver's `bench.py --gpus N` with the dcgan64 DEFAULT workload (batch 1024 per rank,
     K = 20, hipGraph x 2 in flight).  The same command at world 2 on the one GPU: graphs captured on every rank with RCCL-free gloo
     threads around, no eager fallback, rank 0's extra profiling step (the other rank waits for it inside an all-gather) far below
-    the collective timeout -- with the exact-fp32 default and with the opt-in split-bf16 contraction."""
+    the collective timeout -- with the exact-fp32 default and with the opt-in split-bf16 contraction; and BASELINE config 5 in its
+    multi-rank form (cyclegan256, batch 8 per rank, four calls in flight per rank)."""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("RANK", None); env.pop("WORLD_SIZE", None); env.pop("MASTER_ADDR", None)
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu",
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu", "--arch", arch,
                           "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--contraction", contraction], cwd=ROOT, capture_output=True, text=True,
                          timeout=1200, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and "dcgan64" in d["config"]["workload"] and d["config"]["global_batch"] == 2048 and d["config"]["refine_steps"] == 20
+    B, img = (1024, 64 * 64 * 3) if arch == "dcgan64" else (8, 256 * 256 * 3)        # (config 5's per-GPU share: 64 over 8 GPUs)
+    assert d["n_gpus"] == 2 and arch in d["config"]["workload"] and d["config"]["global_batch"] == 2 * B and d["config"]["refine_steps"] == 20
     assert d["config"]["hipgraph"] is True and "hipgraph_fallback" not in d["config"]
     x = d["dist"]
     assert x["world_size"] == 2 and x["ranks_seen"] == 2 and x["hipgraph_ranks"] == 2
-    assert x["pool_bytes"] == 2 * 1024 * 64 * 64 * 3 * 4 and x["pool_rows_match_ranks"] is True and x["pool_rank_sums_distinct"] is True
+    assert x["pool_bytes"] == 2 * B * img * 4 and x["pool_rows_match_ranks"] is True and x["pool_rank_sums_distinct"] is True
     assert 0 < x["rank0_profile_step_wall_s"] < 5.0
     assert 0 < d["roofline"]["frac"] <= 1.0 and ("igemm_bx6" if contraction == "bx6" else "igemm_kernel") in d["roofline"]["kernel"]
     assert d["config"]["contraction"] == contraction and d["dtype"] == ("f32" if contraction == "f32" else "f32 (3xbf16 split, fp32 accumulate)")
