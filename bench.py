@@ -76,6 +76,14 @@ IN_FLIGHT = {"dcgan64": 2, "dcgan32": 4, "mnist": 4, "cyclegan256": 4}
 THREE_CHANNEL = ("convt_rows_kernel", "conv_patch2_kernel", "conv_patch_kernel", "convt_quad", "convt_taps_kernel", "conv_taps_kernel")
 
 
+def lib_stamp():
+    """Which library produced the line: the sha256 of the kernel sources the in-tree .so is built from (``lib.source_hash``: the key
+    profiles/traffic.json is valid for), the ABI version the loaded object reports, and whether CGS_LIB pointed the run at another build."""
+    from cgs_amd import lib as L
+    return {"source_sha16": L.source_hash()[:16], "cgs_version": int(L.load().cgs_version()), "so": os.path.relpath(L.LIB_PATH, ROOT),
+            "cgs_lib_override": bool(os.environ.get("CGS_LIB"))}
+
+
 def _traffic_table():
     """profiles/traffic.json -- or {} when it was collected on other kernel sources than the ones this run executes (a stale
     number is worse than none), or when CGS_LIB points the run at some other build of the library."""
@@ -275,7 +283,7 @@ def bench_synthetic2d(args, dev, rank, world):
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": f"synthetic2d Imbal-8Gaussians MLP-GAN D 2-64x5-1, batch {B}, K={Ksteps}, ladam rate {args.rate}: "
                                       f"real-batch baseline + fused K-step refine (3 launches per batch, no host synchronisation), {n_streams} batches in flight"},
-               "roofline": None}
+               "roofline": None, "lib": lib_stamp()}
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_synthetic2d(S, Ws, bs, x, real, B, Ksteps, args.rate)
         print(json.dumps(out), flush=True)
@@ -410,11 +418,154 @@ def class_surface(dev, configs=(("dcgan64", 1024, 20, 6, 3), ("mnist", 64, 50, 2
                          "hipgraph": bool(r.use_graph) if r.path == "engine" else False}
             if r.graph_fallback:
                 rec[name]["hipgraph_fallback"] = r.graph_fallback
+        if arch == "mnist":
+            # the reference's callers run the refiner one batch_size-64 batch per sess.run (nsgan/main.py:32, nsgan/GAN.py:270-272,398-426):
+            # ``refiner.logical_batch = 64`` hands build_refiner G such batches at once -- one launch per layer, D's batch statistics and
+            # the step bookkeeping per logical batch -- through the same verbatim wiring
+            Gf = FUSE[arch]
+            refiner.logical_batch = B
+            zf = torch.from_numpy(np.random.RandomState(2020).uniform(-1, 1, (steps // 4 + 2, B * Gf) + nets.g_input_shape(A)).astype(np.float32)).to(dev)
+            with torch.no_grad():
+                for i in range(2):
+                    refiner.build_refiner(self.input_to_feature(zf[i]), None, mode="deterministic")
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                for i in range(2, len(zf)):
+                    refiner.build_refiner(self.input_to_feature(zf[i]), None, mode="deterministic")
+                torch.cuda.synchronize(dev)
+            dt = time.perf_counter() - t0
+            kf = len(zf) - 2
+            rec["fused"] = {"samples_per_s": round(B * Gf * kf / dt, 1), "ms_per_call": round(1e3 * dt / kf, 3), "calls": kf, "logical_batch": B,
+                            "logical_batches_per_call": Gf, "path": refiner.path, "hipgraph": bool(refiner.use_graph),
+                            "how": f"refiner.logical_batch = {B}; build_refiner(feature[{B * Gf}], ...): one call, one stream"}
+            refiner.logical_batch = None
+            del zf
         out[arch] = rec
         del self, refiner, generic, z, inputs
         ops.reset_variables()
         torch.cuda.empty_cache()
     return out
+
+
+def shaping_record(dev, configs=(("mnist", 64, 50, 30), ("dcgan64", 64, 20, 12))):
+    """SURVEY 8f-2 measured: one iteration of the reference's D-shaping loop (nsgan/GAN.py:266-272) at the reference's batch size
+    (nsgan/main.py:32) -- sess.run(g_refine_proba) then sess.run([d_optim, d_loss]) -- as ``shaping.shape_step``: probabilistic
+    refine on the engine (hipGraph replay), one Adam step of D (two D passes with batch statistics, weight / bias / gamma / beta
+    gradients, Adam), then ``refresh_weights`` (re-fold + re-pack for the next refine).  Strictly sequential by construction (every
+    refine sees the D the previous step shaped): nothing to fuse across iterations.  ``kernels.wgrad_kernel``: the weight-gradient
+    GEMMs of one D step (HIP events, eager), flops issued / launch time against the fp32 matrix peak."""
+    from cgs_amd import kernels as K
+    from cgs_amd import nets
+    from cgs_amd.engine import RefineEngine
+    from cgs_amd.shaping import DShaper, shape_step
+    out = {}
+    for arch, B, Ksteps, iters in configs:
+        A = nets.ARCHS[arch]
+        P = nets.init_params(arch, dev, seed=2019)
+        eng = RefineEngine(arch, P, B, dev, use_graph=True)
+        sh = DShaper(arch, P, B, dev, learning_rate=1e-5)                     # run_shaping.sh: --learning_rate 1e-5
+        rs = np.random.RandomState(2019)
+        z = torch.from_numpy(rs.uniform(-1, 1, (iters + 3, B) + nets.g_input_shape(A)).astype(np.float32)).to(dev)
+        real = torch.from_numpy(rs.uniform(-1, 1, (B,) + tuple(A["img"])).astype(np.float32)).to(dev)
+        idx = rs.randint(Ksteps + 1, size=B)                                  # ONE draw baked into the graph (collaborator.py:54-56)
+        for i in range(3):
+            shape_step(eng, sh, z[i], real, Ksteps, 0.1, indices=idx)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for i in range(3, 3 + iters):
+            shape_step(eng, sh, z[i], real, Ksteps, 0.1, indices=idx)
+        torch.cuda.synchronize(dev)
+        it_ms = 1e3 * (time.perf_counter() - t0) / iters
+        refined = eng.refine_from_z(z[0], Ksteps, 0.1, mode="probabilistic", indices=idx)[0].clone()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            sh.step(real, refined)
+        torch.cuda.synchronize(dev)
+        d_ms = 1e3 * (time.perf_counter() - t0) / iters
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            eng.refresh_weights()
+        torch.cuda.synchronize(dev)
+        refresh_ms = 1e3 * (time.perf_counter() - t0) / iters
+        K.PROFILE = {}
+        tp = time.perf_counter()
+        sh.step(real, refined)
+        torch.cuda.synchronize(dev)
+        prof_ms = 1e3 * (time.perf_counter() - tp)
+        prof, K.PROFILE = K.PROFILE, None
+        eng.refresh_weights()
+        kern = {}
+        for name, (fl, evs, ex, nb) in prof.items():
+            ms = sum(a.elapsed_time(b) for a, b in evs)
+            if fl > 0 and ms > 0:
+                kern[name] = {"launches": len(evs), "avg_us": round(1e3 * ms / len(evs), 2), "tflops": round(ex / ms / 1e9, 2),
+                              "frac_of_fp32_matrix_peak": round(ex / ms / 1e9 / PEAK_FP32_MATRIX_TFLOPS, 4), "share_of_d_step": round(ms / prof_ms, 3)}
+        out[arch] = {"batch": B, "refine_steps": Ksteps, "iterations": iters, "iteration_ms": round(it_ms, 3), "iterations_per_s": round(1e3 / it_ms, 2),
+                     "samples_per_s": round(B * 1e3 / it_ms, 1), "d_step_ms": round(d_ms, 3), "refresh_weights_ms": round(refresh_ms, 3),
+                     "refine_ms": round(it_ms - d_ms - refresh_ms, 3), "hipgraph": True, "kernels": kern}
+        del eng, sh, P, z
+        torch.cuda.empty_cache()
+    out["note"] = ("nsgan/GAN.py:266-272 per iteration: probabilistic K-step refine (hipGraph replay) + one Adam step of D (real + refined pass, batch "
+                   "statistics) + refresh (re-fold, re-pack); batch 64 as in nsgan/main.py:32: launch-latency-bound by construction")
+    return out
+
+
+def f1_fill(dev, eval_size=50000, B=64, Ksteps=50, G=None):
+    """SURVEY 8f-1 measured: the reference's evaluate fill loop (nsgan/GAN.py:384-426, "collaborate": eval_size = 50 000 at
+    batch_size 64, nsgan/main.py:32-33) on mnist -- score the real set, standard samples as the chain's first pass, then refine ->
+    D-score -> MH independence chain (T = 20) until eval_size samples are accepted (MIN_EFFICIENCY = 0.2 cut-off) -- as
+    ``evaluate.collaborate_fused`` over ``FusedProposer``: G logical batches per device round, the host chain one round behind.
+    Random-init weights and uniform noise as the "real" set (no dataset here): the acceptance statistics are those of this D, the
+    bookkeeping and the device work per proposal are the reference's."""
+    from cgs_amd import nets, ops
+    from cgs_amd.evaluate import MIN_EFFICIENCY, FusedProposer, collaborate_fused
+    from cgs_amd.model import GAN
+    from cgs_amd.sampling import IndependenceSampler
+    G = G or FUSE["mnist"]
+    ops.reset_variables()
+    gan = GAN("mnist", batch_size=B, device=dev, params=nets.init_params("mnist", dev, seed=2019))
+    prop = FusedProposer(gan, Ksteps, 0.1, batch=B, groups=G, depth=2)
+    n_batch = eval_size // B
+    n_eval = n_batch * B                                     # (the reference's int(eval_size / batch_size) whole batches, :386)
+    np.random.seed(2019)                                     # nsgan/GAN.py:257
+    real = np.random.RandomState(1).uniform(-1, 1, (n_eval, 28, 28, 1)).astype(np.float32)
+    z0 = np.random.uniform(-1, 1, [prop.b * prop.G, gan.z_dim]).astype(np.float32)
+    prop.result(prop.launch(z0)); prop.result(prop.launch(z0))            # both slots: graph capture, workspaces (untimed)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    sigmoid_real = prop.score_real(real)                                   # :388-390
+    t1 = time.perf_counter()
+    eval_z = np.random.uniform(-1, 1, [n_eval, gan.z_dim]).astype(np.float32)      # :391
+    std_img = np.empty((n_eval, 28, 28, 1), dtype=np.float32)
+    std_sig = np.empty((n_eval, 1), dtype=np.float32)
+    n = prop.b * prop.G
+    for i in range(0, n_eval, n):                                          # :394-400 (standard samples + their sigmoids), G batches per launch
+        zb = eval_z[i:i + n]
+        m = len(zb)
+        if m < n:
+            zb = np.concatenate([zb, np.zeros((n - m, gan.z_dim), np.float32)])
+        im, sg = prop.result(prop.launch(zb, refine=False))
+        std_img[i:i + m], std_sig[i:i + m] = im[:m], sg[:m]
+    t2 = time.perf_counter()
+    st = {}
+    samples, eff = collaborate_fused(prop, IndependenceSampler(T=20), n_eval, float(np.mean(sigmoid_real)), base=(std_img, std_sig),
+                                     min_efficiency=MIN_EFFICIENCY, stats=st)
+    t3 = time.perf_counter()
+    assert samples.shape[0] == n_eval and np.isfinite(samples).all()
+    fill_s = t3 - t2
+    rec = {"arch": "mnist", "eval_size": n_eval, "batch": B, "refine_steps": Ksteps, "logical_batches_per_round": G, "rounds_in_flight": 2,
+           "accepted_samples_per_s": round(n_eval / fill_s, 1), "fill_s": round(fill_s, 3), "efficiency": round(eff, 4),
+           "proposed": int(st["proposed"]), "proposals_per_s": round(st["proposed"] / fill_s, 1), "rounds": int(st["rounds"]),
+           "host_chain_s": round(st["host_chain_s"], 3), "host_chain_share_of_wall": round(st["host_chain_s"] / fill_s, 3),
+           "device_wait_s": round(st["device_wait_s"], 3), "score_real_s": round(t1 - t0, 3), "standard_pass_s": round(t2 - t1, 3),
+           "note": "nsgan/GAN.py:384-426 (method 'collaborate'): real-set scoring, standard pass, then refine -> score -> MH chain (T=20) fill with "
+                   "the MIN_EFFICIENCY=0.2 cut-off; the host chain of round r runs while the device refines round r+1; random-init weights, "
+                   "uniform noise as the real set"}
+    del prop, gan
+    ops.reset_variables()
+    torch.cuda.empty_cache()
+    return rec
 
 
 DTYPE = {"f32": "f32", "bx6": "f32 (3xbf16 split, fp32 accumulate)"}
@@ -568,8 +719,15 @@ def main():
     n_batches = args.steps + args.warmup                                # a step = one engine call = G logical batches
     rs = np.random.RandomState(D.rank_seed(rank))                       # rank-offset seed (2019 + rank): disjoint z shards
     z = torch.from_numpy(rs.uniform(-1, 1, (n_batches, B * G) + nets.g_input_shape(A)).astype(np.float32)).to(dev)   # z, or source images
+    # one node-wide pool buffer per batch in flight (config 4: 8 ranks x 1024 x 64x64x3 fp32 = 402.7 MB per buffer, x 2 in flight per rank):
+    # sized against the device's free memory BEFORE allocating, so a pool that cannot fit is a message, not an OOM inside the timed region
+    pool_bytes = world * B * G * int(np.prod(A["img"])) * 4
+    mem_free, mem_total = torch.cuda.mem_get_info(dev)
+    if use_dist and pool_bytes * n_flight > 0.5 * mem_free:
+        raise SystemExit(f"[bench rank {rank}] the sample pool needs {n_flight} x {pool_bytes / 1e6:.1f} MB but only {mem_free / 1e6:.1f} MB of device "
+                         f"memory are free (half of it is kept for the engines): lower --batch / --streams")
     pools = [torch.empty((world * B * G,) + tuple(A["img"]), dtype=torch.float32, device=dev) if use_dist else None
-             for _ in range(n_flight)]                                   # one node-wide pool buffer per batch in flight
+             for _ in range(n_flight)]
 
     # -- prepare: every engine's first call (packs weights, sizes workspaces, captures its hipGraph).  No collective in here, so
     # a rank whose capture fails can fall back to eager launches by itself without unbalancing the ranks' gather counts.
@@ -667,7 +825,9 @@ def main():
             per_rank = B * G * args.steps / rows[:, 1]
             dist_rec = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "ranks_seen": len({int(r) for r in rows[:, 0]}),
                         "devices": "shared cuda:0 (debug)" if args.share_gpu else "one per rank",
-                        "pool_bytes": int(pools[0].numel() * 4), "gathers_per_step": 1,
+                        "pool_bytes": int(pools[0].numel() * 4), "pool_buffers_per_rank": n_flight,
+                        "pool_bytes_per_rank_total": int(pool_bytes * n_flight), "device_mem_free_before_pools": int(mem_free),
+                        "device_mem_total": int(mem_total), "gathers_per_step": 1,
                         "gather_ms_per_step": round(sum(a.elapsed_time(b) for a, b in gather_ev) / max(1, len(gather_ev)), 4),
                         "gather": "all_gather_into_tensor on the step's stream, HIP events around it" + ("" if args.backend == "nccl" else " (gloo: staged through the host)"),
                         "per_rank_samples_per_s": [round(float(per_rank.min()), 1), round(float(per_rank.max()), 1)],
@@ -692,6 +852,7 @@ def main():
                        "hipgraph": all_graph, "batches_in_flight": n_flight * G, "fused_per_launch": G, "sync_bn": bool(args.sync_bn),
                        "contraction": args.contraction},
             "algorithmic_tflops": round(value * flops_per_sample / 1e12, 2),
+            "lib": lib_stamp(),
         }
         if graph_fallback:
             out["config"]["hipgraph_fallback"] = graph_fallback
@@ -718,6 +879,8 @@ def main():
                 out["bx6"] = bx6_line(args, P, B, G, Ksteps, z, dev, n_flight, streams, flops_per_sample)
             out["other_configs"] = other_configs(dev, args.arch, not args.no_cpu_baseline)
             out["class_surface"] = class_surface(dev)
+            out["f1"] = f1_fill(dev)
+            out["shaping"] = shaping_record(dev)
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)

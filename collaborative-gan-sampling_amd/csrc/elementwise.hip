@@ -152,6 +152,38 @@ int cgs_bce_ones_grad_rowmean(const float* logits, float* dlogits, float* logit_
     return CGS_OK;
 }
 
+// sig[b] = mean_p sigmoid(l[b, p]): fake_sigmoids = tf.nn.sigmoid(fake_logits) (nsgan/GAN.py:154-155; P = 1 there), the score the
+// accept / reject step reads (nsgan/GAN.py:409, sampling/idpsampler.py:18).  One thread per sample (P < 64) or one wave (P >= 64).
+__device__ __forceinline__ float sigmoid_stable(float v) { return v >= 0.f ? 1.f / (1.f + expf(-v)) : expf(v) / (1.f + expf(v)); }
+
+__global__ void sigmoid_rowmean_kernel(const float* __restrict__ l, float* __restrict__ sig, int B, int P) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float s = 0.f;
+    for (int i = 0; i < P; ++i) s += sigmoid_stable(l[(size_t)b * P + i]);
+    sig[b] = P == 1 ? s : s / (float)P;
+}
+
+__global__ __launch_bounds__(256) void sigmoid_rowmean_wave_kernel(const float* __restrict__ l, float* __restrict__ sig, int B, int P) {
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (b >= B) return;
+    float s = 0.f;
+    for (int i = lane; i < P; i += 64) s += sigmoid_stable(l[(size_t)b * P + i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) sig[b] = s / (float)P;
+}
+
+int cgs_sigmoid_rowmean(const float* logits, float* sigmoids, int B, int P, void* stream) {
+    if (B <= 0 || P <= 0) return cgs_set_error(CGS_EINVAL, "sigmoid_rowmean: B=%d P=%d", B, P);
+    if (P >= 64)
+        hipLaunchKernelGGL(sigmoid_rowmean_wave_kernel, dim3(cgs_ceil_div(B, 4)), dim3(256), 0, (hipStream_t)stream, logits, sigmoids, B, P);
+    else
+        hipLaunchKernelGGL(sigmoid_rowmean_kernel, dim3(cgs_ceil_div(B, 128)), dim3(128), 0, (hipStream_t)stream, logits, sigmoids, B, P);
+    CGS_CHECK_LAUNCH("sigmoid_rowmean");
+    return CGS_OK;
+}
+
 // OP 0: softplus(-l) (stable form);  1: dy * (sigmoid(l) - 1);  2: clip
 template <int OP>
 __global__ __launch_bounds__(256) void loss_unary_kernel(const float* __restrict__ p0, const float* __restrict__ p1, float lo, float hi,

@@ -465,6 +465,22 @@ class Tape:
 
 
 # ----------------------------------------------------------------------------- the loop
+def _entry(fn):
+    """A public entry point of an engine: the engine's contraction mode is in force for the call and the calling thread's previous
+    mode is restored after it (ops.* calls, a DShaper step or another engine do not inherit this engine's opt-in)."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(self, *a, **kw):
+        prev = K.set_contraction(self.contraction)
+        try:
+            return fn(self, *a, **kw)
+        finally:
+            if prev != self.contraction:
+                K.set_contraction(prev)
+    return wrapped
+
+
 class RefineEngine:
     """K-step collaborative refinement of a batch of G activation maps on one GPU."""
 
@@ -481,7 +497,14 @@ class RefineEngine:
         if self.dev.type != "cuda":
             raise L.CgsError("RefineEngine needs a GPU device (there is no CPU path)")
         L.load()
-        K.set_contraction(self.contraction)
+        prev_mode = K.set_contraction(self.contraction)
+        try:
+            self._build(params, batch_size, use_graph, sync_bn, bn_groups)
+        finally:
+            if prev_mode != self.contraction:
+                K.set_contraction(prev_mode)
+
+    def _build(self, params, batch_size, use_graph, sync_bn, bn_groups):
         A, B = self.A, int(batch_size)
         self.B, self.P = B, params
         with torch.cuda.device(self.dev):
@@ -552,11 +575,13 @@ class RefineEngine:
         inference-bn affines; after ``ops.set_variables`` / a shaping step (``K.WS.invalidate()``) the last two are stale, and a
         captured hipGraph would replay a MIX of old and new state.  Any engine -- also one built directly, not through
         ``model.GAN`` -- re-derives them here before its next use."""
-        K.set_contraction(self.contraction)          # (a string compare when it is already in force)
         if self._ws_epoch != K.WS.epoch:
             self._resync()
 
     def _resync(self):
+        # the eager forward + backward below re-packs the workspaces of THIS engine's kernel families (the cache is keyed by family):
+        # the engine's own contraction must be in force, whichever engine of the process ran last
+        K.set_contraction(self.contraction)
         epoch = K.WS.epoch
         with torch.cuda.device(self.dev):
             for tape in (self.g_head, self.g_tail, self.d):
@@ -574,20 +599,36 @@ class RefineEngine:
         self._ws_epoch = epoch
 
     # -- pieces (sampling/collaborator.py:26-39) ------------------------------------------------
+    @_entry
     def input_to_feature(self, z):
         """G head (nsgan/GAN.py:87-92)."""
         self._sync_weights()
         return self.g_head.forward(z)
 
+    @_entry
     def feature_to_data(self, feat):
         """G tail (nsgan/GAN.py:94-101)."""
         self._sync_weights()
         return self.g_tail.forward(feat)
 
+    @_entry
     def discriminator(self, x):
         """D with batch-statistics bn (nsgan/GAN.py:59-70 bound at :175)."""
         self._sync_weights()
         return self.d.forward(x)
+
+    @_entry
+    def generate(self, z):
+        """fake_images = generator(z, is_training=False): G head + G tail, no refinement (nsgan/GAN.py:153).  Engine-owned buffer."""
+        self._sync_weights()
+        return self.g_tail.forward(self.g_head.forward(z))
+
+    @_entry
+    def score(self, images, out=None):
+        """fake_sigmoids = sigmoid(D(images)) with D on batch statistics -- per logical batch under ``bn_groups`` -- as [B, 1]
+        (nsgan/GAN.py:154-155): what Rejector / IndependenceSampler read.  Stays on the device."""
+        self._sync_weights()
+        return K.sigmoid_rowmean(self.d.forward(images), out=out)
 
     def forward_logits(self, theta, logit_out):
         logits = self.d.forward(self.g_tail.forward(theta))
@@ -598,6 +639,7 @@ class RefineEngine:
         """d sum_b softplus(-logit_b) / d theta, through D then the G tail (collaborator.py:31)."""
         return self.g_tail.backward(self.d.backward(self.dlogits))
 
+    @_entry
     def compute_forward_logits_and_grad(self, feature):
         self._sync_weights()
         self.forward_logits(feature, self.logit)
@@ -623,6 +665,7 @@ class RefineEngine:
             K.refine_select_rows(render, self.logit, forced, i, self.images, self.best_logit)
             K.refine_select(th, self.logit, forced, i, self.best_theta, self.best_logit, self.best_step)
 
+    @_entry
     def refine(self, feature0, steps, rate, method="momentum", mode="deterministic", indices=None,
                vmin=None, vmax=None):
         """collaborator.py:41-88 on device.  Returns (images, default_logit, optimal_logit, optimal_step,
@@ -665,16 +708,22 @@ class RefineEngine:
                         self._program(steps, rate, alpha, prob, vmin, vmax)
                         self.theta.copy_(feature0)
                     torch.cuda.synchronize(self.dev)
-                    g = torch.cuda.CUDAGraph()
                     # (thread-local capture: other threads of the process -- RCCL proxies, the distributed watchdog, a second engine's
                     # host thread -- may make HIP calls meanwhile without invalidating this capture)
-                    with torch.cuda.graph(g, stream=self._gstream, capture_error_mode="thread_local"):
-                        self._program(steps, rate, alpha, prob, vmin, vmax)
+                    try:
+                        g = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(g, stream=self._gstream, capture_error_mode="thread_local"):
+                            self._program(steps, rate, alpha, prob, vmin, vmax)
+                    except L.CgsError:
+                        raise
+                    except Exception as ex:                          # noqa: BLE001 (HIP / allocator / another thread's HIP call refused the capture)
+                        raise L.GraphCaptureError(f"{type(ex).__name__}: {str(ex)[:300]}") from ex
                     cur.wait_stream(self._gstream)
                     self._graphs[key] = g
                 g.replay()
         return self.images, self.default_logit, self.best_logit, self.best_step, self.best_theta
 
+    @_entry
     def refresh_weights(self):
         """Call after the parameter tensors were updated in place by a kernel torch does not see (``shaping.DShaper.step``):
         marks every packed copy stale (for ALL engines: each one re-derives its state at its next call, ``_sync_weights``)
@@ -682,6 +731,7 @@ class RefineEngine:
         K.WS.invalidate()
         self._resync()
 
+    @_entry
     def refine_from_z(self, z, steps, rate, **kw):
         """Propose (G head) + refine + render: one whole unit of the BASELINE metric."""
         return self.refine(self.input_to_feature(z), steps, rate, **kw)

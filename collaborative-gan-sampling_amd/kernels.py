@@ -79,17 +79,34 @@ def same_out(size, stride):
 # ---- contraction arithmetic of the implicit-GEMM layers (include/cgs_hip.h, cgs_set_contraction): "f32" = exact fp32 MFMA (default),
 # "bx6" = opt-in split-bf16 MFMA for the big layers, "bx6_all" = the same for every eligible call (test coverage).  The library keeps
 # the mode per host thread; this module mirrors the mode of the thread that drives it (one host thread per process here).
-CONTRACTION = "f32"
+CONTRACTION = "f32"     # the mode this module last put in force (informational; the thread's real state is asked of the library)
 
 
 def set_contraction(mode):
-    """Switch the calling thread's contraction mode; returns the previous one."""
+    """Switch the CALLING THREAD's contraction mode; returns the previous one.  The library keeps the mode per host thread
+    (a second host thread starts in "f32" whatever another thread set), so the compare is against the thread's own state."""
     global CONTRACTION
-    prev = CONTRACTION
+    prev = L.get_contraction()
     if mode != prev:
         L.set_contraction(mode)
-        CONTRACTION = mode
+    CONTRACTION = mode
     return prev
+
+
+class contraction:
+    """``with contraction("bx6"): ...`` -- the mode for the block, the previous mode restored after it (generic ops.* calls,
+    DShaper steps and other engines of the thread do not inherit an engine's opt-in)."""
+
+    def __init__(self, mode):
+        self.mode = mode
+
+    def __enter__(self):
+        self.prev = set_contraction(self.mode)
+        return self
+
+    def __exit__(self, *exc):
+        set_contraction(self.prev)
+        return False
 
 
 class _WsCache:
@@ -611,6 +628,15 @@ def bce_ones_bwd(dloss, logits, out=None):
     return o
 
 
+def sigmoid_rowmean(logits, out=None):
+    """Per-sample discriminator score: the mean over a sample's logits of sigmoid(logit), [B, 1]   (fake_sigmoids, nsgan/GAN.py:154-155)."""
+    _chk(logits, "logits")
+    B = logits.shape[0]
+    o = out if out is not None else torch.empty((B, 1), dtype=torch.float32, device=logits.device)
+    L.call("cgs_sigmoid_rowmean", _ptr(logits), _ptr(o), B, logits.numel() // B, _stream())
+    return o
+
+
 def clip(x, vmin, vmax, out=None):
     """tf.clip_by_value (sampling/collaborator.py:69-70)."""
     _chk(x, "x")
@@ -664,8 +690,12 @@ def conv2d_bwd_weight(x, dy, kh, kw, sh=2, sw=2, out=None, accumulate=False):
     Cout = dy.shape[3]
     dw = out if out is not None else torch.empty((kh, kw, Cin, Cout), dtype=torch.float32, device=x.device)
     ws = _wgrad_workspace(int(L.load().cgs_conv_wgrad_ws_bytes(B, H, W, Cin, Cout, kh, kw, sh, sw)), x.device)
+    # (the weight-gradient GEMM multiplies the zero-padding taps too: issued = nominal flops; the slab reduce rides in the same record)
+    pr = _Prof(2.0 * B * dy.shape[1] * dy.shape[2] * Cout * kh * kw * Cin, "", _nb(x, dy, dw), op="wgrad_kernel") if PROFILE is not None else None
     L.call("cgs_conv2d_nhwc_bwd_weight", _ptr(x), _ptr(dy), _ptr(dw), B, H, W, Cin, Cout, kh, kw, sh, sw,
            1 if accumulate else 0, _ptr(ws), ws.numel() * 4, _stream())
+    if pr is not None:
+        pr.done()
     return dw
 
 
@@ -676,7 +706,10 @@ def linear_bwd_weight(x, dy, out=None, accumulate=False):
     N = dy.shape[1]
     dw = out if out is not None else torch.empty((K, N), dtype=torch.float32, device=x.device)
     ws = _wgrad_workspace(int(L.load().cgs_conv_wgrad_ws_bytes(B, 1, 1, K, N, 1, 1, 1, 1)), x.device)
+    pr = _Prof(2.0 * B * K * N, "", _nb(x, dy, dw), op="wgrad_kernel") if PROFILE is not None else None
     L.call("cgs_linear_bwd_weight", _ptr(x), _ptr(dy), _ptr(dw), B, K, N, 1 if accumulate else 0, _ptr(ws), ws.numel() * 4, _stream())
+    if pr is not None:
+        pr.done()
     return dw
 
 

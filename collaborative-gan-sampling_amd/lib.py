@@ -69,6 +69,7 @@ SIGNATURES = {
     "cgs_bce_ones_grad_rowmean": (_i, [_p, _p, _p, _i, _i, _p]),
     "cgs_bce_ones_fwd": (_i, [_p, _p, _z, _p]),
     "cgs_bce_ones_bwd": (_i, [_p, _p, _p, _z, _p]),
+    "cgs_sigmoid_rowmean": (_i, [_p, _p, _i, _i, _p]),
     "cgs_clip": (_i, [_p, _f, _f, _p, _z, _p]),
     "cgs_refine_update": (_i, [_p, _p, _p, _f, _f, _i, _i, _f, _f, _z, _p]),
     "cgs_refine_select": (_i, [_p, _p, _p, _i, _p, _p, _p, _i, _i, _p]),
@@ -92,6 +93,11 @@ _lib = None
 
 class CgsError(RuntimeError):
     pass
+
+
+class GraphCaptureError(RuntimeError):
+    """hipGraph capture of an engine's K-step program was refused (raised around the capture block only: argument errors and
+    failures of the eager warm-up stay what they are).  Callers may fall back to eager launches of the same engine."""
 
 
 def load():

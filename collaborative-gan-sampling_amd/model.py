@@ -103,17 +103,27 @@ class GAN(object):
             self.discriminator(self.generator(z, is_training=False, reuse=False), is_training=False, reuse=False)
         return ops.variables()
 
-    def engine(self, batch_size=None, use_graph=False, contraction="f32"):
+    def engine(self, batch_size=None, use_graph=False, contraction="f32", bn_groups=1):
         """The fused device program for this net at a batch size (compiled once, cached).  ``contraction``: "f32" (exact fp32 MFMA,
-        the default) or the opt-in "bx6" (include/cgs_hip.h, cgs_set_contraction)."""
+        the default) or the opt-in "bx6" (include/cgs_hip.h, cgs_set_contraction).  ``bn_groups`` = G: ``batch_size`` holds G
+        logical batches of batch_size / G samples back to back -- one launch per layer for all of them, D's batch statistics kept
+        per logical batch (nsgan/GAN.py:175 at the reference's own batch size, nsgan/main.py:32), so the result is that of G calls."""
         from .engine import RefineEngine
         B = int(batch_size or self.batch_size)
-        key = (B, use_graph, contraction)
+        key = (B, use_graph, contraction, int(bn_groups))
         hit = self._engines.get(key)
         if hit is None or hit[1] != ops.generation():       # a checkpoint was loaded since: re-fold the G bn affines, re-pack
-            hit = self._engines[key] = (RefineEngine(self.A, self.build_variables(), B, self.device, use_graph=use_graph, contraction=contraction),
-                                        ops.generation())
+            hit = self._engines[key] = (RefineEngine(self.A, self.build_variables(), B, self.device, use_graph=use_graph, contraction=contraction,
+                                                     bn_groups=int(bn_groups)), ops.generation())
         return hit[0]
+
+    @staticmethod
+    def _engines_generation():
+        return ops.generation()
+
+    def drop_engine(self, batch_size, use_graph, contraction="f32", bn_groups=1):
+        """Forget a cached engine (its activation buffers are freed with it)."""
+        self._engines.pop((int(batch_size), use_graph, contraction, int(bn_groups)), None)
 
     def build_refiner(self, rollout_steps, rollout_rate, rollout_method="momentum"):
         """nsgan/GAN.py:179-181."""

@@ -5,15 +5,24 @@ Same constructor, ``set_env`` / ``set_constraints`` / ``compute_forward_logits_a
 ``optimal_step``, ``optimal_feature``).  The reference's ``build_refiner`` emits a K-times unrolled
 TF graph that a later ``sess.run`` executes; here it executes: it returns the refined images.
 
-Execution paths (both all-HIP, no CPU fallback; ``refiner.path`` says which one the last call took):
+Execution paths (both all-HIP, no CPU fallback; ``refiner.path`` says which one the last call took and
+``refiner.why_generic`` why the engine was not taken):
   * engine:  if ``discriminator`` / ``feature_to_data`` are a ``cgs_amd.model.GAN``'s own methods -- bound, or wrapped
              in ``functools.partial`` the way nsgan/GAN.py:174-175 wraps them -- and ``func_loss`` computes the
              cross entropy against ones (GAN.loss_refine, or any closure that evaluates to softplus(-logit), :176-177),
              the whole loop runs as the fused device program (``engine.RefineEngine``): state resident in HBM, no host
              sync, the K-step program replayed as a hipGraph (``use_graph``, default on; eager fallback in-process).
+             The engine differentiates softplus(-logit) analytically: a ``func_loss`` with a CUSTOM backward or side
+             effects that merely evaluates to BCE-vs-ones must set ``refiner.force_generic = True``.
   * generic: any other callables built from ``cgs_amd.ops``; the loop below differentiates them with
              ``torch.autograd`` (each op's backward-data is a HIP kernel) and applies the fused
-             update / select kernels.
+             update / select kernels.  Several times slower at small batches (launch-bound): the first fall to this
+             path warns once with the reason.
+
+``refiner.logical_batch = b`` (extension): ``build_refiner(feature[G*b], ...)`` is G reference calls at the reference's own
+batch size b (nsgan/main.py:32: 64) in ONE launch per layer -- D's batch statistics per logical batch (nsgan/GAN.py:175), the
+probabilistic step draw per logical batch (collaborator.py:54-56), the optimizer reset per call (:86) -- instead of G
+launch-latency-bound calls.  On the generic path the G batches run one after the other (same results).
 """
 import functools
 import weakref
@@ -41,6 +50,10 @@ class Refiner():
         self.contraction = "f32"        # engine path: "f32" = exact fp32 matrix instructions (the reference's precision); "bx6" opts the big
                                         # layers into the split-bf16 contraction (include/cgs_hip.h, cgs_set_contraction)
         self.indices_batch = None       # last probabilistic draw
+        self.logical_batch = None       # b: build_refiner's rows are consecutive batches of b samples, each with the reference's per-batch
+                                        # semantics (batch statistics, index draw); None = the rows are ONE batch (the reference's call)
+        self.force_generic = False      # True: never take the engine (e.g. a func_loss with a custom backward that evaluates to BCE-vs-ones)
+        self.why_generic = None         # why the last engine detection said no (None while the engine is taken)
 
     def set_env(self, discriminator, feature_to_data, func_loss):
         self.discriminator = discriminator
@@ -80,76 +93,107 @@ class Refiner():
             return None
         return owner, func, kw
 
-    _BCE_PROBE = {}            # id(func_loss) -> (weak reference to it, verdict); an entry dies with its function
+    _BCE_PROBE = {}            # key of func_loss -> (weak reference to it, verdict); an entry dies with its function / its object
+    _WARNED = set()            # generic-path reasons already warned about (once per process and reason)
 
     @classmethod
     def _loss_is_bce_ones(cls, func_loss, device):
         """Is ``func_loss`` the unreduced cross entropy against all-ones labels, softplus(-logit) (nsgan/GAN.py:176-177)?  The
-        reference passes a local closure, so identity cannot tell: the function is evaluated ONCE on 16 fixed logits and compared
-        with softplus(-l) to 1e-6 (shape kept = no reduction).  Anything else -- another loss, a reduction, an exception -- keeps
-        the generic path, which differentiates whatever it is."""
+        reference passes a local closure, so identity cannot tell: the function is evaluated ONCE on 40 logits -- 24 evenly spaced
+        over [-40, 40] (a clipped / saturating variant deviates there) and 16 seeded random ones -- and compared with softplus(-l)
+        to 4 fp32 ulp relative + 1e-7 (shape kept = no reduction).  Anything else -- another loss, a reduction, an exception --
+        keeps the generic path, which differentiates whatever it is.  Only VALUES are compared: see ``force_generic``."""
         from ..model import GAN
         if func_loss is GAN.loss_refine:
             return True
-        hit = cls._BCE_PROBE.get(id(func_loss))
-        if hit is not None and hit[0]() is func_loss:
-            return hit[1]
+        # a bound method is a fresh object at every attribute access: key it by (object, function), and follow the object with WeakMethod
+        bound = hasattr(func_loss, "__self__") and hasattr(func_loss, "__func__")
+        key = ("m", id(func_loss.__self__), id(func_loss.__func__)) if bound else ("f", id(func_loss))
+        hit = cls._BCE_PROBE.get(key)
+        if hit is not None:
+            alive = hit[0]()
+            if alive is not None and (alive == func_loss if bound else alive is func_loss):
+                return hit[1]
         ok = False
         try:
-            l = np.linspace(-12.0, 12.0, 16, dtype=np.float32).reshape(16, 1)
+            l = np.concatenate([np.linspace(-40.0, 40.0, 24), np.random.RandomState(2019).normal(0.0, 6.0, 16)]).astype(np.float32).reshape(40, 1)
             with torch.no_grad():
                 got = func_loss(torch.from_numpy(l).to(device))
             want = np.logaddexp(0.0, -l.astype(np.float64))
-            ok = (torch.is_tensor(got) and tuple(got.shape) == (16, 1)
-                  and bool(np.abs(got.detach().double().cpu().numpy() - want).max() < 1e-6))
-        except Exception:                                   # noqa: BLE001 (a loss that cannot take a [16, 1] tensor is not this one)
+            ok = (torch.is_tensor(got) and tuple(got.shape) == (40, 1)
+                  and bool((np.abs(got.detach().double().cpu().numpy() - want) <= 4 * 2.0 ** -23 * np.abs(want) + 1e-7).all()))
+        except Exception:                                   # noqa: BLE001 (a loss that cannot take a [40, 1] tensor is not this one)
             ok = False
         try:       # (the reference makes a new closure per model build: keep no function alive, drop the verdict with it)
-            key = id(func_loss)
-            cls._BCE_PROBE[key] = (weakref.ref(func_loss, lambda _r, key=key: cls._BCE_PROBE.pop(key, None)), ok)
+            drop = lambda _r, key=key: cls._BCE_PROBE.pop(key, None)        # noqa: E731
+            cls._BCE_PROBE[key] = ((weakref.WeakMethod if bound else weakref.ref)(func_loss, drop), ok)
         except TypeError:                                   # not weak-referenceable (a builtin): probe it again next time
             pass
         return ok
 
     def _engine_owner(self):
         """The ``model.GAN`` whose layer lists ARE the three callables of ``set_env`` -- in any of the spellings the reference's
-        wiring allows (the bound methods, ``functools.partial`` of them, a BCE-vs-ones closure) -- or None."""
+        wiring allows (the bound methods, ``functools.partial`` of them, a BCE-vs-ones closure) -- or None, with the reason left
+        in ``why_generic``."""
         from ..model import GAN
+        self.why_generic = None
+
+        def no(reason):
+            self.why_generic = reason
+            return None
+        if self.force_generic:
+            return no("refiner.force_generic is set")
         d = self._unwrap(self.discriminator, ("is_training", "reuse"))
         f = self._unwrap(self.feature_to_data, ("is_training",))
-        if d is None or f is None:
-            return None
+        if d is None:
+            return no("discriminator is not a bound GAN method (or a keyword-only functools.partial of one): a lambda / free function hides the layer list")
+        if f is None:
+            return no("feature_to_data is not a bound GAN method (or a keyword-only functools.partial of one)")
         owner = d[0]
         if not isinstance(owner, GAN) or f[0] is not owner:
-            return None
+            return no("discriminator and feature_to_data do not belong to one cgs_amd.model.GAN")
         if d[1] is GAN.discriminator_refine:
             if d[2]:
-                return None
+                return no("discriminator_refine takes no keywords")
         elif d[1] is GAN.discriminator:
             if d[2].get("is_training", True) is not True:   # (GAN.discriminator's default; the engine's D runs batch-statistics bn)
-                return None
+                return no("discriminator is bound with is_training=False: the engine's D runs batch-statistics bn (nsgan/GAN.py:175)")
         else:
-            return None
+            return no("discriminator is not GAN.discriminator / GAN.discriminator_refine")
         if f[1] is not GAN.feature_to_data or f[2].get("is_training", False) is not False:
-            return None
+            return no("feature_to_data is not GAN.feature_to_data in inference mode")
         if self.optimizer.method not in ("momentum", "sgd"):
-            return None
+            return no(f"rollout_method {self.optimizer.method!r}: the engine runs momentum / sgd")
         if not self._loss_is_bce_ones(self.func_loss, owner.device):
-            return None
+            return no("func_loss does not evaluate to the unreduced cross entropy against ones, softplus(-logit) (nsgan/GAN.py:176-177)")
         return owner
 
     def _engine_for(self, batch):
         owner = self._engine_owner()
         return None if owner is None else owner.engine(batch, use_graph=self.use_graph, contraction=self.contraction)
 
+    def _groups(self, B):
+        """Number of logical batches in a call of B rows (``logical_batch``)."""
+        b = self.logical_batch
+        if not b or int(b) == B:
+            return 1
+        if int(b) <= 0 or B % int(b):
+            raise L.CgsError(f"logical_batch={b} does not divide the {B} rows handed to build_refiner")
+        return B // int(b)
+
     def build_refiner(self, fake_feature, real_batch, mode='deterministic', indices=None):
         """collaborator.py:41-88.  ``real_batch`` only feeds statistics the reference computes and never
         uses (:44-45); it is accepted and ignored.  ``indices`` (extension) replays a fixed probabilistic
-        draw; by default one is drawn per call with np.random.randint(K+1, size=B) (:54-56)."""
+        draw; by default one is drawn per call with np.random.randint(K+1, size=B) (:54-56) -- per logical batch,
+        in order, under ``logical_batch``."""
         K_steps = self.forward_steps
         B = fake_feature.shape[0]
+        G = self._groups(B)
         if mode == 'probabilistic':
-            self.indices_batch = np.asarray(indices) if indices is not None else np.random.randint(K_steps + 1, size=B)
+            if indices is not None:
+                self.indices_batch = np.asarray(indices)
+            else:       # G consecutive reference calls draw G times from the global stream
+                self.indices_batch = np.concatenate([np.random.randint(K_steps + 1, size=B // G) for _ in range(G)])
         elif mode != 'deterministic':
             raise NotImplementedError
 
@@ -158,21 +202,22 @@ class Refiner():
             self.path = "engine"
             args = (fake_feature, K_steps, self.optimizer.lambda_, self.optimizer.method, mode,
                     self.indices_batch if mode == 'probabilistic' else None, self.vmin, self.vmax)
+            eng = owner.engine(B, use_graph=self.use_graph, contraction=self.contraction, bn_groups=G)
             try:
-                out = owner.engine(B, use_graph=self.use_graph, contraction=self.contraction).refine(*args)
-            except L.CgsError:
-                raise                                             # an argument error, not a capture failure
-            except Exception as ex:                               # noqa: BLE001 (hipGraph capture refused: HIP, allocator, another thread's HIP call)
-                if not self.use_graph:
-                    raise
-                # same process, same engine code, launched kernel by kernel instead; the refiner stays eager from here on and says why
-                self.graph_fallback = f"{type(ex).__name__}: {str(ex)[:300]}"
+                out = eng.refine(*args)
+            except L.GraphCaptureError as ex:                     # the capture block refused (HIP, allocator, another thread's HIP call)
+                # same process, the SAME engine and buffers, launched kernel by kernel instead; the refiner stays eager from here on
+                # and says why.  (Argument errors, OOM or a failure of the eager warm-up are not caught: they are what they are.)
+                self.graph_fallback = str(ex)
                 self.use_graph = False
                 try:
                     torch.cuda.synchronize(fake_feature.device)
                 except Exception:                                 # noqa: BLE001
                     pass
-                out = owner.engine(B, use_graph=False, contraction=self.contraction).refine(*args)
+                eng.use_graph = False
+                owner.drop_engine(B, True, self.contraction, G)
+                owner._engines[(B, False, self.contraction, G)] = (eng, owner._engines_generation())
+                out = eng.refine(*args)
             img, d_l, o_l, o_s, o_f = out
             # the engine returns its own (cached, reused) buffers: hand out copies, so that a second build_refiner -- the
             # reference builds a deterministic and a probabilistic refiner side by side, nsgan/GAN.py:182-183 -- does not
@@ -184,6 +229,26 @@ class Refiner():
 
         # ---- generic path -----------------------------------------------------------------------
         self.path = "generic"
+        if self.why_generic not in self._WARNED:
+            self._WARNED.add(self.why_generic)
+            import warnings
+            warnings.warn("cgs_amd Refiner: this wiring runs on the generic (ops + autograd) path, several times slower than the fused "
+                          f"engine at small batches -- {self.why_generic}", RuntimeWarning, stacklevel=2)
+        if G == 1:
+            return self._build_generic(fake_feature, mode, self.indices_batch if mode == 'probabilistic' else None)
+        b = B // G
+        outs, attrs = [], {k: [] for k in ("default_logit", "optimal_logit", "optimal_step", "optimal_feature")}
+        for j in range(G):                                    # G reference calls, one after the other
+            idx = self.indices_batch[j * b:(j + 1) * b] if mode == 'probabilistic' else None
+            outs.append(self._build_generic(fake_feature[j * b:(j + 1) * b], mode, idx))
+            for k in attrs:
+                attrs[k].append(getattr(self, k))
+        for k, v in attrs.items():
+            setattr(self, k, torch.cat(v))
+        return torch.cat(outs)
+
+    def _build_generic(self, fake_feature, mode, indices):
+        K_steps = self.forward_steps
         self.current_feature = fake_feature.detach().clone().contiguous()
         self.current_logit, self.forward_grad = self.compute_forward_logits_and_grad(self.current_feature)
         self.default_logit = self.current_logit
@@ -192,7 +257,7 @@ class Refiner():
         self.optimal_step = torch.ones_like(self.optimal_logit)
         forced = None
         if mode == 'probabilistic':
-            forced = torch.as_tensor(self.indices_batch, dtype=torch.int32).to(fake_feature.device)
+            forced = torch.as_tensor(indices, dtype=torch.int32).to(fake_feature.device)
 
         for i in range(K_steps):
             self.current_feature = self.optimizer.apply_gradient(self.current_feature, self.forward_grad)

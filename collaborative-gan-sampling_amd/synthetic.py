@@ -181,7 +181,7 @@ def proposer(refiner, generate, discriminator):
         return refiner.manipulate_sample(generate())
 
     def score(batch):
-        return discriminator.sigmoid_and_saliency(batch, want_saliency=False)[0].cpu().numpy().astype(np.float64)
+        return discriminator.sigmoid_and_saliency(batch, want_saliency=False)[0].cpu().numpy()      # float32 [n, 1] like sess.run(gan.fake_sigmoid) (synthetic/main.py:232)
 
     return propose, score
 

@@ -277,6 +277,9 @@ int cgs_bce_ones_grad_rowmean(const float* logits, float* dlogits, float* logit_
  * and its input gradient dlogits[i] = dloss[i] * (sigmoid(logits[i]) - 1)  (what tf.gradients emits, collaborator.py:31). */
 int cgs_bce_ones_fwd(const float* logits, float* loss, size_t n, void* stream);
 int cgs_bce_ones_bwd(const float* dloss, const float* logits, float* dlogits, size_t n, void* stream);
+/* sigmoids[b] = mean over the P logits of sample b of sigmoid(logit): self.fake_sigmoids = tf.nn.sigmoid(self.fake_logits)
+ * (nsgan/GAN.py:154-155; P = 1 there), the discriminator score the accept / reject step reads (nsgan/GAN.py:409,422). */
+int cgs_sigmoid_rowmean(const float* logits, float* sigmoids, int B, int P, void* stream);
 /* y = min(max(x, vmin), vmax): tf.clip_by_value on the refined map (sampling/collaborator.py:69-70). */
 int cgs_clip(const float* x, float vmin, float vmax, float* y, size_t n, void* stream);
 

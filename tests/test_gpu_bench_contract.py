@@ -56,6 +56,14 @@ def test_bench_line_small_config():
         e, g = cs[arch]["engine"], cs[arch]["generic"]
         assert e["path"] == "engine" and e["hipgraph"] is True and "hipgraph_fallback" not in e and g["path"] == "generic"
         assert e["samples_per_s"] > g["samples_per_s"] > 0
+    f = cs["mnist"]["fused"]                  # the reference's batch-64 calls, G per launch through the same wiring (Refiner.logical_batch)
+    assert f["path"] == "engine" and f["logical_batch"] == 64 and f["samples_per_s"] > 2.0 * cs["mnist"]["engine"]["samples_per_s"]
+    f1 = d["f1"]                              # the evaluate fill loop (nsgan/GAN.py:384-426), measured
+    assert f1["eval_size"] == 49984 and f1["accepted_samples_per_s"] > 0 and 0 < f1["efficiency"] <= 1.0 and 0 <= f1["host_chain_share_of_wall"] < 1
+    assert len(d["lib"]["source_sha16"]) == 16
+    for arch in ("mnist", "dcgan64"):         # the D shaping iteration (nsgan/GAN.py:266-272) at batch 64, with the weight-gradient kernel's record
+        sr = d["shaping"][arch]
+        assert sr["batch"] == 64 and sr["iteration_ms"] > sr["d_step_ms"] > 0 and 0 < sr["kernels"]["wgrad_kernel"]["frac_of_fp32_matrix_peak"] <= 1.0
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
 
@@ -163,6 +171,39 @@ def test_two_ranks_on_the_one_gpu_with_the_drivers_own_workload(arch, contractio
     assert 0 < x["rank0_profile_step_wall_s"] < 5.0
     assert 0 < d["roofline"]["frac"] <= 1.0 and ("igemm_bx6" if contraction == "bx6" else "igemm_kernel") in d["roofline"]["kernel"]
     assert d["config"]["contraction"] == contraction and d["dtype"] == ("f32" if contraction == "f32" else "f32 (3xbf16 split, fp32 accumulate)")
+
+
+@pytest.mark.parametrize("arch,extra,B,G,img", [("mnist", ["--fuse", "4", "--refine-steps", "3"], 64, 4, 28 * 28), ("dcgan64", [], 1024, 1, 64 * 64 * 3)],
+                         ids=["mnist", "config4_dcgan64_8x1024"])
+def test_eight_ranks_on_the_one_gpu(arch, extra, B, G, img):
+    """world 8 has never run anywhere.  `python bench.py --gpus 8 --backend gloo --share-gpu`: eight children started
+    before any GPU call, rendezvous on the loopback, eight DISTINCT pool shards (seeds 2019 + rank), ranks_seen == 8, hipGraphs on
+    every rank, the MAX-reduce, ONE JSON line, the exit code relayed.  With the dcgan64 default this is BASELINE config 4 in its own
+    form -- 8 x 1024 samples, a 402.7 MB node-wide pool per batch in flight -- minus the transport (gloo through the host instead of
+    RCCL over xGMI) and with the eight ranks time-slicing one GPU; the pool arithmetic is asserted against the device's memory."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("RANK", None); env.pop("WORLD_SIZE", None); env.pop("MASTER_ADDR", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--backend", "gloo", "--share-gpu", "--arch", arch,
+                          "--steps", "3", "--warmup", "1", "--no-cpu-baseline"] + extra, cwd=ROOT, capture_output=True, text=True,
+                         timeout=1500, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak" and d["value"] > 0 and d["config"]["global_batch"] == 8 * B * G
+    assert "x8" in d["config"]["parallelism"] and d["config"]["hipgraph"] is True and "hipgraph_fallback" not in d["config"]
+    x = d["dist"]
+    assert x["world_size"] == 8 and x["ranks_seen"] == 8 and x["hipgraph_ranks"] == 8
+    assert x["pool_bytes"] == 8 * B * G * img * 4
+    assert x["pool_bytes_per_rank_total"] == x["pool_bytes"] * x["pool_buffers_per_rank"] < 0.5 * x["device_mem_free_before_pools"]
+    if arch == "dcgan64":
+        assert x["pool_bytes"] == 402653184 and x["pool_buffers_per_rank"] == 2          # 8 x 50.3 MB, two batches in flight
+        assert x["pool_bytes_per_rank_total"] < 0.01 * x["device_mem_total"]              # < 1 % of the 288 GB of one MI355X
+    assert x["pool_rows_match_ranks"] is True and x["pool_rank_sums_distinct"] is True
+    assert 0 < x["rank0_profile_step_wall_s"] < 60.0
+    lo, hi = x["per_rank_samples_per_s"]
+    assert 0 < lo <= hi and d["value"] <= 8.0 * hi * 1.01
+    assert len(d["lib"]["source_sha16"]) == 16 and d["lib"]["cgs_version"] >= 100 and d["lib"]["cgs_lib_override"] is False
 
 
 def test_gather_pool_on_rccl_world1_goes_through_the_collective():

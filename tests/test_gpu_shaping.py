@@ -54,7 +54,7 @@ def test_linear_weight_grad(B, Kin, Nout):
     close(K.linear_bwd_weight(x.to(dev()), dy.to(dev())), x.t() @ dy, 3e-5)
 
 
-@pytest.mark.parametrize("arch,B", [("mnist", 16), ("dcgan32", 8)])
+@pytest.mark.parametrize("arch,B", [("mnist", 16), ("dcgan32", 8), ("mnist", 64), ("dcgan64", 64)])      # (64: nsgan/main.py:32)
 def test_d_shaping_step_matches_autograd(arch, B):
     from cgs_amd.nets import to_device
     from cgs_amd.shaping import DShaper

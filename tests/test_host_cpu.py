@@ -162,6 +162,86 @@ def test_collaborate_fill_loop():
     assert len(calls) >= 2 and out2.shape == (120, 3)
 
 
+class _ScriptedProposer:
+    """A FusedProposer stand-in on the host (no GPU): images / sigmoids are fixed functions of z, so the one-batch-at-a-time loop and
+    the fused rounds see the same proposals and the comparison isolates the loop's bookkeeping and its use of the global stream."""
+    zdim = 5
+
+    def __init__(self, b, G, depth=2):
+        self.b, self.G, self.depth, self.slots, self.launched = b, G, depth, {}, 0
+
+    @staticmethod
+    def images(z):
+        return np.tanh(z[:, :3]).astype(np.float32)
+
+    @staticmethod
+    def sigmoids(z):
+        return (1.0 / (1.0 + np.exp(-z.sum(1, keepdims=True)))).astype(np.float32)
+
+    def launch(self, z, refine=True):
+        k = self.launched % self.depth
+        self.launched += 1
+        self.slots[k] = (self.images(z), self.sigmoids(z))
+        return k
+
+    def result(self, k):
+        return self.slots[k]
+
+
+@pytest.mark.parametrize("G,eval_size,min_eff", [(1, 40, None), (4, 100, None), (3, 64, 0.2), (8, 200, 0.5), (5, 37, 0.9)])
+def test_collaborate_fused_equals_the_one_batch_loop(G, eval_size, min_eff):
+    """collaborate_fused (G logical batches per device round, uniforms drawn ahead, chain run a round later) == collaborate fed one
+    batch at a time (nsgan/GAN.py:398-426): the same accepted samples, the same efficiency, and the global numpy stream left in the
+    same state -- including the efficiency cut-off branch, which stops consuming chain uniforms part-way (min_efficiency)."""
+    from cgs_amd.evaluate import collaborate, collaborate_fused
+    from cgs_amd.sampling import IndependenceSampler
+    b = 16
+    P = _ScriptedProposer(b, G)
+    base_z = np.random.RandomState(3).uniform(-1, 1, (eval_size, P.zdim)).astype(np.float32)
+    base = (P.images(base_z), P.sigmoids(base_z))
+    last = {}
+
+    def propose():
+        last["z"] = np.random.uniform(-1, 1, [b, P.zdim]).astype(np.float32)
+        return P.images(last["z"])
+
+    def score(batch):
+        return P.sigmoids(last["z"])
+    np.random.seed(11)
+    want, eff = collaborate(propose, score, IndependenceSampler(T=6), eval_size, 0.45, base=base, min_efficiency=min_eff)
+    tail = np.random.uniform(size=3)
+    np.random.seed(11)
+    st = {}
+    got, eff2 = collaborate_fused(P, IndependenceSampler(T=6), eval_size, 0.45, base=base, min_efficiency=min_eff, stats=st)
+    np.testing.assert_array_equal(got, want)
+    assert eff2 == eff
+    np.testing.assert_array_equal(np.random.uniform(size=3), tail)          # the stream was rewound to where the reference's loop leaves it
+    assert st["proposed"] % b == 0 and st["rounds"] >= 1 and st["discarded_batches"] >= 0
+
+
+def test_independence_sampler_walk_with_predrawn_uniforms():
+    """IndependenceSampler.walk(sigmoids, uniforms): uniforms drawn ahead from the global stream give the chain the per-proposal draws
+    of idpsampler.py:50, bit for bit; float32 [B, 1] scores (what sess.run returns) and float64 ones; state type kept."""
+    import copy
+    from cgs_amd.sampling import IndependenceSampler
+    rs = np.random.RandomState(2)
+    for dt in (np.float32, np.float64):
+        a = IndependenceSampler(T=5, B=1)
+        a.set_score_curr(0.5)
+        for it in range(3):
+            x, sg = rs.randn(200, 2).astype(np.float32), rs.uniform(0.02, 0.98, (200, 1)).astype(dt)
+            b = copy.deepcopy(a)
+            np.random.seed(it)
+            ya = a.sampling(x, sg)
+            np.random.seed(it)
+            yb = b.sampling(x, sg, uniforms=np.random.uniform(0, 1, size=200))
+            np.testing.assert_array_equal(ya, yb)
+            assert a.cnt_chain == b.cnt_chain and type(a.d_curr) is type(b.d_curr) and np.array_equal(a.d_curr, b.d_curr)
+    fresh = IndependenceSampler()
+    with pytest.raises(ValueError):
+        fresh.walk(np.full((4, 1), 0.5), np.zeros(4))          # an unstarted chain takes its first proposal without a draw
+
+
 def test_checkpoint_roundtrip_and_tf_name_cleaning(tmp_path):
     from cgs_amd import checkpoint as C
     P = {k: v.numpy() for k, v in N.init_params("mnist", 3, True).items()}
