@@ -9,6 +9,8 @@ static thread_local char g_err[512] = "";
 static thread_local const char* g_last_kernel = "";
 
 static thread_local double g_last_flops = 0.0;
+static thread_local int g_last_tail[2] = {0, 0};
+void cgs_note_tail(int tiles, int split) { g_last_tail[0] = tiles; g_last_tail[1] = split; }
 static thread_local int g_contraction = CGS_CONTRACTION_F32;
 int cgs_contraction_mode() { return g_contraction; }
 
@@ -30,6 +32,8 @@ int cgs_version(void) { return 105; }
 const char* cgs_last_error(void) { return g_err; }
 const char* cgs_last_kernel(void) { return g_last_kernel; }
 double cgs_last_executed_flops(void) { return g_last_flops; }
+int cgs_last_tail_tiles(void) { return g_last_tail[0]; }
+int cgs_last_tail_split(void) { return g_last_tail[1]; }
 int cgs_set_contraction(int mode) {
     if (mode < CGS_CONTRACTION_F32 || mode > CGS_CONTRACTION_BX6_ALL) return cgs_set_error(CGS_EINVAL, "set_contraction: mode %d", mode);
     g_contraction = mode;
@@ -84,6 +88,7 @@ static int run_dir(const CgsLayer& L, bool dirT, int B, const float* in, const f
                    int prepacked, hipStream_t s, const char* who, float* stat_part = nullptr, unsigned* sign_out = nullptr,
                    const unsigned* aux_signs = nullptr) {
     cgs_note_flops(0.0);
+    cgs_note_tail(0, 0);
     if (B <= 0) return cgs_set_error(CGS_EINVAL, "%s: B=%d", who, B);
     if (!in || !w || !out) return cgs_set_error(CGS_EINVAL, "%s: null tensor", who);
     if (epilogue < CGS_EPI_NONE || epilogue > CGS_EPI_TANH_BWD) return cgs_set_error(CGS_EINVAL, "%s: epilogue %d", who, epilogue);
@@ -171,7 +176,7 @@ size_t cgs_conv_ws_bytes_for(int op, int B, int H, int W, int Cin, int Cout, int
     IgemmParams p;
     p.B = B; p.stat_part = nullptr; p.sign_out = nullptr; p.sign_plane = 0;
     if (dirT) cgs_geom_T(L, p); else cgs_geom_F(L, p);
-    return packed + cgs_igemm_splitk_bytes(p);
+    return packed + cgs_igemm_slab_bytes(p);
 }
 
 int cgs_conv_family(int op, int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int sh, int sw, int epilogue,

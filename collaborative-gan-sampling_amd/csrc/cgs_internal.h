@@ -10,6 +10,7 @@ int cgs_set_error(int code, const char* fmt, ...);
 void cgs_note_kernel(const char* name);   // remembered per thread, read back by cgs_last_kernel()
 void cgs_note_flops(double executed);     // ... by cgs_last_executed_flops()
 void cgs_add_flops(double executed);      // (accumulating form: one entry point may launch several batch chunks)
+void cgs_note_tail(int tiles, int split); // ... by cgs_last_tail_tiles() / cgs_last_tail_split()
 
 #define CGS_CHECK_LAUNCH(name)                                                        \
     do {                                                                              \
@@ -81,6 +82,10 @@ struct IgemmParams {
     int stat_cls_rows;   // partial rows per parity class = 2 * m-tiles of a class (the launcher sets it)
     int vec;             // the 32-channel-chunk K order / 16-byte row gathers apply: Cred % 32 == 0 and at most 16 taps per axis
     int prio_t[3];       // progress thresholds (1/256 of the block's K tiles) at which a block steps its wave priority down; 0 = off
+    // tail split (igemm.hip, "tail split"): the LAST tail_n tiles of the launch (the end of the last class in dispatch order) are each
+    // contracted by tail_s blocks over disjoint K ranges into compact partial tiles slab[tail tile][split][BM][BN], which
+    // tail_reduce_kernel sums in a fixed order and finishes (bias, epilogue, store).  tail_s <= 1: off.
+    int tail_from, tail_n, tail_s;
     int nclasses;
     IgemmClass cls[CGS_MAX_CLASSES];
     unsigned char perm[CGS_MAX_CLASSES][256];   // per class: base pixels sorted by descending valid-tap count
@@ -101,7 +106,8 @@ size_t cgs_packed_floats(const IgemmParams& p);
 // launchers
 int cgs_pack_weights(const IgemmParams& p, const CgsLayer& L, bool dirT, const float* w, float* packed, hipStream_t s);
 int cgs_igemm_launch(const IgemmParams& p, void* slab, size_t slab_bytes, hipStream_t s);
-size_t cgs_igemm_splitk_bytes(const IgemmParams& p);   // slab bytes the launch would like (0 = no split-K)
+size_t cgs_igemm_splitk_bytes(const IgemmParams& p);   // slab bytes the launch would like for split-K (0 = no split-K)
+size_t cgs_igemm_slab_bytes(const IgemmParams& p);     // ... for split-K or the tail split: what a workspace should offer behind the packed weights
 void cgs_igemm_row_policy(IgemmParams& p, int BM);     // sets pix_major, lpt, perm (BM = rows of the launch's block tile)
 void cgs_igemm_count_flops(const IgemmParams& p, int BM);
 // split-bf16 implicit GEMM (igemm_bx6.hip): fp32 operands as three bf16 pieces each, six bf16 MFMA products, fp32 accumulate

@@ -169,8 +169,16 @@ __global__ __launch_bounds__(64 * NW, 2) void igemm_kernel(IgemmParams p) {
     // their n-tiles back to back; in the LPT order (m-tile = pixel rank * groups + image group) that also gives an XCD
     // the same image groups for every pixel, so the tap overlap between neighbouring pixels hits in its L2 too.
     const int nblk_n = p.Np / BN;
-    const unsigned wi = blockIdx.x;
+    unsigned wi = blockIdx.x;
     const int cls_i = blockIdx.y;
+    // tail split: the block ids from tail_from on (last class) are (tail tile, K slice) pairs -- tail_s consecutive ids per tile
+    int tsplit = 1, tz = 0, ttile = 0;
+    if (p.tail_s > 1 && cls_i == p.nclasses - 1 && wi >= (unsigned)p.tail_from) {
+        const unsigned t = wi - (unsigned)p.tail_from;
+        ttile = (int)(t / (unsigned)p.tail_s); tz = (int)(t - (unsigned)ttile * (unsigned)p.tail_s); tsplit = p.tail_s;
+        if (ttile >= p.tail_n) return;
+        wi = (unsigned)p.tail_from + (unsigned)ttile;
+    }
     int nb, mb;
     if (p.xcd_map) {
         const unsigned xcd = wi & 7u, q = wi >> 3;
@@ -259,6 +267,11 @@ __global__ __launch_bounds__(64 * NW, 2) void igemm_kernel(IgemmParams p) {
     if (p.splitk > 1) {
         const int cps = (nk_all + p.splitk - 1) / p.splitk;
         kbeg = blockIdx.z * cps;
+        nk = kbeg + cps < nk_all ? kbeg + cps : nk_all;
+    } else if (tsplit > 1) {
+        const int cps = (nk_all + tsplit - 1) / tsplit;
+        kbeg = tz * cps;
+        if (kbeg > nk_all) kbeg = nk_all;
         nk = kbeg + cps < nk_all ? kbeg + cps : nk_all;
     }
 
@@ -715,6 +728,21 @@ __global__ __launch_bounds__(64 * NW, 2) void igemm_kernel(IgemmParams p) {
 #undef DECODE_ROW
     __builtin_amdgcn_s_setprio(3);      // epilogue: retire quickly, the slot is what the next block (or kernel) is waiting for
     // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    if (tsplit > 1) {        // raw partial tile -> slab[tail tile][K slice][BM][BN]; tail_reduce_kernel finishes the tile
+        float* slab = p.slab + ((size_t)ttile * tsplit + tz) * (BM * BN);
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const int nl = wn * (BN / WN) + tn * 32 + j;
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ml = wm * (BM / 2) + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    slab[ml * BN + nl] = acc[tm][tn][r];
+                }
+        }
+        return;
+    }
     if (p.splitk > 1) {      // raw partial tile -> slab[class][split][m][Np]; bias / epilogue happen in the reduce kernel
         float* slab = p.slab + c.slab_off + (size_t)blockIdx.z * M * p.Np;
 #pragma unroll
@@ -880,6 +908,57 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(IgemmParams p) {
     }
 }
 
+// Tail split, second half: block = one tail tile.  out[pix(m)][n] = epi(bias[n] + sum_z slab[tile][z][m - m0][n - n0]), the K slices
+// added in index order (deterministic); the tile decode is the main kernel's (same wi -> (m-tile, n-tile), same row -> pixel map).
+__global__ __launch_bounds__(256) void tail_reduce_kernel(IgemmParams p, int BM, int BN) {
+    const int cls_i = p.nclasses - 1;
+    const IgemmClass& c = p.cls[cls_i];
+    const int RC = c.R * c.C, M = p.B * RC;
+    const int nblk_n = p.Np / BN;
+    const unsigned wi = (unsigned)p.tail_from + blockIdx.x;
+    int nb, mb;
+    if (p.xcd_map) {
+        const unsigned xcd = wi & 7u, q = wi >> 3;
+        nb = (int)(q % (unsigned)nblk_n);
+        mb = (int)(q / (unsigned)nblk_n) * 8 + (int)xcd;
+    } else {
+        nb = (int)(wi % (unsigned)nblk_n);
+        mb = (int)(wi / (unsigned)nblk_n);
+    }
+    if (mb * BM >= M) return;
+    if (p.lpt) {
+        const int gpp = p.B / BM;
+        const int rank = mb / gpp, grp = mb - rank * gpp;
+        mb = (int)p.perm[cls_i][rank] * gpp + grp;
+    }
+    const int m0 = mb * BM, n0 = nb * BN;
+    const float* slab = p.slab + (size_t)blockIdx.x * p.tail_s * (BM * BN);
+    const int qpr = BN / 4;                                   // column quads per row
+    const int cq = threadIdx.x % qpr, r0 = threadIdx.x / qpr, rstep = 256 / qpr;
+    const int n = n0 + cq * 4;
+    if (n >= p.N) return;                                     // (N % 4 == 0 on this path: the launcher checks)
+    f32x4 bias = {0.f, 0.f, 0.f, 0.f}, ea = {1.f, 1.f, 1.f, 1.f}, eb = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) bias = *(const f32x4*)(p.bias + n);
+    if (p.epilogue == CGS_EPI_AFFINE_RELU) { ea = *(const f32x4*)(p.ep_a + n); eb = *(const f32x4*)(p.ep_b + n); }
+    if (p.epilogue == CGS_EPI_RELU_BWD_AFFINE) ea = *(const f32x4*)(p.ep_a + n);
+    for (int rl = r0; rl < BM; rl += rstep) {
+        const int m = m0 + rl;
+        if (m >= M) break;
+        f32x4 a = *(const f32x4*)(slab + rl * BN + cq * 4);
+        for (int z = 1; z < p.tail_s; ++z) a += *(const f32x4*)(slab + (size_t)z * (BM * BN) + rl * BN + cq * 4);
+        int b, rem;
+        if (p.pix_major) { rem = m / p.B; b = m - rem * p.B; } else { b = m / RC; rem = m - b * RC; }
+        const int r = rem / c.C, cc = rem - r * c.C;
+        const size_t o = (size_t)((b * p.Hout + r * p.So + c.py) * p.Wout + cc * p.So + c.px) * p.N + n;
+        f32x4 aux = {0.f, 0.f, 0.f, 0.f};
+        if (p.epilogue >= CGS_EPI_RELU_BWD_AFFINE) aux = *(const f32x4*)(p.ep_aux + o);
+        f32x4 y;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] = epilogue_apply(a[e] + bias[e], p.epilogue, ea[e], eb[e], aux[e]);
+        *(f32x4*)(p.out + o) = y;
+    }
+}
+
 static long igemm_blocks(const IgemmParams& p, int BN) {
     long blocks = 0;
     for (int i = 0; i < p.nclasses; ++i) blocks += (((long)p.B * p.cls[i].R * p.cls[i].C + 127) / 128) * (p.Np / BN);
@@ -901,6 +980,138 @@ static int choose_splitk(const IgemmParams& p) {
     if (s > nk_min / 4) s = nk_min / 4;
     if (s > 64) s = 64;
     return s < 2 ? 1 : (int)s;
+}
+
+// Block tile of a launch (the row policy and the split-K decision are made): 128 x 128 or 128 x 64 (``wide``), 32- or 16-deep K tiles
+// (``deep``); ``mid`` = a mid-size grid that took the narrow tile to fill the block slots.  One function: the launcher and the
+// workspace sizing (tail split) must agree on it.
+struct IgemmTiles { bool wide, mid, deep; };
+static IgemmTiles igemm_choose_tiles(const IgemmParams& p) {
+    const bool vec = p.vec != 0;
+    int maxRC = 0;
+    for (int i = 0; i < p.nclasses; ++i) maxRC = p.cls[i].R * p.cls[i].C > maxRC ? p.cls[i].R * p.cls[i].C : maxRC;
+    bool wide = (p.Np % 128) == 0;
+    if (wide && p.lpt && maxRC <= 64) {   // uneven tiles (9..25 valid taps on grids <= 8x8) need >= 2 rounds of blocks over the 512 block slots to balance: halve BN if short
+        long blocks = 0;
+        for (int i = 0; i < p.nclasses; ++i) blocks += ((long)p.B * p.cls[i].R * p.cls[i].C / 128) * (p.Np / 128);
+        if (blocks < 1024) wide = false;
+    }
+    // K tile: 32 when every tile lies inside one tap (VEC); 16 for the generic-K gather (small K: less padding waste)
+    // (8-wave 128x128 blocks, 4 waves per SIMD: +1.3 % with one batch in flight, +-0 with two -- not kept)
+    // 16-deep K tiles (LDS 37 KB, 110 VGPRs -> FOUR blocks per CU instead of two: more independent waves to fill the matrix
+    // pipe's gaps; the epilogue stages half a wave tile at a time to fit) win 2.5-9 % when every parity class brings at
+    // least two blocks per CU, and lose up to 11 % on smaller grids, where a CU holds one block and the doubled barrier
+    // count per FLOP is all that is left of the change (measured per layer, 40 launches each, dcgan64 / dcgan32 / config 5).
+    // Mid-size grids (round 3, measured per layer on config 5's PatchGAN / up-sampling layers at batch 8, a same-session A/B of tools/layer_bench.py): a launch
+    // of 256..511 blocks of 128x128 leaves half of the 512 block slots of the 32-deep form empty (one block per CU: nobody hides
+    // its barrier and load latencies) -- as 128x64 blocks it fills them: 64x64 128<-256 85 -> 75 us, 128x128 64->128 88 -> 77 us,
+    // 32x32 256->512 302 -> 265 us (not for grids < 256 blocks, which are split over K instead: 32x32 256<-512 272 -> 295 us)
+    // (with the 32-deep K tiles: the same grids as 16-deep 128x64 blocks measured 93 / 329 us for the last two)
+    bool mid = false;
+    if (wide && vec && p.splitk == 1) {
+        const long wb = igemm_blocks(p, 128);
+        if (wb >= 256 && wb < 512) { wide = false; mid = true; }
+        // a launch that leaves norm statistics or a sign mask comes out of the one-pass epilogue and cannot be split over K: under
+        // 256 blocks of 128x128 it would leave most CUs idle (config 5's PatchGAN 4x4 128->256 layer: 128 blocks, 54 TFLOP/s) --
+        // as 128x64 blocks at least every CU gets one
+#ifndef CGS_NO_STAT_NARROW
+        else if (wb < 256 && (p.stat_part || p.sign_out)) { wide = false; mid = true; }
+#endif
+    }
+    bool deep = true;
+    if (vec && p.splitk == 1 && !mid) {
+        long min_blocks = 1L << 40, tot_blocks = 0;
+        for (int i = 0; i < p.nclasses; ++i) {
+            const long m = (long)p.B * p.cls[i].R * p.cls[i].C;
+            if (m > 0) { const long bl = (m + 127) / 128 * (p.Np / (wide ? 128 : 64)); if (bl < min_blocks) min_blocks = bl; tot_blocks += bl; }
+        }
+        deep = min_blocks < 512;        // (thresholds 256 / 512 / 1024 measured: 512 is best on dcgan64 and neutral elsewhere)
+        // ... except image-major launches whose classes TOGETHER fill the 1024 slots of the 16-deep form with even tiles (the four
+        // parity classes of config 5's transposed layers, 256 blocks each: 128x128 64<-128 102 -> 86 us, 64x64 256->128 164 -> 152 us);
+        // the pixel-major 8x8 256<-512 layer of dcgan64 (1024 very uneven blocks) stays 32-deep: 0.61 vs 0.74 ms
+        if (deep && !p.pix_major && p.nclasses > 1 && tot_blocks >= 1024) deep = false;
+    }
+#ifdef CGS_EXPERIMENT
+    if (getenv("CGS_FORCE_DEEP")) deep = atoi(getenv("CGS_FORCE_DEEP")) != 0;
+    if (getenv("CGS_FORCE_NARROW")) wide = false;
+#endif
+    return IgemmTiles{wide, mid, deep};
+}
+
+// blocks of this tile shape a CU holds at once (LDS: 2 * 128 * (TBK + 4) + 2 * TBK * BN floats + the row map; registers allow as many)
+static int igemm_blocks_per_cu(bool wide, bool deep) { return deep ? (wide ? 2 : 3) : (wide ? 4 : 5); }
+
+// Tail split.  The dispatcher deals the blocks of a launch to the CUs as slots free up; what is left for the end is a partial round:
+// r tiles on L = 256 * blocks-per-CU slots.  Two regimes lose time there (measured per layer, round 5: tools/stage_bench.py):
+//   * ONE partial round (T <= L tiles): T = a * 256 + r leaves r CUs with a + 1 tiles and the others with a -- the launch lasts
+//     a + 1 tile times although the chip holds a + r / 256 (mnist's 2048 x 6272 x 1024 linear backward: 784 tiles = 3.06 per CU,
+//     0.64 of peak where its tile runs at 0.85);
+//   * a short last round (T = q * L + r, r < L): the r tiles run a few per CU, with nobody to hide their latencies.
+// Either way the last r tiles are cut into S K-slices each (r * S ~ one block per CU resp. one full round of short blocks); the slices
+// leave raw partial tiles and tail_reduce_kernel adds them in index order (deterministic) and runs the epilogue.
+struct IgemmTail { int from, n, s; };
+static IgemmTail igemm_choose_tail(const IgemmParams& p, const IgemmTiles& t) {
+    IgemmTail none{0, 0, 0};
+    if (!p.vec || p.splitk > 1 || p.stat_part || p.sign_out || (p.N & 3)) return none;
+    // MEASURED AND NOT ADOPTED (round 5, profiles/r05_c_tail_split_ab.txt: every conv / deconv / linear stage of the four configurations
+    // with and without it, interleaved in one process): neutral within +-1 % on most launches, -6 % on the two it was built for
+    // (mnist's linear backward 254 -> 270 us with 16 tiles x 16 slices; dcgan32's 16x16 64<-128 backward-data 381 -> 406 us), +3 % on
+    // one (dcgan32 4x4 256<-512).  The partial round is not where those launches lose their time: the CUs that hold one tile more
+    // set the launch's length either way, and the K slices pay a prologue, a raw 64 KB store and the reduce pass each.  The plan stays
+    // available to experiment builds (CGS_TAIL=1) together with its parity test; product builds never split a tail.
+#ifdef CGS_EXPERIMENT
+    if (!getenv("CGS_TAIL") || atoi(getenv("CGS_TAIL")) == 0) return none;
+#else
+    return none;
+#endif
+    const int bn = t.wide ? 128 : 64, tbk = t.deep ? 32 : 16;
+    const IgemmClass& cl = p.cls[p.nclasses - 1];
+    const long Ml = (long)p.B * cl.R * cl.C;
+    if (Ml <= 0) return none;
+    const long mtl = (Ml + 127) / 128, Tl = mtl * (p.Np / bn);          // tiles of the last class
+    const long T = igemm_blocks(p, bn);
+    const long L = 256L * igemm_blocks_per_cu(t.wide, t.deep);
+    const int nk = cgs_ceil_div(cl.K, tbk);
+    long r; int S;
+    if (T < 256) return none;                                            // (under-filled grids are split over K as a whole)
+    if (T <= L) {
+        r = T % 256;
+        if (r == 0 || r > 176) return none;                              // (a remainder above ~2/3 of the CUs: the last tile time is mostly used)
+        S = (int)((256 + r / 2) / r);
+        if (S > 16) S = 16;
+    } else {
+        r = T % L;
+        if (r == 0 || r * 5 > L * 4) return none;
+        S = (int)((L + r / 2) / r);
+        if (S > 8) S = 8;
+    }
+    if (S > nk / 4) S = nk / 4;                                          // at least 4 K tiles per slice
+#ifdef CGS_EXPERIMENT
+    if (getenv("CGS_TAIL_S")) S = atoi(getenv("CGS_TAIL_S"));
+#endif
+    if (S < 2) return none;
+    if (r > Tl) r = Tl;
+    for (int i = 0; i < p.nclasses; ++i)                                 // (one id space for all classes: equal sizes only)
+        if ((long)p.B * p.cls[i].R * p.cls[i].C != Ml) return none;
+    // the tail tiles are the LAST ids of the last class in the launch's own decode (per-XCD decode: ids run over the padded m-tile count)
+    const bool xcd_map = (mtl % 8 == 0 || mtl >= 64);
+    const long ids = (xcd_map ? (mtl + 7) / 8 * 8 : mtl) * (p.Np / bn);
+    if (xcd_map && (mtl % 8) != 0) return none;                          // (padded ids decode to no tile: keep the tail dense)
+    return IgemmTail{(int)(ids - r), (int)r, S};
+}
+
+static size_t igemm_tail_bytes(const IgemmTail& tl, bool wide) { return (size_t)tl.n * tl.s * 128 * (wide ? 128 : 64) * sizeof(float); }
+
+// slab bytes behind the packed weights a launch of this geometry can use: split-K slabs (under-filled grids) or tail-split partial tiles
+size_t cgs_igemm_slab_bytes(const IgemmParams& p_in) {
+    const size_t sk = cgs_igemm_splitk_bytes(p_in);
+    if (sk) return sk;
+    IgemmParams p = p_in;
+    p.splitk = 1; p.stat_part = nullptr; p.sign_out = nullptr;
+    cgs_igemm_row_policy(p, 128);
+    const IgemmTiles t = igemm_choose_tiles(p);
+    const IgemmTail tl = igemm_choose_tail(p, t);
+    return tl.s > 1 ? igemm_tail_bytes(tl, t.wide) : 0;
 }
 
 int cgs_igemm_signs_ok(const IgemmParams& p) {
@@ -939,10 +1150,18 @@ static int launch_cfg(const IgemmParams& p, hipStream_t s) {
     const long mtiles = (maxM + BM - 1) / BM;
     IgemmParams q = p;
     q.xcd_map = (mtiles % 8 == 0 || mtiles >= 64) ? 1 : 0;        // per-XCD decode only where it keeps the 8 XCDs evenly loaded
-    const long gx = (q.xcd_map ? (mtiles + 7) / 8 * 8 : mtiles) * (p.Np / BN);
+    long gx = (q.xcd_map ? (mtiles + 7) / 8 * 8 : mtiles) * (p.Np / BN);
+    if (p.tail_s > 1) {          // the tail tiles' ids are replaced by tail_s ids each (the planner and this decode agree: igemm_choose_tail)
+        if ((long)p.tail_from + p.tail_n != gx) return cgs_set_error(CGS_EINVAL, "igemm: tail split planned for another grid (%d + %d != %ld)", p.tail_from, p.tail_n, gx);
+        gx = (long)p.tail_from + (long)p.tail_n * p.tail_s;
+    }
     if (gx > 0x7fffffffL) return cgs_set_error(CGS_EINVAL, "igemm: grid too large");
     hipLaunchKernelGGL((igemm_kernel<BM, BN, NW, VEC, TBK, PAR>), dim3((unsigned)gx, p.nclasses, p.splitk > 1 ? p.splitk : 1), dim3(64 * NW), smem, s, q);
     CGS_CHECK_LAUNCH("igemm");
+    if (p.tail_s > 1) {
+        hipLaunchKernelGGL(tail_reduce_kernel, dim3((unsigned)p.tail_n), dim3(256), 0, s, q, BM, BN);
+        CGS_CHECK_LAUNCH("tail_reduce");
+    }
     if (p.splitk > 1) {
         long tot = 0;
         for (int i = 0; i < p.nclasses; ++i) { long t = (long)p.B * p.cls[i].R * p.cls[i].C * (p.Np / 4); if (t > tot) tot = t; }
@@ -1032,6 +1251,7 @@ int cgs_igemm_row_order(const IgemmParams& p) {
 int cgs_igemm_launch(const IgemmParams& p_in, void* slab, size_t slab_bytes, hipStream_t s) {
     IgemmParams p = p_in;
     p.splitk = 1; p.slab = nullptr;
+    p.tail_from = p.tail_n = p.tail_s = 0;
     p.prio_t[0] = p.prio_t[1] = p.prio_t[2] = 0;
 #ifdef CGS_DIAG_STAMPS
     // (the stamps go to the LAST MiB of the caller's workspace: 16384 blocks x 64 bytes; tools/clock_probe.py sizes it so)
@@ -1066,46 +1286,14 @@ int cgs_igemm_launch(const IgemmParams& p_in, void* slab, size_t slab_bytes, hip
     }
     const bool vec = p.vec != 0;
     cgs_igemm_count_flops(p, 128);
-    bool wide = (p.Np % 128) == 0;
-    if (wide && p.lpt && maxRC <= 64) {   // uneven tiles (9..25 valid taps on grids <= 8x8) need >= 2 rounds of blocks over the 512 block slots to balance: halve BN if short
-        long blocks = 0;
-        for (int i = 0; i < p.nclasses; ++i) blocks += ((long)p.B * p.cls[i].R * p.cls[i].C / 128) * (p.Np / 128);
-        if (blocks < 1024) wide = false;
-    }
-    // K tile: 32 when every tile lies inside one tap (VEC); 16 for the generic-K gather (small K: less padding waste)
-    // (8-wave 128x128 blocks, 4 waves per SIMD: +1.3 % with one batch in flight, +-0 with two -- not kept)
-    // 16-deep K tiles (LDS 37 KB, 110 VGPRs -> FOUR blocks per CU instead of two: more independent waves to fill the matrix
-    // pipe's gaps; the epilogue stages half a wave tile at a time to fit) win 2.5-9 % when every parity class brings at
-    // least two blocks per CU, and lose up to 11 % on smaller grids, where a CU holds one block and the doubled barrier
-    // count per FLOP is all that is left of the change (measured per layer, 40 launches each, dcgan64 / dcgan32 / config 5).
-    // Mid-size grids (round 3, measured per layer on config 5's PatchGAN / up-sampling layers at batch 8, a same-session A/B of tools/layer_bench.py): a launch
-    // of 256..511 blocks of 128x128 leaves half of the 512 block slots of the 32-deep form empty (one block per CU: nobody hides
-    // its barrier and load latencies) -- as 128x64 blocks it fills them: 64x64 128<-256 85 -> 75 us, 128x128 64->128 88 -> 77 us,
-    // 32x32 256->512 302 -> 265 us (not for grids < 256 blocks, which are split over K instead: 32x32 256<-512 272 -> 295 us)
-    // (with the 32-deep K tiles: the same grids as 16-deep 128x64 blocks measured 93 / 329 us for the last two)
-    bool mid = false;
-    if (wide && vec && p.splitk == 1) {
-        const long wb = igemm_blocks(p, 128);
-        if (wb >= 256 && wb < 512) { wide = false; mid = true; }
-        // a launch that leaves norm statistics or a sign mask comes out of the one-pass epilogue and cannot be split over K: under
-        // 256 blocks of 128x128 it would leave most CUs idle (config 5's PatchGAN 4x4 128->256 layer: 128 blocks, 54 TFLOP/s) --
-        // as 128x64 blocks at least every CU gets one
-#ifndef CGS_NO_STAT_NARROW
-        else if (wb < 256 && (p.stat_part || p.sign_out)) { wide = false; mid = true; }
-#endif
-    }
-    bool deep = true;
-    if (vec && p.splitk == 1 && !mid) {
-        long min_blocks = 1L << 40, tot_blocks = 0;
-        for (int i = 0; i < p.nclasses; ++i) {
-            const long m = (long)p.B * p.cls[i].R * p.cls[i].C;
-            if (m > 0) { const long bl = (m + 127) / 128 * (p.Np / (wide ? 128 : 64)); if (bl < min_blocks) min_blocks = bl; tot_blocks += bl; }
+    const IgemmTiles tiles = igemm_choose_tiles(p);
+    bool wide = tiles.wide, deep = tiles.deep;
+    {   // tail split (see igemm_choose_tail), if the caller's workspace has room for the partial tiles
+        const IgemmTail tl = igemm_choose_tail(p, tiles);
+        if (tl.s > 1 && slab && slab_bytes >= igemm_tail_bytes(tl, wide)) {
+            p.tail_from = tl.from; p.tail_n = tl.n; p.tail_s = tl.s; p.slab = (float*)slab;
+            cgs_note_tail(tl.n, tl.s);
         }
-        deep = min_blocks < 512;        // (thresholds 256 / 512 / 1024 measured: 512 is best on dcgan64 and neutral elsewhere)
-        // ... except image-major launches whose classes TOGETHER fill the 1024 slots of the 16-deep form with even tiles (the four
-        // parity classes of config 5's transposed layers, 256 blocks each: 128x128 64<-128 102 -> 86 us, 64x64 256->128 164 -> 152 us);
-        // the pixel-major 8x8 256<-512 layer of dcgan64 (1024 very uneven blocks) stays 32-deep: 0.61 vs 0.74 ms
-        if (deep && !p.pix_major && p.nclasses > 1 && tot_blocks >= 1024) deep = false;
     }
     {
         // Launches whose blocks are all resident at once (one "round": <= 4 blocks per CU with the 16-deep tiles, 2 with the
@@ -1156,8 +1344,6 @@ int cgs_igemm_launch(const IgemmParams& p_in, void* slab, size_t slab_bytes, hip
 #ifdef CGS_EXPERIMENT
     if (getenv("CGS_PRIO")) sscanf(getenv("CGS_PRIO"), "%d,%d,%d", &p.prio_t[0], &p.prio_t[1], &p.prio_t[2]);
     if (getenv("CGS_NOBALANCE")) { /* diagnostic: handled by CGS_PRIO=0,0,0 for (a); (b) has no switch */ }
-    if (getenv("CGS_FORCE_DEEP")) deep = atoi(getenv("CGS_FORCE_DEEP")) != 0;
-    if (getenv("CGS_FORCE_NARROW")) wide = false;
 #endif
     if (vec && !deep && !p.tap_parity) return wide ? launch_cfg<128, 128, 4, true, 16>(p, s) : launch_cfg<128, 64, 4, true, 16>(p, s);
     if (vec && !deep && p.tap_parity) return wide ? launch_cfg<128, 128, 4, true, 16, true>(p, s) : launch_cfg<128, 64, 4, true, 16, true>(p, s);

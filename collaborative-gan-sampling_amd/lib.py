@@ -26,6 +26,8 @@ SIGNATURES = {
     "cgs_last_error": (C.c_char_p, []),
     "cgs_last_kernel": (C.c_char_p, []),
     "cgs_last_executed_flops": (C.c_double, []),
+    "cgs_last_tail_tiles": (_i, []),
+    "cgs_last_tail_split": (_i, []),
     "cgs_set_contraction": (_i, [_i]),
     "cgs_get_contraction": (_i, []),
     "cgs_conv_ws_bytes": (_z, [_i] * 7),

@@ -61,6 +61,12 @@ const char* cgs_last_kernel(void);
 /* Floating-point operations that call really issued to the matrix cores: 2 x (algorithmic multiply-accumulates minus those
  * of zero-padding taps the kernel skipped).  0 = the kernel skips nothing (executed = algorithmic).  For rooflines. */
 double cgs_last_executed_flops(void);
+/* Tail split of the calling thread's most recent conv-family call (0 / 0 = none): how many of the launch's last output tiles were
+ * contracted by several workgroups over disjoint ranges of the reduction, and by how many each -- a scheduling detail of the
+ * implicit GEMM (a launch whose tile count leaves a partial last round of workgroups; csrc/igemm.hip), reported for profiling and
+ * tests.  The partial tiles are added in a fixed order: results stay bit-identical from run to run. */
+int cgs_last_tail_tiles(void);
+int cgs_last_tail_split(void);
 
 /* Contraction arithmetic of the implicit-GEMM layers, per calling THREAD (default CGS_CONTRACTION_F32; no process-wide state).
  * F32: v_mfma_f32_32x32x2_f32 -- exact fp32 products, an fp32 fma chain over K: what tf.nn.conv2d / conv2d_transpose / matmul

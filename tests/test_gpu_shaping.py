@@ -54,24 +54,58 @@ def test_linear_weight_grad(B, Kin, Nout):
     close(K.linear_bwd_weight(x.to(dev()), dy.to(dev())), x.t() @ dy, 3e-5)
 
 
+def _oracle_d_with_lrelu_sides(arch, P, x, sides):
+    """The oracle D in float64 with every LeakyReLU taking the side (x > 0 ? 1 : leak) it is TOLD (``sides``: one bool tensor per lrelu, in
+    layer order) instead of deciding it from its own pre-activation: the exact gradient of the piecewise-linear branch the GPU's forward
+    evaluated.  At batch 64 a handful of the ~10^6 pre-activations of a D pass lie within fp32 rounding of the kink, land on the other side
+    than in the oracle's arithmetic and multiply ONE gradient entry by 5 each (measured with tools/diag_shaping2.py: 2 of 524,288 at
+    dcgan64 / batch 32, every kernel on the way within 2.4e-6 of float64) -- a measure-zero event of the function, not an error of a kernel."""
+    sides = list(sides)
+    for L in N.ARCHS[arch]["d"]:
+        if L[0] == "lrelu":
+            m = sides.pop(0)
+            x = torch.where(m, x, R.LRELU_LEAK * x)
+        else:
+            x = N.run_layers([L], x, P, "discriminator", bn_training=True)
+    assert not sides
+    return x
+
+
 @pytest.mark.parametrize("arch,B", [("mnist", 16), ("dcgan32", 8), ("mnist", 64), ("dcgan64", 64)])      # (64: nsgan/main.py:32)
 def test_d_shaping_step_matches_autograd(arch, B):
+    from cgs_amd import lib as L
+    from cgs_amd.engine import _BnTrainLrelu, _Conv, _Linear
     from cgs_amd.nets import to_device
     from cgs_amd.shaping import DShaper
     P = N.init_params(arch, 2019, True)
     real = rnd((B,) + tuple(N.ARCHS[arch]["img"]), 1).clamp(-1, 1)
     fake = torch.tanh(rnd((B,) + tuple(N.ARCHS[arch]["img"]), 2))
-    Pg = {k: (v.clone().requires_grad_(True) if k.startswith("discriminator/") and "moving" not in k else v) for k, v in P.items()}
     bce = torch.nn.functional.binary_cross_entropy_with_logits
-    lr = N.discriminator(arch, Pg, real)
-    lf = N.discriminator(arch, Pg, fake)
-    loss = bce(lr, torch.ones_like(lr)) + bce(lf, torch.zeros_like(lf))                 # nsgan/GAN.py:126-131
-    loss.backward()
     d = dev()
     Pd = to_device(P, d)
     sh = DShaper(arch, Pd, B, d, learning_rate=1e-3)
+
+    def lrelu_sides(x):        # the side every LeakyReLU took in the GPU's forward of this batch
+        sh.tape.forward(x.to(d))
+        out = []
+        for st in sh.tape.stages:
+            if (isinstance(st, (_Conv, _Linear)) and st.epi == L.EPI_LRELU) or (isinstance(st, _BnTrainLrelu) and st.leak != 1.0):
+                out.append((st.out > 0).cpu())
+        return out
+    sides_r, sides_f = lrelu_sides(real), lrelu_sides(fake)
+    # (a) float64 autograd of the branch the GPU evaluated: the tight bar, at every size
+    Pg = {k: (v.clone().double().requires_grad_(True) if k.startswith("discriminator/") and "moving" not in k else v.double()) for k, v in P.items()}
+    lr = _oracle_d_with_lrelu_sides(arch, Pg, real.double(), sides_r)
+    lf = _oracle_d_with_lrelu_sides(arch, Pg, fake.double(), sides_f)
+    loss = bce(lr, torch.ones_like(lr)) + bce(lf, torch.zeros_like(lf))                 # nsgan/GAN.py:126-131
+    loss.backward()
+    # (b) plain float32 autograd of the oracle D (its own lrelu decisions)
+    Pp = {k: (v.clone().requires_grad_(True) if k.startswith("discriminator/") and "moving" not in k else v) for k, v in P.items()}
+    lr32, lf32 = N.discriminator(arch, Pp, real), N.discriminator(arch, Pp, fake)
+    loss32 = bce(lr32, torch.ones_like(lr32)) + bce(lf32, torch.zeros_like(lf32))
+    loss32.backward()
     got_loss = sh.loss_and_grads(real.to(d), fake.to(d))
-    assert abs(got_loss.item() - loss.item()) < 1e-5 * max(1.0, abs(loss.item()))
+    assert abs(got_loss.item() - loss.item()) < 1e-5 * max(1.0, abs(loss.item())) and abs(got_loss.item() - loss32.item()) < 1e-5 * max(1.0, abs(loss32.item()))
     names = [k for k in Pg if Pg[k].requires_grad]
     checked = 0
     for st in sh.tape.stages:
@@ -79,14 +113,19 @@ def test_d_shaping_step_matches_autograd(arch, B):
             if hasattr(st, "g_" + attr):
                 p = getattr(st, attr)
                 name = [k for k in names if Pd[k] is p][0]
-                g_ref = Pg[name].grad
-                tol = 2e-4
+                g_ref, g32, got = Pg[name].grad, Pp[name].grad.double(), getattr(st, "g_" + attr).cpu().double()
                 if float(g_ref.abs().max()) < 1e-6:                    # bias in front of a batch norm: exactly-zero gradient
-                    assert float(getattr(st, "g_" + attr).abs().max()) < 1e-4
+                    assert float(got.abs().max()) < 1e-4
                 else:
-                    close(getattr(st, "g_" + attr), g_ref, tol)
+                    close(got, g_ref, 2e-5)                               # the evaluated branch, float64: every kernel of the step
+                    # against the oracle's OWN branch: identical unless a pre-activation sat on the kink (then a few entries move)
+                    l2 = float((got - g32).norm() / g32.norm())
+                    assert l2 < (2e-4 if B <= 16 else 2e-2), (name, l2)
+                    if B <= 16:
+                        close(got, g32, 2e-4)
                 checked += 1
     assert checked == len(names)
+    Pg = Pp                                                                # (the Adam check below: the plain float32 gradients, as before)
     # one Adam step (tf.train.AdamOptimizer formula) on a copy of the weights
     before = {k: Pd[k].clone() for k in names}
     sh.step(real.to(d), fake.to(d))
