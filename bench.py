@@ -59,6 +59,10 @@ TRAFFIC_JSON = os.path.join(ROOT, "profiles", "traffic.json")
 HBM_OPS = {
     "bn_train_lrelu_fwd_from_partials": ["bn_slice_sums_kernel", "bn_finalize_slices_kernel", "bn_apply_fwd_kernel"],
     "bn_train_lrelu_bwd_data": ["bn_partial_kernel<1>", "bn_finalize_kernel<1>", "bn_apply_bwd_kernel"],
+    # (the fused configurations' norms: the same kernels per group of rows; where a configuration also runs an un-fused norm -- mnist's bn
+    # behind its linear layer -- the forward kernels' per-launch averages mix the two tensor sizes: an approximation there)
+    "groupnorm_lrelu_fwd_from_partials": ["bn_finalize_kernel<0>", "bn_apply_fwd_kernel"],
+    "instnorm_lrelu_bwd_data": ["bn_partial_kernel<1>", "bn_finalize_kernel<1>", "bn_apply_bwd_kernel"],
     "refine_update": ["refine_update_kernel"],
     "linear_out1_fwd": ["linear_out1_fwd_kernel"],
     "linear_out1_bwd": ["linear_out1_bwd_kernel"],
@@ -98,10 +102,12 @@ def _traffic_table():
         return {}
 
 
-def measured_traffic(name, table=None):
+def measured_traffic(name, table=None, arch=None):
     """HBM bytes per launch of a kernel (or per call of an HBM_OPS entry point: its kernels' bytes summed) from the committed
-    PMC passes; None when unknown."""
+    PMC passes; None when unknown.  ``arch``: the table of a non-headline configuration (``_by_arch`` of traffic.json)."""
     t = _traffic_table() if table is None else table
+    if arch is not None:
+        t = t.get("_by_arch", {}).get(arch, {})
     if name in HBM_OPS:
         ks = HBM_OPS[name]
         if not all(k in t for k in ks):
@@ -111,7 +117,7 @@ def measured_traffic(name, table=None):
     return t.get(name, {}).get("hbm_bytes_per_launch_corrected")
 
 
-def profile_records(prof, prof_ms, step_ms, timing_note, with_traffic, prof_steps=1):
+def profile_records(prof, prof_ms, step_ms, timing_note, with_traffic, prof_steps=1, traffic_arch=None):
     """The per-kernel HIP-event records of one profiled step -> (roofline, kernels, hbm, executed flops of the step).
 
     roofline: the dominant kernel.  ``achieved`` / ``frac`` count what is ISSUED to the matrix cores: the implicit-GEMM
@@ -132,7 +138,7 @@ def profile_records(prof, prof_ms, step_ms, timing_note, with_traffic, prof_step
                          "nominal_tflops": round(fl / ms / 1e9, 2), "share_of_step": round(ms / prof_ms, 3)}
         if fl == 0 or name.startswith(THREE_CHANNEL) or name.startswith("linear_out1"):
             gbps = nb / ms / 1e6
-            tr = measured_traffic(name, table)
+            tr = measured_traffic(name, table, traffic_arch)
             hbm[name] = {"launches": n, "avg_us": round(1e3 * ms / n, 2), "algorithmic_bytes": int(nb / n),
                          "achieved": round(gbps, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(gbps / PEAK_HBM_GBPS, 4),
                          "traffic": tr, "traffic_over_algorithmic": round(tr / (nb / n), 3) if tr else None,
@@ -141,7 +147,7 @@ def profile_records(prof, prof_ms, step_ms, timing_note, with_traffic, prof_step
     name, (fl, evs, ex, nb) = max(mf.items(), key=lambda kv: sum(a.elapsed_time(b) for a, b in kv[1][1]))
     ms = sum(a.elapsed_time(b) for a, b in evs)
     n = len(evs)
-    tr = measured_traffic(name, table)
+    tr = measured_traffic(name, table, traffic_arch)
     peak = kernel_peak(name)
     roof = {"kernel": name, "bound": "mfma", "achieved": round(ex / ms / 1e9, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
             "frac": round(ex / ms / 1e9 / peak, 4),
@@ -354,10 +360,12 @@ def other_configs(dev, skip, want_cpu):
                      "algorithmic_tflops": round(B * G * steps / dt * nets.refine_flops_per_sample(arch, Ksteps) / 1e12, 2)}
         prof, prof_ms = profile_one_step(arch, P, B, G, Ksteps, 0.1, z[0], dev, streams[0], engine=engines[0])
         del engines
-        roof, _, hbm, _ = profile_records(prof, prof_ms, 1e3 * dt / steps, "one extra eager single-stream step", False)
-        roof.pop("note"); roof.pop("traffic"); roof.pop("traffic_over_algorithmic")
+        # (traffic: the PMC passes of THIS configuration at these very launch sizes, profiles/traffic.json `_by_arch`; null while the
+        # table belongs to other kernel sources)
+        roof, _, hbm, _ = profile_records(prof, prof_ms, 1e3 * dt / steps, "one extra eager single-stream step", True, traffic_arch=arch)
+        roof.pop("note")
         out[arch]["roofline"] = roof
-        out[arch]["hbm"] = {k: {f: v[f] for f in ("avg_us", "achieved", "frac", "share_of_step")} for k, v in hbm.items()}
+        out[arch]["hbm"] = {k: {f: v[f] for f in ("avg_us", "achieved", "frac", "share_of_step", "traffic", "traffic_over_algorithmic")} for k, v in hbm.items()}
         out[arch]["bx6"] = {"samples_per_s": round(B * G * steps / dt_bx6, 1), "dtype": DTYPE["bx6"], "contraction": "bx6",
                             "note": "opt-in (--contraction bx6): the layers with >= 64 output channels and GPU-filling grids on split-bf16 MFMA"}
         if want_cpu:

@@ -910,6 +910,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(IgemmParams p) {
 
 // Tail split, second half: block = one tail tile.  out[pix(m)][n] = epi(bias[n] + sum_z slab[tile][z][m - m0][n - n0]), the K slices
 // added in index order (deterministic); the tile decode is the main kernel's (same wi -> (m-tile, n-tile), same row -> pixel map).
+#define TAIL_RSPLIT 16
 __global__ __launch_bounds__(256) void tail_reduce_kernel(IgemmParams p, int BM, int BN) {
     const int cls_i = p.nclasses - 1;
     const IgemmClass& c = p.cls[cls_i];
@@ -934,14 +935,17 @@ __global__ __launch_bounds__(256) void tail_reduce_kernel(IgemmParams p, int BM,
     const int m0 = mb * BM, n0 = nb * BN;
     const float* slab = p.slab + (size_t)blockIdx.x * p.tail_s * (BM * BN);
     const int qpr = BN / 4;                                   // column quads per row
-    const int cq = threadIdx.x % qpr, r0 = threadIdx.x / qpr, rstep = 256 / qpr;
+    // blockIdx.y = one of TAIL_RSPLIT row chunks of the tile (a tile per block left the pass on tail_n CUs: 16 blocks adding 1 MB each)
+    const int cq = threadIdx.x % qpr, rstep = 256 / qpr;
+    const int rbeg = blockIdx.y * (BM / TAIL_RSPLIT), rend = rbeg + BM / TAIL_RSPLIT;
+    const int r0 = rbeg + threadIdx.x / qpr;
     const int n = n0 + cq * 4;
     if (n >= p.N) return;                                     // (N % 4 == 0 on this path: the launcher checks)
     f32x4 bias = {0.f, 0.f, 0.f, 0.f}, ea = {1.f, 1.f, 1.f, 1.f}, eb = {0.f, 0.f, 0.f, 0.f};
     if (p.bias) bias = *(const f32x4*)(p.bias + n);
     if (p.epilogue == CGS_EPI_AFFINE_RELU) { ea = *(const f32x4*)(p.ep_a + n); eb = *(const f32x4*)(p.ep_b + n); }
     if (p.epilogue == CGS_EPI_RELU_BWD_AFFINE) ea = *(const f32x4*)(p.ep_a + n);
-    for (int rl = r0; rl < BM; rl += rstep) {
+    for (int rl = r0; rl < rend; rl += rstep) {
         const int m = m0 + rl;
         if (m >= M) break;
         f32x4 a = *(const f32x4*)(slab + rl * BN + cq * 4);
@@ -995,6 +999,15 @@ static IgemmTiles igemm_choose_tiles(const IgemmParams& p) {
         long blocks = 0;
         for (int i = 0; i < p.nclasses; ++i) blocks += ((long)p.B * p.cls[i].R * p.cls[i].C / 128) * (p.Np / 128);
         if (blocks < 1024) wide = false;
+        // ... unless the wide tiles make ONE partial round that the tail split evens out (igemm_choose_tail: 512 < T <= 1024 tiles at four
+        // per CU, a remainder of at most 176 over whole CUs, no statistics / sign mask to leave): mnist's 7x7 128<-64 backward-data, 784
+        // tiles, 200.2 us as 1568 narrow tiles -> 183.4 us (0.72 -> 0.79 of peak; profiles/r05_e_wide_tail_ab.txt)
+        if (!wide && vec && p.splitk == 1 && !p.stat_part && !p.sign_out && (p.N & 3) == 0 && p.nclasses == 1 && blocks >= 512 && blocks <= 1024 &&
+            (blocks % 256) != 0 && (blocks % 256) <= 176)
+            wide = true;
+#ifdef CGS_EXPERIMENT
+        if (getenv("CGS_FORCE_WIDE")) wide = atoi(getenv("CGS_FORCE_WIDE")) != 0;      // (A/B: 0 = the narrow tiles, 1 = the wide ones, whatever the rules above said)
+#endif
     }
     // K tile: 32 when every tile lies inside one tap (VEC); 16 for the generic-K gather (small K: less padding waste)
     // (8-wave 128x128 blocks, 4 waves per SIMD: +1.3 % with one batch in flight, +-0 with two -- not kept)
@@ -1041,28 +1054,23 @@ static IgemmTiles igemm_choose_tiles(const IgemmParams& p) {
 // blocks of this tile shape a CU holds at once (LDS: 2 * 128 * (TBK + 4) + 2 * TBK * BN floats + the row map; registers allow as many)
 static int igemm_blocks_per_cu(bool wide, bool deep) { return deep ? (wide ? 2 : 3) : (wide ? 4 : 5); }
 
-// Tail split.  The dispatcher deals the blocks of a launch to the CUs as slots free up; what is left for the end is a partial round:
-// r tiles on L = 256 * blocks-per-CU slots.  Two regimes lose time there (measured per layer, round 5: tools/stage_bench.py):
-//   * ONE partial round (T <= L tiles): T = a * 256 + r leaves r CUs with a + 1 tiles and the others with a -- the launch lasts
-//     a + 1 tile times although the chip holds a + r / 256 (mnist's 2048 x 6272 x 1024 linear backward: 784 tiles = 3.06 per CU,
-//     0.64 of peak where its tile runs at 0.85);
-//   * a short last round (T = q * L + r, r < L): the r tiles run a few per CU, with nobody to hide their latencies.
-// Either way the last r tiles are cut into S K-slices each (r * S ~ one block per CU resp. one full round of short blocks); the slices
-// leave raw partial tiles and tail_reduce_kernel adds them in index order (deterministic) and runs the epilogue.
+// Tail split.  The dispatcher deals the workgroups of a launch to the CUs round-robin (tools/probe/place_probe.hip: workgroups b, b + 256,
+// b + 512, ... share a CU), so a launch of T = a * 256 + r tiles that fits one round of block slots leaves r CUs with a + 1 tiles and the
+// others with a: it lasts a + 1 tile times although the chip holds a + r / 256 (mnist's 2048 x 6272 x 1024 linear backward: 784 tiles of
+// 128 x 128 = 3.06 per CU ran at 0.66 of peak where its tile runs at 0.85).  The last r tiles are therefore cut into S ~ 256 / r K-slices
+// each -- one short block per CU behind its a whole tiles; the slices leave raw partial tiles, tail_reduce_kernel adds them in index order
+// (deterministic) and runs the epilogue.  Measured per stage, A/B interleaved in one process (profiles/r05_d_tail_split_ab.txt): that launch
+// 253.4 -> 209.1 us (0.66 -> 0.80 of peak).
+// Launches of SEVERAL rounds (T = q * L + r on L = 256 * blocks-per-CU slots, the short last round cut the same way) were measured too and
+// are NOT split: +2 % / +-0 / +4.5 % on three of them, -3.4 % and -1.3 % on two (dcgan32 16x16 64<-128, dcgan64 32x32 64<-128: their
+// last round already overlaps the tail of the one before, and the slices pay a prologue, a raw 32 KB store and the reduce pass each);
+// experiment builds keep that plan behind CGS_TAIL_MULTI=1.
 struct IgemmTail { int from, n, s; };
 static IgemmTail igemm_choose_tail(const IgemmParams& p, const IgemmTiles& t) {
     IgemmTail none{0, 0, 0};
     if (!p.vec || p.splitk > 1 || p.stat_part || p.sign_out || (p.N & 3)) return none;
-    // MEASURED AND NOT ADOPTED (round 5, profiles/r05_c_tail_split_ab.txt: every conv / deconv / linear stage of the four configurations
-    // with and without it, interleaved in one process): neutral within +-1 % on most launches, -6 % on the two it was built for
-    // (mnist's linear backward 254 -> 270 us with 16 tiles x 16 slices; dcgan32's 16x16 64<-128 backward-data 381 -> 406 us), +3 % on
-    // one (dcgan32 4x4 256<-512).  The partial round is not where those launches lose their time: the CUs that hold one tile more
-    // set the launch's length either way, and the K slices pay a prologue, a raw 64 KB store and the reduce pass each.  The plan stays
-    // available to experiment builds (CGS_TAIL=1) together with its parity test; product builds never split a tail.
 #ifdef CGS_EXPERIMENT
-    if (!getenv("CGS_TAIL") || atoi(getenv("CGS_TAIL")) == 0) return none;
-#else
-    return none;
+    if (getenv("CGS_TAIL") && atoi(getenv("CGS_TAIL")) == 0) return none;
 #endif
     const int bn = t.wide ? 128 : 64, tbk = t.deep ? 32 : 16;
     const IgemmClass& cl = p.cls[p.nclasses - 1];
@@ -1080,10 +1088,15 @@ static IgemmTail igemm_choose_tail(const IgemmParams& p, const IgemmTiles& t) {
         S = (int)((256 + r / 2) / r);
         if (S > 16) S = 16;
     } else {
+#ifdef CGS_EXPERIMENT
+        if (!getenv("CGS_TAIL_MULTI") || atoi(getenv("CGS_TAIL_MULTI")) == 0) return none;
         r = T % L;
         if (r == 0 || r * 5 > L * 4) return none;
         S = (int)((L + r / 2) / r);
         if (S > 8) S = 8;
+#else
+        return none;
+#endif
     }
     if (S > nk / 4) S = nk / 4;                                          // at least 4 K tiles per slice
 #ifdef CGS_EXPERIMENT
@@ -1159,7 +1172,7 @@ static int launch_cfg(const IgemmParams& p, hipStream_t s) {
     hipLaunchKernelGGL((igemm_kernel<BM, BN, NW, VEC, TBK, PAR>), dim3((unsigned)gx, p.nclasses, p.splitk > 1 ? p.splitk : 1), dim3(64 * NW), smem, s, q);
     CGS_CHECK_LAUNCH("igemm");
     if (p.tail_s > 1) {
-        hipLaunchKernelGGL(tail_reduce_kernel, dim3((unsigned)p.tail_n), dim3(256), 0, s, q, BM, BN);
+        hipLaunchKernelGGL(tail_reduce_kernel, dim3((unsigned)p.tail_n, TAIL_RSPLIT), dim3(256), 0, s, q, BM, BN);
         CGS_CHECK_LAUNCH("tail_reduce");
     }
     if (p.splitk > 1) {

@@ -88,10 +88,11 @@ def test_logical_batches_through_the_refiner_match_the_reference_golden(name, G,
         assert torch.allclose(a[1], single.default_logit, rtol=1e-4, atol=1e-5)
         same = a[3] == single.optimal_step
         ties += int((~same).sum())
-        scale = single.optimal_logit.abs().max().item()
-        assert torch.allclose(a[2][same], single.optimal_logit[same], rtol=tol, atol=0.1 * tol * scale)
-        assert torch.allclose(a[2], single.optimal_logit, rtol=0, atol=10 * tol * scale)      # (a flipped select: two near-equal candidates)
-        assert torch.allclose(a[4][same], single.optimal_feature[same], rtol=0, atol=tol * single.optimal_feature.abs().max().item())
+        # (each of the two is held to the golden / the oracle within ``tol`` of max|ref| elsewhere: against each other, twice that)
+        sm = same.cpu().numpy()
+        assert relerr(a[2].cpu().numpy()[sm], single.optimal_logit.cpu().numpy()[sm]) < 2 * tol
+        assert relerr(a[2].cpu().numpy(), single.optimal_logit.cpu().numpy()) < 20 * tol       # (a flipped select: two near-equal candidates)
+        assert relerr(a[4].cpu().numpy()[sm], single.optimal_feature.cpu().numpy()[sm]) < 2 * tol
     assert ties <= max(1, G * b // 100)                                     # a flipped select only on a numerical tie
 
 

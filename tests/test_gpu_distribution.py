@@ -30,7 +30,7 @@ def _features(arch, P, images, b):
         for i in range(0, len(images), b):
             x = images[i:i + b]
             f = N.run_layers(body, x, P, "discriminator", bn_training=True)
-            feats.append(f.mean(dim=(1, 2)) if f.dim() == 4 else f)
+            feats.append(f.mean(dim=(1, 2)) if f.dim() == 4 else f[:, :256])      # (a fixed 256-coordinate marginal of the 1024-d fc features: n >> d)
             sig.append(torch.sigmoid(N.discriminator(arch, P, x)).reshape(len(x), -1).mean(1, keepdim=True))
     return torch.cat(feats).double().numpy(), torch.cat(sig).numpy()
 
@@ -49,12 +49,13 @@ def _acceptance(images, sig, b):
     return kept / len(images), acc / len(images)
 
 
-@pytest.mark.parametrize("arch,b,G,K", [("dcgan32", 256, 8, 20), ("mnist", 64, 32, 50)])
+@pytest.mark.parametrize("arch,b,G,K", [("dcgan32", 256, 4, 20), ("mnist", 64, 16, 50)])      # (1024-sample pools: the oracle's refinement is the cost)
 def test_refined_pool_is_the_oracles_pool_in_feature_space(arch, b, G, K):
     from cgs_amd.engine import RefineEngine
     from cgs_amd.metrics import frechet_distance
     from cgs_amd.nets import to_device
     d = torch.device("cuda:0")
+    torch.set_num_threads(min(16, torch.get_num_threads()))             # (the oracle on the host: 16 threads beat 128 on these layer sizes, bench.cpu_baseline)
     P = N.init_params(arch, 2019, True)
     n = b * G
     z = torch.from_numpy(np.random.RandomState(2019).uniform(-1, 1, (n, N.ARCHS[arch]["z_dim"])).astype(np.float32))

@@ -234,11 +234,11 @@ def test_packed_weight_cache_never_drops_live_entries():
 
 @pytest.mark.parametrize("case", ["linear_bwd_mnist", "deconv_bwd_mnist", "conv_bwd_aux", "deconv_fwd_affine"])
 def test_tail_split_launches(case):
-    """Round 5 experiment (measured, not adopted; runs under an experiment build with CGS_TAIL=1): launches whose tile count leaves a partial
-    last round of workgroups contract their LAST tiles in several K slices (csrc/igemm.hip, igemm_choose_tail; partial tiles added in a fixed
-    order by tail_reduce_kernel).  The big launch must agree with
-    the same op on 64-sample pieces (small grids: the oracle-pinned paths), carry its epilogue through the reduce kernel, and be
-    bit-identical from run to run."""
+    """Round 5: a launch whose tiles fill ONE partial round of workgroup slots (T = a * 256 + r tiles) contracts its last r tiles in
+    several K slices (csrc/igemm.hip, igemm_choose_tail; partial tiles added in a fixed order by tail_reduce_kernel) -- the product plan,
+    case "linear_bwd_mnist".  The other cases are launches of several rounds, whose short last round is cut the same way only in
+    experiment builds (CGS_TAIL_MULTI=1: measured, not adopted); they skip here.  The big launch must agree with the same op on 64-sample
+    pieces (small grids: the oracle-pinned paths), carry its epilogue through the reduce kernel, and be bit-identical from run to run."""
     from cgs_amd import kernels as K, lib as L
     d = torch.device("cuda:0")
     g = torch.Generator().manual_seed(11)
@@ -265,9 +265,8 @@ def test_tail_split_launches(case):
     big = run(*args)
     tiles, split = int(lib.cgs_last_tail_tiles()), int(lib.cgs_last_tail_split())
     if tiles == 0:
-        # measured and not adopted (csrc/igemm.hip, igemm_choose_tail): product builds never split a tail; the experiment build
-        # (tools/build_exp.sh, CGS_LIB=... CGS_TAIL=1) runs the assertions below -- they passed on MI355X when the plan was on
-        pytest.skip("the tail split is an experiment-build plan (CGS_TAIL=1)")
+        assert case != "linear_bwd_mnist", "the one-round tail split is the product plan for this launch"
+        pytest.skip("launches of several rounds are split in experiment builds only (CGS_TAIL_MULTI=1)")
     assert split >= 2, (case, tiles, split, L.last_kernel())
     pieces = torch.cat([run(*[t[i:i + 64].contiguous() for t in args]) for i in range(0, B, 64)])
     assert int(lib.cgs_last_tail_tiles()) == 0                             # (the small grids do not split a tail)

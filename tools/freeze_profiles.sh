@@ -19,6 +19,9 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/bx6 -o bx6 -- python3
 LB_ITERS=3 CGS_CONTRACTION=bx6 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --output-format csv -d $O/sq_bx6 -o sq -- python3 $R/tools/layer_bench.py dcgan64 1024 > $O/sq_bx6_layer.log 2>&1
 for A in mnist dcgan32 cyclegan256; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/$A -o $A -- python3 $R/bench.py --arch $A --no-graph --streams 1 --steps 4 --warmup 1 --no-cpu-baseline --no-other-configs > $O/${A}_bench.log 2>&1
+  # counter traffic of the configuration at its bench.py launch sizes (-> traffic.json `_by_arch`, tools/make_traffic_json.py --arch)
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch_$A -o f -- python3 $R/bench.py --arch $A --no-graph --streams 1 --steps 1 --warmup 1 --no-cpu-baseline --no-other-configs > $O/fetch_$A.log 2>&1
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write_$A -o w -- python3 $R/bench.py --arch $A --no-graph --streams 1 --steps 1 --warmup 1 --no-cpu-baseline --no-other-configs > $O/write_$A.log 2>&1
 done
 cd $R
 ( time python bench.py ) > $O/bench_default.log 2>$O/bench_default.err
