@@ -1308,6 +1308,14 @@ int cgs_igemm_launch(const IgemmParams& p_in, void* slab, size_t slab_bytes, hip
             cgs_note_tail(tl.n, tl.s);
         }
     }
+#ifdef CGS_EXPERIMENT
+    if (getenv("CGS_PLAN_PRINT")) {
+        const long T_ = igemm_blocks(p, wide ? 128 : 64), L_ = 256L * igemm_blocks_per_cu(wide, deep);
+        fprintf(stderr, "[igemm plan] B=%d in %dx%dx%d -> out %dx%dx%d classes %d K0=%d: tile 128x%dx%d, T=%ld L=%ld (T%%256=%ld, T%%L=%ld) splitk=%d stats=%d signs=%d pix_major=%d lpt=%d tail=%dx%d\n",
+                p.B, p.Hin, p.Win, p.Cred, p.Hout, p.Wout, p.N, p.nclasses, p.cls[0].K, wide ? 128 : 64, deep ? 32 : 16, T_, L_, T_ % 256, T_ % L_, p.splitk,
+                p.stat_part != nullptr, p.sign_out != nullptr, p.pix_major, p.lpt, p.tail_n, p.tail_s);
+    }
+#endif
     {
         // Launches whose blocks are all resident at once (one "round": <= 4 blocks per CU with the 16-deep tiles, 2 with the
         // 32-deep ones) end when their slowest CU ends.  Two things even that out (measured per layer with in-kernel stamps,
