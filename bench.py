@@ -308,14 +308,23 @@ def profile_one_step(arch, P, B, G, Ksteps, rate, z1, dev, stream, by_layer=Fals
         with torch.cuda.stream(stream):
             eng.refine_from_z(z1, Ksteps, rate)                         # (untimed first pass: packs weights, sizes workspaces)
         torch.cuda.synchronize(dev)
-        K.PROFILE, K.PROFILE_BY_LAYER = {}, by_layer
-        tp = time.perf_counter()
-        with torch.cuda.stream(stream):
-            eng.refine_from_z(z1, Ksteps, rate)
-        torch.cuda.synchronize(dev)
-        ms = (time.perf_counter() - tp) * 1e3
-        prof, K.PROFILE = K.PROFILE, None
+        # two profiled passes, the faster one kept: a single pass now and then catches a transient (round 5: one kernel at 1.5x its
+        # usual time in ONE pass of one run, 749 -> 1109 us, nothing of it in the timed region or in the rocprofv3 table of the same
+        # box) and the roofline record of a whole run should not hang on it; the averages are those of the kept pass
+        best = None
+        for _ in range(2):
+            K.PROFILE, K.PROFILE_BY_LAYER = {}, by_layer
+            tp = time.perf_counter()
+            with torch.cuda.stream(stream):
+                eng.refine_from_z(z1, Ksteps, rate)
+            torch.cuda.synchronize(dev)
+            ms = (time.perf_counter() - tp) * 1e3
+            prof, K.PROFILE = K.PROFILE, None
+            if best is None or ms < best[1]:
+                best = (prof, ms)
+        prof, ms = best
     finally:
+        K.PROFILE = None
         eng.use_graph = was_graph
     return prof, ms
 
@@ -362,7 +371,7 @@ def other_configs(dev, skip, want_cpu):
         del engines
         # (traffic: the PMC passes of THIS configuration at these very launch sizes, profiles/traffic.json `_by_arch`; null while the
         # table belongs to other kernel sources)
-        roof, _, hbm, _ = profile_records(prof, prof_ms, 1e3 * dt / steps, "one extra eager single-stream step", True, traffic_arch=arch)
+        roof, _, hbm, _ = profile_records(prof, prof_ms, 1e3 * dt / steps, "an extra eager single-stream step (the faster of two passes)", True, traffic_arch=arch)
         roof.pop("note")
         out[arch]["roofline"] = roof
         out[arch]["hbm"] = {k: {f: v[f] for f in ("avg_us", "achieved", "frac", "share_of_step", "traffic", "traffic_over_algorithmic")} for k, v in hbm.items()}
@@ -413,7 +422,9 @@ def class_surface(dev, configs=(("dcgan64", 1024, 20, 6, 3), ("mnist", 64, 50, 2
         inputs = torch.empty((B,) + tuple(A["img"]), dtype=torch.float32, device=dev).uniform_(-1, 1)
         rec = {"batch": B, "refine_steps": Ksteps}
         for name, r, k in (("engine", refiner, steps), ("generic", generic, gsteps)):
-            with torch.no_grad():
+            import warnings
+            with torch.no_grad(), warnings.catch_warnings():
+                warnings.simplefilter("ignore", RuntimeWarning)          # (the generic leg is meant to take the generic path: no need to be told)
                 for i in range(2):                                   # first call: packs, sizes workspaces, captures the graph
                     r.build_refiner(self.input_to_feature(z[i]), inputs, mode="deterministic")
                 torch.cuda.synchronize(dev)
@@ -599,7 +610,7 @@ def bx6_line(args, P, B, G, Ksteps, z, dev, n_flight, streams, flops_per_sample)
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
     prof, prof_ms = profile_one_step(args.arch, P, B, G, Ksteps, args.rate, z[args.warmup], dev, streams[0], engine=engines[0])
-    roof, kern, _, ex_step = profile_records(prof, prof_ms, 1e3 * dt / args.steps, "one extra eager single-stream step right after this mode's timed steps",
+    roof, kern, _, ex_step = profile_records(prof, prof_ms, 1e3 * dt / args.steps, "an extra eager single-stream step right after this mode's timed steps (the faster of two passes)",
                                              args.arch == "dcgan64" and B == 1024 and G == 1)
     value = B * G * args.steps / dt
     return {"value": round(value, 2), "unit": "samples/s", "ms_per_step": round(1e3 * dt / args.steps, 3), "steps": args.steps,
@@ -821,7 +832,7 @@ def main():
         prof, prof_ms = profile_one_step(args.arch, P, B, G, Ksteps, args.rate, z[args.warmup], dev, streams[0], args.by_layer, sync,
                                          engine=engines[0])
         prof_wall_s = time.perf_counter() - t_prof       # (ranks 1.. wait in the all-gather below meanwhile: must stay far below the collective timeout)
-        prof_note = "HIP events around every launch of one extra single-stream step right after the timed region" + (" (launched eagerly; the timed region replays hipGraphs)" if args.graph else "")
+        prof_note = "HIP events around every launch of an extra single-stream step right after the timed region (the faster of two passes)" + (" (launched eagerly; the timed region replays hipGraphs)" if args.graph else "")
     dist_rec = None
     if use_dist:
         # what the collective layer really saw (all ranks take part in these two small all-gathers)

@@ -38,6 +38,36 @@ def load(path, counter):
 
 
 def table(F, W):
+    out = {}
+    for k in F:
+        if not any(s in k for s in KEEP) and "pack" not in k:
+            continue
+        f, w = sum(F[k]) / len(F[k]), sum(W.get(k, [0.0])) / max(1, len(W.get(k, [])))
+        out[k] = {"launches": len(F[k]), "FETCH_SIZE_KB_avg": round(f, 1), "WRITE_SIZE_KB_avg": round(w, 1),
+                  "hbm_bytes_per_launch_corrected": int(round((2 * f + w) * 1024))}
+    return out
+
+
+def main():
+    by_arch = {}
+    while "--arch" in sys.argv:
+        i = sys.argv.index("--arch")
+        name, fp, wp = sys.argv[i + 1:i + 4]
+        del sys.argv[i:i + 4]
+        Fa, _ = load(fp, "FETCH_SIZE")
+        Wa, _ = load(wp, "WRITE_SIZE")
+        by_arch[name] = table(Fa, Wa)
+    fpath, wpath, tag = sys.argv[1], sys.argv[2], sys.argv[3]
+    F, frows = load(fpath, "FETCH_SIZE")
+    W, wrows = load(wpath, "WRITE_SIZE")
+    if len(sys.argv) > 5:            # the split-bf16 run: only its own kernels are taken from it
+        F2, frows2 = load(sys.argv[4], "FETCH_SIZE")
+        W2, wrows2 = load(sys.argv[5], "WRITE_SIZE")
+        for k in F2:
+            if "igemm_bx6" in k:
+                F[k], W[k] = F2[k], W2.get(k, [0.0])
+        frows += [r for r in frows2 if "igemm_bx6" in r["Kernel_Name"]]
+        wrows += [r for r in wrows2 if "igemm_bx6" in r["Kernel_Name"]]
     out = table(F, W)
     sys.path.insert(0, ROOT)
     from cgs_amd.lib import source_hash
