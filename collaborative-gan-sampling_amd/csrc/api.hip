@@ -78,8 +78,14 @@ static int choose_family(const CgsLayer& L, bool dirT, int B, int epilogue, bool
     if ((patch_f || patch_t) && have_ws && ws_bytes >= cgs_conv_patch_ws_floats(L, dirT) * sizeof(float) && ws_al && rest_al)
         return CGS_FAMILY_PATCH;
     // the calling thread opted into the split-bf16 contraction (cgs_set_contraction): the calls it serves leave the fp32 kernel
-    if (g_contraction != CGS_CONTRACTION_F32 && cgs_igemm_bx6_ok(L, dirT, B, g_contraction == CGS_CONTRACTION_BX6_ALL))
-        return CGS_FAMILY_IGEMM_BX6;
+    // (... if the workspace can hold its three bf16 weight planes, 6 bytes per weight: an undersized one keeps the fp32 kernel, whose
+    // packed image it was sized for, instead of failing with EWORKSPACE -- the patch family above falls back the same way)
+    if (g_contraction != CGS_CONTRACTION_F32 && cgs_igemm_bx6_ok(L, dirT, B, g_contraction == CGS_CONTRACTION_BX6_ALL)) {
+        IgemmParams q;
+        q.B = B; q.stat_part = nullptr; q.sign_out = nullptr; q.sign_plane = 0; q.epilogue = epilogue;
+        if (dirT) cgs_geom_T(L, q); else cgs_geom_F(L, q);
+        if (have_ws && ws_bytes >= cgs_igemm_bx6_packed_bytes(q)) return CGS_FAMILY_IGEMM_BX6;
+    }
     return CGS_FAMILY_IGEMM;
 }
 

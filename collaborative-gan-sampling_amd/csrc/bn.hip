@@ -443,12 +443,21 @@ int cgs_bn_sync_bwd_apply(const float* dy, const float* x, const float* gamma, c
 }
 
 
-// bias gradient db[c] (+)= sum_m dy[m][c]: the same two-stage deterministic column reduction
-__global__ void colsum_finalize_kernel(const float* __restrict__ part, int G, int C, float* __restrict__ db, int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// bias gradient db[c] (+)= sum_m dy[m][c]: the same two-stage deterministic column reduction.  Stage 2 in bn_finalize_kernel's form
+// (8 channels x 32 slices of the G partial rows per block, each slice and then the 32 slice sums added in a fixed order in double): one
+// thread per channel walking all G rows took 63 us on average in the D-shaping step of dcgan64 (profiles/r05_i_shaping_kernel_stats.csv).
+__global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ part, int G, int C, float* __restrict__ db, int accumulate) {
+    __shared__ double red[BNF_SL][BNF_CH + 1];
+    const int cl = threadIdx.x % BNF_CH, sl = threadIdx.x / BNF_CH;
+    const int c = blockIdx.x * BNF_CH + cl;
     double a = 0.0;
-    for (int g = 0; g < G; ++g) a += (double)part[((size_t)g * 2 + 0) * C + c];
+    if (c < C)
+        for (int g = sl; g < G; g += BNF_SL) a += (double)part[((size_t)g * 2 + 0) * C + c];
+    red[sl][cl] = a;
+    __syncthreads();
+    if (sl != 0 || c >= C) return;
+    a = 0.0;
+    for (int i = 0; i < BNF_SL; ++i) a += red[i][cl];
     db[c] = accumulate ? db[c] + (float)a : (float)a;
 }
 
@@ -458,7 +467,7 @@ int cgs_bias_grad(const float* dy, float* db, int M, int C, int accumulate, void
     hipStream_t s = (hipStream_t)stream;
     const BnGeom g = bn_geom(M, C);
     hipLaunchKernelGGL(bn_partial_kernel<0>, dim3(g.G), dim3(256), 0, s, dy, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, (float*)ws, M, C, g.rows_per_block);
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cgs_ceil_div(C, 128)), dim3(128), 0, s, (const float*)ws, g.G, C, db, accumulate);
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cgs_ceil_div(C, BNF_CH)), dim3(256), 0, s, (const float*)ws, g.G, C, db, accumulate);
     CGS_CHECK_LAUNCH("bias_grad");
     return CGS_OK;
 }

@@ -487,7 +487,7 @@ class RefineEngine:
     def __init__(self, arch, params, batch_size, device=None, use_graph=False, sync_bn=None, bn_groups=1, contraction="f32"):
         self.A = ARCHS[arch] if isinstance(arch, str) else arch
         # "f32": every contraction on the exact-fp32 matrix instructions (the reference's precision; default).  "bx6": opt-in, the
-        # layers with >= 128 output channels and GPU-filling grids through split-bf16 MFMA (include/cgs_hip.h, cgs_set_contraction;
+        # layers with a multiple of 64 output channels, Cred % 32 == 0 and GPU-filling grids through split-bf16 MFMA (include/cgs_hip.h, cgs_set_contraction;
         # csrc/igemm_bx6.hip) -- same results to fp32 rounding, less matrix time.  The mode is a property of the ENGINE: it is put in
         # force at construction (the layer compilation asks the library which kernel families it will get) and at every entry point.
         if contraction not in L.CONTRACTIONS:

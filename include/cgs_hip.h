@@ -71,8 +71,9 @@ int cgs_last_tail_split(void);
 /* Contraction arithmetic of the implicit-GEMM layers, per calling THREAD (default CGS_CONTRACTION_F32; no process-wide state).
  * F32: v_mfma_f32_32x32x2_f32 -- exact fp32 products, an fp32 fma chain over K: what tf.nn.conv2d / conv2d_transpose / matmul
  *      (nsgan/ops.py:41,55,81) compute at the reference's precision.  The headline numbers are measured in this mode.
- * BX6: opt-in.  Calls with >= 128 output channels, a reduction over whole 32-channel chunks and a grid that fills the GPU run
- *      on the bf16 matrix cores instead: every fp32 operand is split exactly into three bf16 pieces and six of the nine piece
+ * BX6: opt-in.  Calls whose output channels are a multiple of 64, that reduce over whole 32-channel chunks (Cred % 32 == 0, at most
+ *      16 taps per axis) and whose grid fills the GPU (>= 256 blocks, K >= 512) -- cgs_conv_family says which -- run on the bf16 matrix
+ *      cores instead: every fp32 operand is split exactly into three bf16 pieces and six of the nine piece
  *      products are accumulated in fp32 (the dropped ones are below 3 * 2^-24 of the product): the result differs from the F32
  *      mode's by rounding errors of the size of an fp32 chain's own (igemm_bx6.hip; error analysis: DESIGN.md), in 6/16 of
  *      the matrix time.  Everything else (families, epilogues, fused statistics, layouts) is unchanged; the packed-weight

@@ -23,6 +23,8 @@ for A in mnist dcgan32 cyclegan256; do
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch_$A -o f -- python3 $R/bench.py --arch $A --no-graph --streams 1 --steps 1 --warmup 1 --no-cpu-baseline --no-other-configs > $O/fetch_$A.log 2>&1
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write_$A -o w -- python3 $R/bench.py --arch $A --no-graph --streams 1 --steps 1 --warmup 1 --no-cpu-baseline --no-other-configs > $O/write_$A.log 2>&1
 done
+# row f2: the kernel table of the D-shaping loop (weight gradients, Adam) at the reference's batch 64
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/shaping -o shaping -- python3 $R/tools/shaping_bench.py > $O/shaping_bench.log 2>&1
 cd $R
 ( time python bench.py ) > $O/bench_default.log 2>$O/bench_default.err
 tail -1 $O/bench_default.log | cut -c1-300
