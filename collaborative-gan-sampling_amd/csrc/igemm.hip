@@ -144,8 +144,9 @@ __global__ __launch_bounds__(64 * NW, 2) void igemm_kernel(IgemmParams p) {
     constexpr int BK = TBK;                       // K tile (shadows the packing granule; TBK divides it)
     constexpr int LDA = BK + 4;                   // padded A row (floats): keeps the b128 fragment reads conflict-free
     constexpr int NT = 64 * NW;                   // threads per block
-    constexpr int WN = NW / 2;                    // waves along N
-    constexpr int TM = BM / 64, TN = BN / (32 * WN);   // 32x32 MFMA tiles per wave
+    constexpr int WM = BM / 64;                   // waves along M: 2 (128-row tiles) or 4 (the tall 256 x 64 tile: four 64 x 64 wave tiles stacked)
+    constexpr int WN = NW / WM;                   // waves along N
+    constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);   // 32x32 MFMA tiles per wave
     constexpr int QPR = BK / 4;                   // k-quads per A row chunk
     constexpr int AI = BM * QPR / NT, BI = BN * QPR / NT;  // float4 staged per thread (A rows / B columns)
     constexpr int AR = NT / QPR;                  // A rows covered per staging pass
@@ -154,7 +155,7 @@ __global__ __launch_bounds__(64 * NW, 2) void igemm_kernel(IgemmParams p) {
     float* Bs = smem + 2 * BM * LDA;               // [2][BK/4][BN][4]
     constexpr int KLOOP_F = 2 * BM * LDA + 2 * BK * BN;              // floats of the K-loop double buffers
     constexpr int EH = (VEC && TBK == 16) ? 2 : 1;                    // epilogue passes (the 16-deep variant stages half a wave tile at a time)
-    constexpr int STAGE_F = NW * (BM / 2 / EH) * (BN / WN + 4);       // floats of the epilogue staging tiles
+    constexpr int STAGE_F = NW * (BM / WM / EH) * (BN / WN + 4);      // floats of the epilogue staging tiles
     int* rowpix = (int*)(smem + (KLOOP_F > STAGE_F ? KLOOP_F : STAGE_F));   // [BM] output pixel of each tile row, -1 = out of range
 
     // block id -> (m-tile, n-tile); class = blockIdx.y (heaviest class first).  Measured and rejected: computing all
@@ -566,7 +567,7 @@ __global__ __launch_bounds__(64 * NW, 2) void igemm_kernel(IgemmParams p) {
     // re-uses the fragment registers, which serialises everything again.
 #define FRAG_READ(buf_, jj_, fa_, fb_)                                                                          \
     do {                                                                                                        \
-        const float* a_ = As + (buf_) * BM * LDA + (wm * (BM / 2) + j) * LDA;                                   \
+        const float* a_ = As + (buf_) * BM * LDA + (wm * (BM / WM) + j) * LDA;                                   \
         const float* b_ = Bs + (buf_) * BK * BN + (wn * (BN / WN) + j) * 4;                                     \
         const int kq = 2 * (jj_) + h;                                                                           \
         _Pragma("unroll") for (int tm = 0; tm < TM; ++tm) fa_[tm] = *(const f32x4*)(a_ + tm * 32 * LDA + kq * 4); \
@@ -651,7 +652,7 @@ __global__ __launch_bounds__(64 * NW, 2) void igemm_kernel(IgemmParams p) {
         PRIO_STEP(cur.kt);                                                                                      \
         KIt ld = NXT_;                                  /* tile to prefetch (the current one again after the last) */ \
         if ((NXT_).kt >= nk) ld = cur;                                                                          \
-        const float* a = As + (BUF_) * BM * LDA + (wm * (BM / 2) + j) * LDA;                                    \
+        const float* a = As + (BUF_) * BM * LDA + (wm * (BM / WM) + j) * LDA;                                    \
         const float* b = Bs + (BUF_) * BK * BN + (wn * (BN / WN) + j) * 4;                                      \
         MFMA_GROUP(0);                                                                                          \
         ADDR_(ld);                                                                                              \
@@ -697,7 +698,7 @@ __global__ __launch_bounds__(64 * NW, 2) void igemm_kernel(IgemmParams p) {
 #endif
             const int kn = next_chunk(kt + 1);
             const int kl = kn < nk ? kn : kt;            // tile to prefetch (the current one again after the last)
-            const float* a = As + buf * BM * LDA + (wm * (BM / 2) + j) * LDA;
+            const float* a = As + buf * BM * LDA + (wm * (BM / WM) + j) * LDA;
             const float* b = Bs + buf * BK * BN + (wn * (BN / WN) + j) * 4;
             MFMA_GROUP(0);
             LOAD_TILE(kl);
@@ -737,7 +738,7 @@ __global__ __launch_bounds__(64 * NW, 2) void igemm_kernel(IgemmParams p) {
             for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int ml = wm * (BM / 2) + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const int ml = wm * (BM / WM) + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                     slab[ml * BN + nl] = acc[tm][tn][r];
                 }
         }
@@ -752,7 +753,7 @@ __global__ __launch_bounds__(64 * NW, 2) void igemm_kernel(IgemmParams p) {
             for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int m = m0 + wm * (BM / 2) + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const int m = m0 + wm * (BM / WM) + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                     if (m < M) slab[(size_t)m * p.Np + n] = acc[tm][tn][r];
                 }
         }
@@ -765,7 +766,7 @@ __global__ __launch_bounds__(64 * NW, 2) void igemm_kernel(IgemmParams p) {
         // the aux loads / output stores are 16 bytes per lane, 256 contiguous bytes per 16 lanes: 4x fewer
         // store (and aux load) instructions than the per-register scalar form below.
         constexpr int LDE = WTN + 4;
-        constexpr int ER = BM / 2 / EH;           // rows staged per pass
+        constexpr int ER = BM / WM / EH;          // rows staged per pass
         float* E = smem + wave * ER * LDE;        // this wave's [ER][LDE] staging tile (launch_cfg sizes the LDS for it)
         constexpr int LPR = WTN / 4;              // lanes per row (16 for 64 columns, 8 for 32)
         constexpr int RPP = 64 / LPR;             // rows per pass
@@ -793,7 +794,7 @@ __global__ __launch_bounds__(64 * NW, 2) void igemm_kernel(IgemmParams p) {
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             if (n < p.N) {
-                const int* rp = rowpix + wm * (BM / 2) + ph * ER;
+                const int* rp = rowpix + wm * (BM / WM) + ph * ER;
                 if (p.stat_part) {        // (only with CGS_EPI_NONE: the statistics are those of the stored tensor)
                     epilogue_rows<CGS_EPI_NONE, ER, RPP, LDE, true>(p, E, rp, rsub, c4, n, bias, ea, eb, &st_a, &st_b);
                 } else if (p.sign_out) {  // (N % 32 == 0: every lane of the wave is inside N, the ballots see whole rows)
@@ -825,7 +826,7 @@ __global__ __launch_bounds__(64 * NW, 2) void igemm_kernel(IgemmParams p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { st_a[e] += __shfl_xor(st_a[e], off); st_b[e] += __shfl_xor(st_b[e], off); }
             if (rsub == 0 && n < p.N) {
-                float* dst = p.stat_part + ((size_t)(cls_i * p.stat_cls_rows + (m0 / BM) * 2 + wm) * 2) * p.N + n;
+                float* dst = p.stat_part + ((size_t)(cls_i * p.stat_cls_rows + m0 / 64 + wm) * 2) * p.N + n;      // one partial row per 64 GEMM rows (= a wave's rows)
                 *(f32x4*)dst = st_a;
                 *(f32x4*)(dst + p.N) = st_b;
             }
@@ -855,7 +856,7 @@ __global__ __launch_bounds__(64 * NW, 2) void igemm_kernel(IgemmParams p) {
         for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = wm * (BM / 2) + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int row = wm * (BM / WM) + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 const int pix = rowpix[row];
                 if (pix >= 0) {
                     const size_t o = (size_t)pix * p.N + n;
@@ -963,9 +964,9 @@ __global__ __launch_bounds__(256) void tail_reduce_kernel(IgemmParams p, int BM,
     }
 }
 
-static long igemm_blocks(const IgemmParams& p, int BN) {
+static long igemm_blocks(const IgemmParams& p, int BN, int BM = 128) {
     long blocks = 0;
-    for (int i = 0; i < p.nclasses; ++i) blocks += (((long)p.B * p.cls[i].R * p.cls[i].C + 127) / 128) * (p.Np / BN);
+    for (int i = 0; i < p.nclasses; ++i) blocks += (((long)p.B * p.cls[i].R * p.cls[i].C + BM - 1) / BM) * (p.Np / BN);
     return blocks;
 }
 
@@ -989,7 +990,7 @@ static int choose_splitk(const IgemmParams& p) {
 // Block tile of a launch (the row policy and the split-K decision are made): 128 x 128 or 128 x 64 (``wide``), 32- or 16-deep K tiles
 // (``deep``); ``mid`` = a mid-size grid that took the narrow tile to fill the block slots.  One function: the launcher and the
 // workspace sizing (tail split) must agree on it.
-struct IgemmTiles { bool wide, mid, deep; };
+struct IgemmTiles { bool wide, mid, deep, tall; };
 static IgemmTiles igemm_choose_tiles(const IgemmParams& p) {
     const bool vec = p.vec != 0;
     int maxRC = 0;
@@ -1048,7 +1049,26 @@ static IgemmTiles igemm_choose_tiles(const IgemmParams& p) {
     if (getenv("CGS_FORCE_DEEP")) deep = atoi(getenv("CGS_FORCE_DEEP")) != 0;
     if (getenv("CGS_FORCE_NARROW")) wide = false;
 #endif
-    return IgemmTiles{wide, mid, deep};
+    // Tall tiles, 256 x 64 (four 64 x 64 wave tiles stacked: the per-wave shape of the 128 x 128 block), for launches to 64 output channels
+    // whose K loops are SHORT (<= 512 per class: 32 tiles of 16) and whose grid is many rounds of blocks: half the blocks, so half the
+    // prologues / epilogues per output, and every A fragment meets two B fragments.  Measured per stage (round 5, A/B interleaved in one
+    // process, profiles/r05_j_tall_tiles_ab.txt): mnist's 7x7 128->64 transposed forward 233.7 -> 214.7 us, its 14x14 64<-128
+    // backward-data 218.7 -> 206.3 us; with LONGER K loops the three resident blocks (48 KB of LDS each) hide latencies worse than five
+    // 128 x 64 ones: dcgan64's 16x16 128->64 forward 754.6 -> 783.3 us, its 32x32 64<-128 backward-data 817.2 -> 862.6 us (K = 1152): not there.
+    bool tall = false;
+    {
+        int kmax = 0;
+        for (int i = 0; i < p.nclasses; ++i) kmax = p.cls[i].K > kmax ? p.cls[i].K : kmax;
+        tall = vec && !wide && !mid && !deep && p.splitk == 1 && p.Np == 64 && (!p.pix_major || (p.B % 256) == 0) && kmax <= 512 &&
+               igemm_blocks(p, 64, 256) >= 1536;
+#ifdef CGS_EXPERIMENT
+        if (getenv("CGS_TALL")) {        // 0: never; 1: wherever the tile can run (from CGS_TALL_MIN blocks on: parity runs force it onto small launches)
+            tall = atoi(getenv("CGS_TALL")) != 0 && vec && !wide && !mid && !deep && p.splitk == 1 && p.Np == 64 && (!p.pix_major || (p.B % 256) == 0) &&
+                   igemm_blocks(p, 64, 256) >= (getenv("CGS_TALL_MIN") ? atol(getenv("CGS_TALL_MIN")) : 1536);
+        }
+#endif
+    }
+    return IgemmTiles{wide, mid, deep, tall};
 }
 
 // blocks of this tile shape a CU holds at once (LDS: 2 * 128 * (TBK + 4) + 2 * TBK * BN floats + the row map; registers allow as many)
@@ -1068,7 +1088,7 @@ static int igemm_blocks_per_cu(bool wide, bool deep) { return deep ? (wide ? 2 :
 struct IgemmTail { int from, n, s; };
 static IgemmTail igemm_choose_tail(const IgemmParams& p, const IgemmTiles& t) {
     IgemmTail none{0, 0, 0};
-    if (!p.vec || p.splitk > 1 || p.stat_part || p.sign_out || (p.N & 3)) return none;
+    if (!p.vec || p.splitk > 1 || p.stat_part || p.sign_out || (p.N & 3) || t.tall) return none;
 #ifdef CGS_EXPERIMENT
     if (getenv("CGS_TAIL") && atoi(getenv("CGS_TAIL")) == 0) return none;
 #endif
@@ -1142,7 +1162,8 @@ size_t cgs_igemm_splitk_bytes(const IgemmParams& p) {
 template <int BM, int BN, int NW, bool VEC, int TBK, bool PAR = false>
 static int launch_cfg(const IgemmParams& p, hipStream_t s) {
     constexpr int EH = (VEC && TBK == 16) ? 2 : 1;
-    constexpr size_t kloop_f = (size_t)2 * BM * (TBK + 4) + 2 * TBK * BN, stage_f = (size_t)NW * (BM / 2 / EH) * (BN / (NW / 2) + 4);
+    constexpr int WM = BM / 64;
+    constexpr size_t kloop_f = (size_t)2 * BM * (TBK + 4) + 2 * TBK * BN, stage_f = (size_t)NW * (BM / WM / EH) * (BN / (NW / WM) + 4);
     constexpr size_t smem = (kloop_f > stage_f ? kloop_f : stage_f) * sizeof(float) + BM * sizeof(int);
     static bool attr_done[64] = {};       // per device: the attribute belongs to the device's code object
     int dev_ = 0;
@@ -1298,9 +1319,11 @@ int cgs_igemm_launch(const IgemmParams& p_in, void* slab, size_t slab_bytes, hip
         }
     }
     const bool vec = p.vec != 0;
-    cgs_igemm_count_flops(p, 128);
     const IgemmTiles tiles = igemm_choose_tiles(p);
     bool wide = tiles.wide, deep = tiles.deep;
+    const bool tall = tiles.tall;
+    if (tall) cgs_igemm_row_policy(p, 256);          // (whole 256-image tiles of one pixel: lpt needs B % 256 == 0)
+    cgs_igemm_count_flops(p, tall ? 256 : 128);
     {   // tail split (see igemm_choose_tail), if the caller's workspace has room for the partial tiles
         const IgemmTail tl = igemm_choose_tail(p, tiles);
         if (tl.s > 1 && slab && slab_bytes >= igemm_tail_bytes(tl, wide)) {
@@ -1326,7 +1349,7 @@ int cgs_igemm_launch(const IgemmParams& p_in, void* slab, size_t slab_bytes, hip
         //      dealt to the CUs by greedy bin packing (heaviest tile to the least loaded CU with a free slot).
         const int bn_sel = wide ? 128 : 64, per_cu = (vec && !deep) ? 4 : 2;
         const long total_blocks = igemm_blocks(p, bn_sel);
-        const bool one_round = vec && p.splitk == 1 && total_blocks <= 256L * per_cu && total_blocks >= 256;
+        const bool one_round = vec && p.splitk == 1 && !tall && total_blocks <= 256L * per_cu && total_blocks >= 256;
         // (a) measured per layer at batch 1024: +2..4 % on every pixel-major layer (one or two rounds of 128x128 / 128x64 blocks),
         // -3 % on the transposed 128x64 layers with their 8192 short blocks (a fresh block at priority 3 starves the ones about
         // to finish), neutral elsewhere -> pixel-major launches only
@@ -1366,6 +1389,7 @@ int cgs_igemm_launch(const IgemmParams& p_in, void* slab, size_t slab_bytes, hip
     if (getenv("CGS_PRIO")) sscanf(getenv("CGS_PRIO"), "%d,%d,%d", &p.prio_t[0], &p.prio_t[1], &p.prio_t[2]);
     if (getenv("CGS_NOBALANCE")) { /* diagnostic: handled by CGS_PRIO=0,0,0 for (a); (b) has no switch */ }
 #endif
+    if (tall) return p.tap_parity ? launch_cfg<256, 64, 4, true, 16, true>(p, s) : launch_cfg<256, 64, 4, true, 16>(p, s);
     if (vec && !deep && !p.tap_parity) return wide ? launch_cfg<128, 128, 4, true, 16>(p, s) : launch_cfg<128, 64, 4, true, 16>(p, s);
     if (vec && !deep && p.tap_parity) return wide ? launch_cfg<128, 128, 4, true, 16, true>(p, s) : launch_cfg<128, 64, 4, true, 16, true>(p, s);
     if (vec && p.tap_parity) return wide ? launch_cfg<128, 128, 4, true, 32, true>(p, s) : launch_cfg<128, 64, 4, true, 32, true>(p, s);

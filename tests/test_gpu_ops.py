@@ -412,7 +412,8 @@ def test_edge_shapes_and_argument_errors():
                                   "dominant_F", "dominant_T", "dominant_T_bwd"])
 def test_many_block_grids_use_the_16_deep_variant(case):
     """Grids with >= 512 blocks per parity class run the 16-deep K-tile instantiation (four blocks per CU, half-staged
-    epilogue); every direction / tap order of it against the oracle, and that it really is the kernel that ran."""
+    epilogue; short-K launches to 64 channels its tall 256 x 64 form); every direction / tap order of it against the oracle, and that
+    it really is the kernel that ran."""
     from cgs_amd import kernels as K, lib
     d = dev()
     if case in ("conv_pixmajor", "conv_parity"):
@@ -469,7 +470,8 @@ def test_many_block_grids_use_the_16_deep_variant(case):
         got = K.deconv2d_fwd(x.to(d), w.to(d), b.to(d), (2 * H, 2 * H), 2, 2, lib.EPI_TANH)
         name = lib.last_kernel()
         close(got, torch.tanh(R.deconv2d(x, w, b, (B, 2 * H, 2 * H, Cout), 2, 2)), 2e-5)
-        assert name == "igemm_kernel<128, 64, 4, true, 16, false>", name
+        # (64 output channels, K <= 512 per parity class, 4096 tall tiles: the 256 x 64 block of round 5 -- four 64 x 64 wave tiles stacked)
+        assert name == "igemm_kernel<256, 64, 4, true, 16, false>", name
     else:
         B, H, Cin, Cout = 256, 16, 128, 32                                                         # F direction over dy [B,32,32,32] -> dx [B,16,16,128]
         x = rnd((B, H, H, Cin), 1).requires_grad_(True)
