@@ -51,7 +51,10 @@ def set_mode(m):
     for kv in m.split(","):
         if kv:
             k, v = kv.split("=")
-            os.environ[k] = v
+            if v == "-":                      # "-" unsets the variable
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
 
 
 def timed(fn):

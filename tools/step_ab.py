@@ -25,7 +25,10 @@ def set_mode(m):
     for kv in m.split(","):
         if kv:
             k, v = kv.split("=")
-            os.environ[k] = v
+            if v == "-":                      # "-" unsets the variable
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
 
 
 # (workspace sizes are asked of the library once per call signature and cached: ask them under the environment of the call, before any mode
