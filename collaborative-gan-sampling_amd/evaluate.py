@@ -218,7 +218,9 @@ def collaborate_fused(proposer, mh_sampler, eval_size, real_sigmoid_mean, base=N
         for j in range(G):
             batch = imgs[j * b:(j + 1) * b]
             if cnt_propose < max_propose:
-                rows = mh_sampler.walk(sigs[j * b:(j + 1) * b], us[j])
+                # (a private copy of the batch's scores: the chain keeps a VIEW of the score it moved to -- idpsampler.py:52 -- and the
+                # pinned buffer behind ``sigs`` is overwritten when its slot is launched again)
+                rows = mh_sampler.walk(sigs[j * b:(j + 1) * b].copy(), us[j])
                 n = len(rows)
                 if n > 0:
                     k = min(n, eval_size - cnt)

@@ -179,9 +179,14 @@ class _ScriptedProposer:
         return (1.0 / (1.0 + np.exp(-z.sum(1, keepdims=True)))).astype(np.float32)
 
     def launch(self, z, refine=True):
+        # like the device proposer, a slot's result buffers are REUSED in place by its next launch: a consumer that keeps a view of
+        # them (the MH chain keeps the score it moved to) must have copied what it keeps
         k = self.launched % self.depth
         self.launched += 1
-        self.slots[k] = (self.images(z), self.sigmoids(z))
+        if k not in self.slots:
+            self.slots[k] = (np.empty((len(z), 3), np.float32), np.empty((len(z), 1), np.float32))
+        self.slots[k][0][...] = self.images(z)
+        self.slots[k][1][...] = self.sigmoids(z)
         return k
 
     def result(self, k):
