@@ -384,18 +384,21 @@ def _gloo_worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_sharding_and_gather_over_gloo(tmp_path):
+@pytest.mark.parametrize("world", [2, 8])
+def test_sharding_and_gather_over_gloo(tmp_path, world):
+    """SURVEY 8e on CPU: one process per rank, rank-offset z shards, one all-gather of the pool, rank-major rows -- at world 2 and at the
+    world size of BASELINE configs 4 / 5 (8)."""
     import torch.multiprocessing as mp
     from cgs_amd import dist as D
-    world, out = 2, str(tmp_path / "pool.pt")
+    out = str(tmp_path / "pool.pt")
     import socket
     with socket.socket() as so:                                   # a free rendezvous port on the loopback interface
         so.bind(("127.0.0.1", 0))
         port = so.getsockname()[1]
     mp.spawn(_gloo_worker, args=(world, port, out), nprocs=world, join=True)
     img, logit, step, rows = torch.load(out)
-    assert rows.shape == (world, 2) and rows[:, 0].tolist() == [0.0, 1.0] and rows[:, 1].tolist() == [10.0, 11.0]
-    assert img.shape == (world * 3 * 4, 5, 2) and logit.shape == (24,) and step.shape == (24,)
+    assert rows.shape == (world, 2) and rows[:, 0].tolist() == [float(r) for r in range(world)] and rows[:, 1].tolist() == [10.0 + r for r in range(world)]
+    assert img.shape == (world * 3 * 4, 5, 2) and logit.shape == (world * 12,) and step.shape == (world * 12,)
     for r in range(world):
         z = torch.from_numpy(D.z_batches(r, 3, 4, 5)).reshape(12, 5)
         np.testing.assert_array_equal(img[r * 12:(r + 1) * 12, :, 0].numpy(), z.numpy())       # rank-major pool
