@@ -6,6 +6,8 @@
 // Per-channel reductions are two-stage and deterministic (no float atomics): stage 1 writes one
 // (sum_a, sum_b) partial per block and channel, stage 2 adds the partials in a fixed order in
 // double and finishes the statistics.  Run-to-run results are bit-identical.
+#include <stdlib.h>
+
 #include "cgs_internal.h"
 
 #define BN_MAX_BLOCKS CGS_BN_MAX_BLOCKS
@@ -280,6 +282,121 @@ __global__ __launch_bounds__(256) void bn_apply_bwd_kernel(const float* __restri
 }
 #undef BWD1
 
+// ------------------------------------------------------------------------------------------------
+// Small groups (<= 128 rows per group: the batch norm behind the fully connected layer of the reference's MNIST D, nsgan/GAN.py:66-67, at
+// its own batch size 64 -- one group per logical batch when several share a launch): a block = (64 channels, one group) keeps its rows in
+// registers, so statistics AND apply are ONE launch instead of three latency-bound ones (partial sums, finalize, apply: 20 us forward /
+// 37 us backward for an 8 MB tensor, round 5).  Same arithmetic as the three-kernel form: float partial sums per row lane, the 16 lanes
+// added in index order in double, var = E[x^2] - mean^2 in double; deterministic.
+// ------------------------------------------------------------------------------------------------
+#define NS_ROWS 8            // rows per thread: 16 row lanes x 8 = 128 rows
+template <bool BWD>
+__global__ __launch_bounds__(256) void norm_small_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float eps, float leak, float* __restrict__ out,
+                                                         float* __restrict__ mean_io, float* __restrict__ invstd_io, float* __restrict__ stat2,
+                                                         int M, int C) {
+    __shared__ float4 red[2][16][17];
+    __shared__ float4 bc[2][16];
+    const int tid = threadIdx.x, q = tid & 15, rl = tid >> 4;
+    const int c = blockIdx.x * 64 + q * 4;
+    const int grp = blockIdx.y;
+    const bool live = c < C;
+    const size_t base = (size_t)grp * M * C;
+    float4 xv[NS_ROWS], dv[NS_ROWS];
+    float4 sa = make_float4(0.f, 0.f, 0.f, 0.f), sb = sa;
+    float4 mu = sa, inv = sa, sc = sa, sh = sa;
+    if (BWD && live) bn_affine4(mean_io + (size_t)grp * C, invstd_io + (size_t)grp * C, gamma, beta, c, mu, inv, sc, sh);
+#pragma unroll
+    for (int i = 0; i < NS_ROWS; ++i) {
+        const int r = rl + 16 * i;
+        xv[i] = make_float4(0.f, 0.f, 0.f, 0.f); dv[i] = xv[i];
+        if (live && r < M) {
+            xv[i] = *(const float4*)(x + base + (size_t)r * C + c);
+            if (BWD) dv[i] = *(const float4*)(dy + base + (size_t)r * C + c);
+            if (!BWD) {
+                sa.x += xv[i].x; sa.y += xv[i].y; sa.z += xv[i].z; sa.w += xv[i].w;
+                sb.x = fmaf(xv[i].x, xv[i].x, sb.x); sb.y = fmaf(xv[i].y, xv[i].y, sb.y); sb.z = fmaf(xv[i].z, xv[i].z, sb.z); sb.w = fmaf(xv[i].w, xv[i].w, sb.w);
+            } else {
+#define NS1(f)                                                                          \
+                {                                                                       \
+                    const float u = fmaf(xv[i].f, sc.f, sh.f);                          \
+                    const float d = dv[i].f * (u > 0.f ? 1.f : leak);                   \
+                    dv[i].f = d;                                                        \
+                    sa.f += d; sb.f = fmaf(d, (xv[i].f - mu.f) * inv.f, sb.f);          \
+                }
+                NS1(x) NS1(y) NS1(z) NS1(w)
+#undef NS1
+            }
+        }
+    }
+    red[0][rl][q] = sa; red[1][rl][q] = sb;
+    __syncthreads();
+    if (rl == 0 && live) {
+        double a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
+        for (int g = 0; g < 16; ++g) {
+            const float4 u = red[0][g][q], v = red[1][g][q];
+            a[0] += u.x; a[1] += u.y; a[2] += u.z; a[3] += u.w;
+            b[0] += v.x; b[1] += v.y; b[2] += v.z; b[3] += v.w;
+        }
+        float o0[4], o1[4];
+        if (!BWD) {
+            for (int e = 0; e < 4; ++e) {
+                const double mean = a[e] / M;
+                double var = b[e] / M - mean * mean;
+                if (var < 0.0) var = 0.0;
+                o0[e] = (float)mean; o1[e] = (float)(1.0 / sqrt(var + (double)eps));
+            }
+            *(float4*)(mean_io + (size_t)grp * C + c) = make_float4(o0[0], o0[1], o0[2], o0[3]);
+            *(float4*)(invstd_io + (size_t)grp * C + c) = make_float4(o1[0], o1[1], o1[2], o1[3]);
+        } else {
+            for (int e = 0; e < 4; ++e) { o0[e] = (float)(a[e] / M); o1[e] = (float)(b[e] / M); }
+            if (stat2) {
+                *(float4*)(stat2 + (size_t)grp * 2 * C + c) = make_float4(o0[0], o0[1], o0[2], o0[3]);
+                *(float4*)(stat2 + (size_t)grp * 2 * C + C + c) = make_float4(o1[0], o1[1], o1[2], o1[3]);
+            }
+        }
+        bc[0][q] = make_float4(o0[0], o0[1], o0[2], o0[3]); bc[1][q] = make_float4(o1[0], o1[1], o1[2], o1[3]);
+    }
+    __syncthreads();
+    if (!live) return;
+    const float4 s0 = bc[0][q], s1 = bc[1][q];
+    if (!BWD) {      // y = lrelu(scale * x + shift): the affine exactly as bn_finalize_kernel<0> forms it
+        const float4 g = *(const float4*)(gamma + c), bt = *(const float4*)(beta + c);
+        float4 scl, shf;
+        scl.x = g.x * s1.x; scl.y = g.y * s1.y; scl.z = g.z * s1.z; scl.w = g.w * s1.w;
+        shf.x = bt.x - s0.x * scl.x; shf.y = bt.y - s0.y * scl.y; shf.z = bt.z - s0.z * scl.z; shf.w = bt.w - s0.w * scl.w;
+#pragma unroll
+        for (int i = 0; i < NS_ROWS; ++i) {
+            const int r = rl + 16 * i;
+            if (r >= M) break;
+            float4 o;
+            o.x = fmaf(xv[i].x, scl.x, shf.x); o.y = fmaf(xv[i].y, scl.y, shf.y); o.z = fmaf(xv[i].z, scl.z, shf.z); o.w = fmaf(xv[i].w, scl.w, shf.w);
+            o.x = o.x > 0.f ? o.x : leak * o.x; o.y = o.y > 0.f ? o.y : leak * o.y;
+            o.z = o.z > 0.f ? o.z : leak * o.z; o.w = o.w > 0.f ? o.w : leak * o.w;
+            *(float4*)(out + base + (size_t)r * C + c) = o;
+        }
+    } else {         // dx = gamma * invstd * (dy' - m1 - xhat * m2)
+#pragma unroll
+        for (int i = 0; i < NS_ROWS; ++i) {
+            const int r = rl + 16 * i;
+            if (r >= M) break;
+            float4 o;
+            o.x = sc.x * (dv[i].x - s0.x - (xv[i].x - mu.x) * inv.x * s1.x);
+            o.y = sc.y * (dv[i].y - s0.y - (xv[i].y - mu.y) * inv.y * s1.y);
+            o.z = sc.z * (dv[i].z - s0.z - (xv[i].z - mu.z) * inv.z * s1.z);
+            o.w = sc.w * (dv[i].w - s0.w - (xv[i].w - mu.w) * inv.w * s1.w);
+            *(float4*)(out + base + (size_t)r * C + c) = o;
+        }
+    }
+}
+#define NORM_SMALL_MAX_ROWS (16 * NS_ROWS)
+static bool norm_small_ok(int rows) {
+#ifdef CGS_EXPERIMENT
+    if (getenv("CGS_NORM_SMALL") && atoi(getenv("CGS_NORM_SMALL")) == 0) return false;      // (A/B switch of experiment builds)
+#endif
+    return rows <= NORM_SMALL_MAX_ROWS;
+}
+
 static unsigned ew_blocks(size_t n) {
     size_t b = (n + 255) / 256;
     if (b > 8192) b = 8192;
@@ -292,6 +409,11 @@ int cgs_bn_train_lrelu_fwd(const float* x, const float* gamma, const float* beta
     if (M <= 0 || C <= 0 || (C & 3)) return cgs_set_error(CGS_EINVAL, "bn fwd: M=%d C=%d (C must be a multiple of 4)", M, C);
     if (ws_bytes < cgs_bn_ws_bytes(M, C)) return cgs_set_error(CGS_EWORKSPACE, "bn fwd: workspace %zu < %zu", ws_bytes, cgs_bn_ws_bytes(M, C));
     hipStream_t s = (hipStream_t)stream;
+    if (norm_small_ok(M)) {               // one launch: statistics + apply from registers
+        hipLaunchKernelGGL(norm_small_kernel<false>, dim3(cgs_ceil_div(C, 64), 1), dim3(256), 0, s, x, nullptr, gamma, beta, eps, leak, y, mean, invstd, nullptr, M, C);
+        CGS_CHECK_LAUNCH("bn_train_lrelu_fwd");
+        return CGS_OK;
+    }
     const BnGeom g = bn_geom(M, C);
     float* part = (float*)ws;
     float* stat = part + (size_t)BN_MAX_BLOCKS * 2 * C;
@@ -333,6 +455,11 @@ int cgs_bn_train_lrelu_bwd_data(const float* dy, const float* x, const float* ga
     float* part = (float*)ws;
     float* stat = part + (size_t)BN_MAX_BLOCKS * 2 * C;           // [4][C]
     float* stat2 = stat + 4 * (size_t)C;                          // [2][C]
+    if (norm_small_ok(M)) {               // one launch (stat2 is left where cgs_bn_train_param_grads reads it)
+        hipLaunchKernelGGL(norm_small_kernel<true>, dim3(cgs_ceil_div(C, 64), 1), dim3(256), 0, s, x, dy, gamma, beta, 0.f, leak, dx, (float*)mean, (float*)invstd, stat2, M, C);
+        CGS_CHECK_LAUNCH("bn_train_lrelu_bwd_data");
+        return CGS_OK;
+    }
     hipLaunchKernelGGL(bn_partial_kernel<1>, dim3(g.G), dim3(256), 0, s, x, dy, mean, invstd, gamma, beta, leak, part, M, C, g.rows_per_block);
     hipLaunchKernelGGL(bn_finalize_kernel<1>, dim3(cgs_ceil_div(C, BNF_CH)), dim3(256), 0, s, part, g.G, M, C, nullptr, nullptr, 0.f, stat2, nullptr, nullptr);
     const size_t n4 = (size_t)M * C / 4;
@@ -501,6 +628,11 @@ int cgs_instnorm_lrelu_fwd(const float* x, const float* scale, const float* offs
     if (B <= 0 || HW <= 0 || C <= 0 || (C & 3) || B > 65535) return cgs_set_error(CGS_EINVAL, "instnorm fwd: B=%d HW=%d C=%d", B, HW, C);
     if (ws_bytes < cgs_instnorm_ws_bytes(B, HW, C)) return cgs_set_error(CGS_EWORKSPACE, "instnorm fwd: workspace %zu < %zu", ws_bytes, cgs_instnorm_ws_bytes(B, HW, C));
     hipStream_t s = (hipStream_t)stream;
+    if (norm_small_ok(HW)) {              // small groups: one launch (see norm_small_kernel)
+        hipLaunchKernelGGL(norm_small_kernel<false>, dim3(cgs_ceil_div(C, 64), B), dim3(256), 0, s, x, nullptr, scale, offset, eps, leak, y, mean, invstd, nullptr, HW, C);
+        CGS_CHECK_LAUNCH("instnorm_lrelu_fwd");
+        return CGS_OK;
+    }
     const BnGeom g = in_geom(B, HW);
     float* part = (float*)ws;
     float* stat = part + (size_t)B * g.G * 2 * C;
@@ -542,6 +674,11 @@ int cgs_instnorm_lrelu_bwd_data(const float* dy, const float* x, const float* sc
     float* part = (float*)ws;
     float* stat = part + (size_t)B * g.G * 2 * C;
     float* stat2 = stat + (size_t)B * 4 * C;
+    if (norm_small_ok(HW)) {
+        hipLaunchKernelGGL(norm_small_kernel<true>, dim3(cgs_ceil_div(C, 64), B), dim3(256), 0, s, x, dy, scale, offset, 0.f, leak, dx, (float*)mean, (float*)invstd, stat2, HW, C);
+        CGS_CHECK_LAUNCH("instnorm_lrelu_bwd_data");
+        return CGS_OK;
+    }
     hipLaunchKernelGGL(bn_partial_kernel<1>, dim3(g.G, B), dim3(256), 0, s, x, dy, mean, invstd, scale, offset, leak, part, HW, C, g.rows_per_block);
     hipLaunchKernelGGL(bn_finalize_kernel<1>, dim3(cgs_ceil_div(C, BNF_CH), B), dim3(256), 0, s, part, g.G, HW, C, nullptr, nullptr, 0.f, stat2, nullptr, nullptr);
     const size_t n4 = (size_t)B * HW * C / 4, gn4 = (size_t)HW * C / 4;

@@ -279,7 +279,8 @@ def test_linear_fwd_bwd(B, K_, N):
     close(K.linear_bwd_data(dy.to(d), w.to(d)), x.grad, 2e-5)
 
 
-@pytest.mark.parametrize("shape", [(64, 7, 7, 128), (64, 1024), (10, 16, 16, 128), (3, 4, 4, 512), (257, 8, 8, 256)])
+@pytest.mark.parametrize("shape", [(64, 7, 7, 128), (64, 1024), (10, 16, 16, 128), (3, 4, 4, 512), (257, 8, 8, 256),
+                                   (128, 256), (129, 256), (50, 40), (1, 5, 5, 8), (16, 1024)])      # (<= 128 rows: the one-launch small-group kernel)
 @pytest.mark.parametrize("leak", [0.2, 1.0])
 def test_bn_train_lrelu_fwd_bwd(shape, leak):
     from cgs_amd import kernels as K
