@@ -426,6 +426,33 @@ __global__ __launch_bounds__(256) void linear_out1_fwd_kernel(const float* __res
     }
 }
 
+// the logit head and the loss seed in one launch (the last launches of every D forward of the refinement loop, both a few microseconds of
+// latency): y[b] = x[b] . w + bias; dl[b] = sigmoid(y[b]) - 1 (d softplus(-y) / dy, the stable form of bce_rowmean_kernel); lm[b] = y[b]
+__global__ __launch_bounds__(256) void linear_out1_bce_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                              float* __restrict__ y, float* __restrict__ dl, float* __restrict__ lm, int B, int K) {
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (b >= B) return;
+    const float* row = x + (size_t)b * K;
+    float s = 0.f;
+    if ((K & 3) == 0) {
+        for (int k = lane * 4; k < K; k += 256) {
+            const float4 a = *(const float4*)(row + k), ww = *(const float4*)(w + k);
+            s = fmaf(a.x, ww.x, s); s = fmaf(a.y, ww.y, s); s = fmaf(a.z, ww.z, s); s = fmaf(a.w, ww.w, s);
+        }
+    } else {
+        for (int k = lane; k < K; k += 64) s = fmaf(row[k], w[k], s);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if (lane == 0) {
+        const float v = s + (bias ? bias[0] : 0.f);
+        y[b] = v;
+        dl[b] = v >= 0.f ? -expf(-v) / (1.f + expf(-v)) : -1.f / (1.f + expf(v));
+        lm[b] = v;
+    }
+}
+
 __global__ __launch_bounds__(256) void linear_out1_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ w,
                                                               float* __restrict__ dx, int B, int K) {
     const size_t n = (size_t)B * K;
@@ -450,6 +477,14 @@ int cgs_linear_fwd(const float* x, const float* w, const float* bias, float* y, 
     int rc = make_layer(L, 1, 1, 1, 1, 1, 1, in, 1, 1, out, "linear_fwd");
     if (rc) return rc;
     return run_dir(L, false, B, x, w, bias, y, epilogue, nullptr, nullptr, nullptr, ws, ws_bytes, ws_prepacked, (hipStream_t)stream, "linear_fwd");
+}
+
+int cgs_linear_out1_bce(const float* x, const float* w, const float* bias, float* logits, float* dlogits, float* logit_mean, int B, int in,
+                        void* stream) {
+    if (B <= 0 || in <= 0 || !x || !w || !logits || !dlogits || !logit_mean) return cgs_set_error(CGS_EINVAL, "linear_out1_bce: bad argument");
+    hipLaunchKernelGGL(linear_out1_bce_kernel, dim3(cgs_ceil_div(B, 4)), dim3(256), 0, (hipStream_t)stream, x, w, bias, logits, dlogits, logit_mean, B, in);
+    CGS_CHECK_LAUNCH("linear_out1_bce");
+    return CGS_OK;
 }
 
 int cgs_linear_bwd_data(const float* dy, const float* w, float* dx, int B, int in, int out, void* ws, size_t ws_bytes,

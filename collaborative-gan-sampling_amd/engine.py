@@ -631,7 +631,15 @@ class RefineEngine:
         return K.sigmoid_rowmean(self.d.forward(images), out=out)
 
     def forward_logits(self, theta, logit_out):
-        logits = self.d.forward(self.g_tail.forward(theta))
+        x = self.g_tail.forward(theta)
+        head = self.d.stages[-1]
+        if isinstance(head, _Linear) and head.w.shape[1] == 1 and head.epi == L.EPI_NONE:
+            # D ends in the one-logit linear head (nsgan/GAN.py:68): head + loss seed + per-sample mean logit in ONE launch
+            for st in self.d.stages[:-1]:
+                x = st.fwd(x)
+            head.x_in = x
+            return K.linear_out1_bce(x, head.w, head.b, head.out, self.dlogits, logit_out)
+        logits = self.d.forward(x)
         K.bce_ones_grad_rowmean(logits, self.dlogits, logit_out)
         return logits
 
@@ -662,8 +670,7 @@ class RefineEngine:
             self.forward_logits(th, self.logit)                     # the K-th gradient is never formed (Q4)
             # collaborator.py:88 renders G_tail(best_theta) once more at the end; the very same image was already
             # rendered in the step that selected it, so it is kept by the same row-select instead (bit-identical)
-            K.refine_select_rows(render, self.logit, forced, i, self.images, self.best_logit)
-            K.refine_select(th, self.logit, forced, i, self.best_theta, self.best_logit, self.best_step)
+            K.refine_select2(render, self.images, th, self.best_theta, self.logit, forced, i, self.best_logit, self.best_step)
 
     @_entry
     def refine(self, feature0, steps, rate, method="momentum", mode="deterministic", indices=None,

@@ -662,6 +662,24 @@ def refine_select(theta, logit, forced, step_index, best_theta, best_logit, best
            _ptr(best_step), B, theta.numel() // B, _stream())
 
 
+def refine_select2(rows, best_rows, theta, best_theta, logit, forced, step_index, best_logit, best_step):
+    """refine_select_rows(rows) + refine_select(theta) with the two row copies in one launch."""
+    B = theta.shape[0]
+    L.call("cgs_refine_select2", _ptr(rows), _ptr(best_rows), rows.numel() // B, _ptr(theta), _ptr(best_theta), theta.numel() // B, _ptr(logit),
+           _ptr(forced), step_index, _ptr(best_logit), _ptr(best_step), B, _stream())
+
+
+def linear_out1_bce(x, w, bias, logits, dlogits, logit_mean):
+    """The one-logit head of D + the loss seed (linear_fwd(N = 1) then bce_ones_grad_rowmean) in one launch."""
+    _chk(x, "x"); _chk(w, "w")
+    B, K = x.shape
+    pr = _Prof(2.0 * B * K, "", _nb(x, w, logits), op="linear_out1_fwd") if PROFILE is not None else None
+    L.call("cgs_linear_out1_bce", _ptr(x), _ptr(w), _ptr(bias), _ptr(logits), _ptr(dlogits), _ptr(logit_mean), B, K, _stream())
+    if pr is not None:
+        pr.done()
+    return logits
+
+
 def refine_select_rows(src, logit, forced, step_index, dst, best_logit):
     """Copy the rows of ``src`` whose sample is selected at this step into ``dst`` (predicate of refine_select;
     call before it, which updates best_logit)."""

@@ -199,6 +199,12 @@ int cgs_deconv2d_nhwc_bwd_data_signs(const float* dy, const float* w, float* dx,
  * Replaces tf.matmul + bias at nsgan/ops.py:81-83.  ws as for conv (op CGS_CONV_FWD, kh=kw=1). */
 int cgs_linear_fwd(const float* x, const float* w, const float* bias, float* y, int B, int in, int out,
                    int epilogue, void* ws, size_t ws_bytes, int ws_prepacked, void* stream);
+/* The single-logit head of D (nsgan/GAN.py:68: linear(net, 1)) and the loss seed of the refinement loop in one launch:
+ * logits[b] = x[b,:] . w + bias; dlogits[b] = sigmoid(logits[b]) - 1 (nsgan/GAN.py:176-177 through tf.gradients,
+ * sampling/collaborator.py:31); logit_mean[b] = logits[b] (collaborator.py:34-37 with one logit per sample).
+ * = cgs_linear_fwd(out = 1) followed by cgs_bce_ones_grad_rowmean(P = 1), bit for bit. */
+int cgs_linear_out1_bce(const float* x, const float* w, const float* bias, float* logits, float* dlogits, float* logit_mean, int B, int in,
+                        void* stream);
 /* linear backward-data: dx[B,in] = dy[B,out] @ w^T   (ws: op CGS_CONV_BWD_DATA, kh=kw=1). */
 int cgs_linear_bwd_data(const float* dy, const float* w, float* dx, int B, int in, int out,
                         void* ws, size_t ws_bytes, int ws_prepacked, void* stream);
@@ -302,6 +308,10 @@ int cgs_refine_update(float* theta, float* m, const float* g, float rate, float 
  * forced = the probabilistic-mode index vector (int32, device) or NULL for deterministic mode. */
 int cgs_refine_select(const float* theta, const float* logit, const int32_t* forced, int step_index,
                       float* best_theta, float* best_logit, float* best_step, int B, int F, void* stream);
+/* cgs_refine_select_rows(rows -> best_rows) followed by cgs_refine_select(theta -> best_theta, scalars) with the two row copies in one
+ * launch: the per-step bookkeeping of the engine (the rendered image follows the selection of the refined map). */
+int cgs_refine_select2(const float* rows, float* best_rows, int Frows, const float* theta, float* best_theta, int F, const float* logit,
+                       const int32_t* forced, int step_index, float* best_logit, float* best_step, int B, void* stream);
 /* The row copy of cgs_refine_select alone (same predicate, best_logit is only read): lets a second per-sample
  * tensor -- e.g. the rendered image of the step -- follow the same selection.  Call it BEFORE cgs_refine_select. */
 int cgs_refine_select_rows(const float* src, const float* logit, const int32_t* forced, int step_index, float* dst,

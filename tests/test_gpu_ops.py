@@ -753,3 +753,28 @@ def test_deep_reduction_small_n_conv(B, H, W, Cin, N, k, s):
         close(got, want, 2e-5 * (max(1.0, lin.abs().max().item()) if epi == lib.EPI_TANH else 1.0))
     got = K.conv2d_fwd(x.to(d), w.to(d), None, s, s)
     close(got, R.conv2d(x, w, torch.zeros(N), s, s), 2e-5)
+
+
+def test_fused_logit_head_and_row_selects_equal_their_parts():
+    """Round 5 launch-count fusions of the loop's per-step bookkeeping: cgs_linear_out1_bce = linear_fwd(N = 1) + bce_ones_grad_rowmean,
+    cgs_refine_select2 = refine_select_rows + refine_select -- bit for bit, deterministic and probabilistic mode."""
+    from cgs_amd import kernels as K
+    d = dev()
+    B, Kin = 77, 1024
+    x, w, b = rnd((B, Kin), 1).to(d), rnd((Kin, 1), 2, 0.1).to(d), rnd((1,), 3).to(d)
+    y = K.linear_fwd(x, w, b)
+    dl, lm = K.bce_ones_grad_rowmean(y)
+    y2, dl2, lm2 = torch.empty_like(y), torch.empty_like(y), torch.empty(B, device=d)
+    K.linear_out1_bce(x, w, b, y2, dl2, lm2)
+    assert torch.equal(y, y2) and torch.equal(dl, dl2) and torch.equal(lm, lm2)
+    for forced in (None, torch.randint(0, 4, (B,), dtype=torch.int32, device=d)):
+        rows, theta, logit = rnd((B, 28, 28, 1), 4).to(d), rnd((B, 7, 7, 16), 5).to(d), rnd((B,), 6).to(d)
+        best = rnd((B,), 7).to(d)
+        a = [torch.zeros_like(rows), torch.zeros_like(theta), best.clone(), torch.ones(B, device=d)]
+        c = [t.clone() for t in a]
+        K.refine_select_rows(rows, logit, forced, 2, a[0], a[2])
+        K.refine_select(theta, logit, forced, 2, a[1], a[2], a[3])
+        K.refine_select2(rows, c[0], theta, c[1], logit, forced, 2, c[2], c[3])
+        assert all(torch.equal(u, v) for u, v in zip(a, c))
+        upd = (forced == 2) if forced is not None else (logit > best)
+        assert torch.equal(c[3], torch.where(upd, torch.full_like(best, 3.0), torch.ones_like(best))) and upd.any() and not upd.all()
