@@ -909,6 +909,52 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(IgemmParams p) {
     }
 }
 
+// The same reduction for a launch that leaves norm statistics (CGS_EPI_NONE, N % 4 == 0; round 5): block = (one partial row = 64 GEMM rows,
+// 32 columns) -- 8 column quads x 32 row lanes of 2 rows each; the K slices are added in index order, the stored values' column sums /
+// sums of squares go through LDS and are added over the row lanes in index order (deterministic), into the row the one-pass epilogue
+// would have written: [class][m / 64][sum | sum of squares][N].  Why: a launch with statistics could not be split over K before, and at the
+// reference's batch size (64 images a call, nsgan/main.py:32) D's statistics-leaving convolutions are 16-128 tiles on 256 CUs (dcgan32's
+// 4x4 256->512 forward: 16 tiles, 266 us = 0.04 of peak against 38 us for its backward-data, which was split).
+__global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(IgemmParams p) {
+    const int cls_i = blockIdx.z;
+    const IgemmClass& c = p.cls[cls_i];
+    const int RC = c.R * c.C;
+    const int M = p.B * RC;
+    const float* slab = p.slab + c.slab_off;
+    const int cq = threadIdx.x & 7, rl = threadIdx.x >> 3;
+    const int n = blockIdx.y * 32 + cq * 4;
+    __shared__ f32x4 red[2][32][8];
+    f32x4 sa = {0.f, 0.f, 0.f, 0.f}, sb = {0.f, 0.f, 0.f, 0.f};
+    if (n < p.N) {
+        f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) bias = *(const f32x4*)(p.bias + n);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = blockIdx.x * 64 + i * 32 + rl;
+            if (m >= M) continue;
+            f32x4 a = *(const f32x4*)(slab + (size_t)m * p.Np + n);
+#pragma unroll 4
+            for (int z = 1; z < p.splitk; ++z) a += *(const f32x4*)(slab + ((size_t)z * M + m) * p.Np + n);
+            int b, rem;
+            if (p.pix_major) { rem = m / p.B; b = m - rem * p.B; } else { b = m / RC; rem = m - b * RC; }
+            const int r = rem / c.C, cc = rem - r * c.C;
+            const size_t o = (size_t)((b * p.Hout + r * p.So + c.py) * p.Wout + cc * p.So + c.px) * p.N + n;
+            const f32x4 y = a + bias;
+            *(f32x4*)(p.out + o) = y;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { sa[e] += y[e]; sb[e] = fmaf(y[e], y[e], sb[e]); }
+        }
+    }
+    red[0][rl][cq] = sa; red[1][rl][cq] = sb;
+    __syncthreads();
+    if (rl < 2 && n < p.N) {             // row lane 0 adds the sums, row lane 1 the sums of squares
+        f32x4 t = red[rl][0][cq];
+#pragma unroll 8
+        for (int r = 1; r < 32; ++r) t += red[rl][r][cq];
+        *(f32x4*)(p.stat_part + ((size_t)(cls_i * p.stat_cls_rows + blockIdx.x) * 2 + rl) * p.N + n) = t;
+    }
+}
+
 // Tail split, second half: block = one tail tile.  out[pix(m)][n] = epi(bias[n] + sum_z slab[tile][z][m - m0][n - n0]), the K slices
 // added in index order (deterministic); the tile decode is the main kernel's (same wi -> (m-tile, n-tile), same row -> pixel map).
 #define TAIL_RSPLIT 16
@@ -981,7 +1027,11 @@ static int choose_splitk(const IgemmParams& p) {
     }
     // (splitting grids of 256-1023 blocks as well was measured on dcgan32, B = 256: -10 % with two batches in flight)
     if (blocks == 0 || blocks >= 256 || nk_min < 8) return 1;
-    long s = (512 + blocks - 1) / blocks;
+    long target = 512;
+#ifdef CGS_EXPERIMENT
+    if (getenv("CGS_SPLITK_TARGET")) target = atol(getenv("CGS_SPLITK_TARGET"));
+#endif
+    long s = (target + blocks - 1) / blocks;
     if (s > nk_min / 4) s = nk_min / 4;
     if (s > 64) s = 64;
     return s < 2 ? 1 : (int)s;
@@ -1025,9 +1075,9 @@ static IgemmTiles igemm_choose_tiles(const IgemmParams& p) {
     if (wide && vec && p.splitk == 1) {
         const long wb = igemm_blocks(p, 128);
         if (wb >= 256 && wb < 512) { wide = false; mid = true; }
-        // a launch that leaves norm statistics or a sign mask comes out of the one-pass epilogue and cannot be split over K: under
-        // 256 blocks of 128x128 it would leave most CUs idle (config 5's PatchGAN 4x4 128->256 layer: 128 blocks, 54 TFLOP/s) --
-        // as 128x64 blocks at least every CU gets one
+        // a launch that leaves a sign mask (one-pass epilogue only), or statistics when the workspace has no room for the split-K slabs
+        // (with room it is split: splitk_reduce_stats_kernel): under 256 blocks of 128x128 it would leave most CUs idle (config 5's
+        // PatchGAN 4x4 128->256 layer: 128 blocks, 54 TFLOP/s) -- as 128x64 blocks at least every CU gets one
 #ifndef CGS_NO_STAT_NARROW
         else if (wb < 256 && (p.stat_part || p.sign_out)) { wide = false; mid = true; }
 #endif
@@ -1201,7 +1251,8 @@ static int launch_cfg(const IgemmParams& p, hipStream_t s) {
         long tot = 0;
         for (int i = 0; i < p.nclasses; ++i) { long t = (long)p.B * p.cls[i].R * p.cls[i].C * (p.Np / 4); if (t > tot) tot = t; }
         unsigned rb = (unsigned)((tot + 63) / 64 > 4096 ? 4096 : (tot + 63) / 64);       // 64 output quads per 256-thread block
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rb, p.nclasses), dim3(256), 0, s, p);
+        if (p.stat_part) hipLaunchKernelGGL(splitk_reduce_stats_kernel, dim3((unsigned)p.stat_cls_rows, (unsigned)((p.N + 31) / 32), p.nclasses), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rb, p.nclasses), dim3(256), 0, s, p);
         CGS_CHECK_LAUNCH("splitk_reduce");
     }
     // the name rocprofv3 prints for this instantiation
@@ -1309,8 +1360,13 @@ int cgs_igemm_launch(const IgemmParams& p_in, void* slab, size_t slab_bytes, hip
     if (p.sign_out && !cgs_igemm_signs_ok(p))
         return cgs_set_error(CGS_EINVAL, "igemm: a sign mask needs N %% 32 == 0, the relu / lrelu forward epilogues and a grid that is not split over K");
     {   // split-K for under-filled grids, if the caller's workspace has room for the partial slabs
-        const size_t need = (p.stat_part || p.sign_out) ? 0 : cgs_igemm_splitk_bytes(p);      // (the statistics / signs come out of the one-pass epilogue)
-        if (need && slab && slab_bytes >= need) {
+        const size_t need = p.sign_out ? 0 : cgs_igemm_splitk_bytes(p);      // (a sign mask comes out of the one-pass epilogue; statistics: splitk_reduce_stats_kernel)
+#ifdef CGS_EXPERIMENT
+        const bool stat_split = !(p.stat_part && getenv("CGS_STAT_SPLIT") && atoi(getenv("CGS_STAT_SPLIT")) == 0);      // (A/B: 0 = statistics launches unsplit, as before round 5)
+#else
+        const bool stat_split = true;
+#endif
+        if (need && stat_split && slab && slab_bytes >= need) {
             p.splitk = choose_splitk(p); p.slab = (float*)slab;
             size_t off = 0;
             for (int i = 0; i < p.nclasses; ++i) {

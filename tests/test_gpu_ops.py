@@ -487,7 +487,10 @@ def test_many_block_grids_use_the_16_deep_variant(case):
 
 
 @pytest.mark.parametrize("B,H,Cin,Cout,k", [(64, 16, 32, 128, 5), (1024, 8, 64, 64, 5), (5, 6, 32, 64, 3), (130, 8, 32, 68, 4), (512, 8, 64, 256, 5),
-                                            (3, 10, 32, 384, 3)])
+                                            (3, 10, 32, 384, 3),
+                                            # the reference's batch size on D's last layers: 16-64 tiles, split over K with the statistics
+                                            # left by the reduce pass (splitk_reduce_stats_kernel)
+                                            (64, 4, 256, 512, 5), (64, 8, 128, 256, 5), (64, 8, 256, 512, 5), (33, 14, 64, 128, 5)])
 def test_conv_with_fused_bn_statistics(B, H, Cin, Cout, k, contraction):
     """cgs_conv2d_nhwc_fwd_stats: the conv's output is unchanged, its per-block partial sums reduce to the per-channel sum and sum
     of squares of that output, and cgs_bn_train_lrelu_fwd_from_partials gives the batch norm of the plain two-kernel path -- also on
