@@ -272,28 +272,42 @@ int cgs_refine_select_rows(const float* src, const float* logit, const int32_t* 
     return CGS_OK;
 }
 
-// both row copies of one step in ONE launch: blockIdx.z = 0 copies the rendered image rows, 1 the refined-map rows (same predicate)
+// both row copies of one step in ONE launch: blockIdx.z = 0 copies the rendered image rows, 1 the refined-map rows (same predicate).
+// With ``tickets`` (B ints, zero between launches) the per-sample scalars are updated in the same launch: every block of a selected
+// sample takes a ticket after its copy, and the one that takes the last (all others have read best_logit[b] by then) writes
+// best_logit / best_step and puts the ticket counter back to zero -- one dependent 4.5-us launch less per refinement step.
 __global__ __launch_bounds__(256) void refine_select_copy2_kernel(const float* __restrict__ src0, float* __restrict__ dst0, int F0,
                                                                   const float* __restrict__ src1, float* __restrict__ dst1, int F1,
                                                                   const float* __restrict__ logit, const int32_t* __restrict__ forced, int step,
-                                                                  const float* __restrict__ best_logit) {
+                                                                  float* best_logit, float* __restrict__ best_step, int* __restrict__ tickets) {
     const int b = blockIdx.y;
-    const bool upd = forced ? forced[b] == step : logit[b] > best_logit[b];
-    if (!upd) return;
+    const float lg = logit[b];
+    const bool upd = forced ? forced[b] == step : lg > best_logit[b];
+    if (!upd) return;                              // (nothing of this sample changes: no ticket needed)
     const int F = blockIdx.z ? F1 : F0;
     const float* src = (blockIdx.z ? src1 : src0) + (size_t)b * F;
     float* dst = (blockIdx.z ? dst1 : dst0) + (size_t)b * F;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < F; i += gridDim.x * blockDim.x) dst[i] = src[i];
+    if (!tickets) return;
+    __syncthreads();                               // every thread of the block has read the predicate (it is the first thing a thread does)
+    if (threadIdx.x == 0) {
+        const int last = (int)(gridDim.x * gridDim.z) - 1;
+        if (atomicAdd(tickets + b, 1) == last) {
+            best_logit[b] = lg; best_step[b] = (float)(step + 1);
+            tickets[b] = 0;
+        }
+    }
 }
 
 int cgs_refine_select2(const float* rows, float* best_rows, int Frows, const float* theta, float* best_theta, int F, const float* logit,
-                       const int32_t* forced, int step_index, float* best_logit, float* best_step, int B, void* stream) {
+                       const int32_t* forced, int step_index, float* best_logit, float* best_step, int* tickets, int B, void* stream) {
     if (B <= 0 || F <= 0 || Frows <= 0 || B > 65535) return cgs_set_error(CGS_EINVAL, "refine_select2: B=%d F=%d Frows=%d", B, F, Frows);
     int bx = cgs_ceil_div(F > Frows ? F : Frows, 256 * 4);
     if (bx < 1) bx = 1;
     hipLaunchKernelGGL(refine_select_copy2_kernel, dim3(bx, B, 2), dim3(256), 0, (hipStream_t)stream, rows, best_rows, Frows, theta, best_theta, F, logit, forced,
-                       step_index, best_logit);
-    hipLaunchKernelGGL(refine_select_scalar_kernel, dim3(cgs_ceil_div(B, 128)), dim3(128), 0, (hipStream_t)stream, logit, forced, step_index, best_logit, best_step, B);
+                       step_index, best_logit, best_step, tickets);
+    if (!tickets)
+        hipLaunchKernelGGL(refine_select_scalar_kernel, dim3(cgs_ceil_div(B, 128)), dim3(128), 0, (hipStream_t)stream, logit, forced, step_index, best_logit, best_step, B);
     CGS_CHECK_LAUNCH("refine_select2");
     return CGS_OK;
 }

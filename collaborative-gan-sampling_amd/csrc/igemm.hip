@@ -1446,6 +1446,14 @@ int cgs_igemm_launch(const IgemmParams& p_in, void* slab, size_t slab_bytes, hip
     if (getenv("CGS_PRIO")) sscanf(getenv("CGS_PRIO"), "%d,%d,%d", &p.prio_t[0], &p.prio_t[1], &p.prio_t[2]);
     if (getenv("CGS_NOBALANCE")) { /* diagnostic: handled by CGS_PRIO=0,0,0 for (a); (b) has no switch */ }
 #endif
+    // Launches of at most 64 GEMM rows that are split over K (the fully connected layers at the reference's batch size, nsgan/main.py:32: 64 x 6272 x 1024):
+    // 64-row tiles -- a 128-row tile is half padding there and the blocks are matrix-bound (4-8 K tiles each on their own SIMDs).  Same-process
+    // A/B (round 5, profiles/r05_t_bm64_ab.txt): mnist's 6272->1024 forward 34.6 -> 25.9 us, backward 32.5 -> 24.0 us, the batch-64 call 12.14 -> 11.38 ms.
+    bool half = vec && wide && deep && p.splitk > 1 && !p.tap_parity && (long)p.B * maxRC <= 64;
+#ifdef CGS_EXPERIMENT
+    if (getenv("CGS_BM64")) half = half && atoi(getenv("CGS_BM64")) != 0;
+#endif
+    if (half) return launch_cfg<64, 128, 4, true, 32>(p, s);
     if (tall) return p.tap_parity ? launch_cfg<256, 64, 4, true, 16, true>(p, s) : launch_cfg<256, 64, 4, true, 16>(p, s);
     if (vec && !deep && !p.tap_parity) return wide ? launch_cfg<128, 128, 4, true, 16>(p, s) : launch_cfg<128, 64, 4, true, 16>(p, s);
     if (vec && !deep && p.tap_parity) return wide ? launch_cfg<128, 128, 4, true, 16, true>(p, s) : launch_cfg<128, 64, 4, true, 16, true>(p, s);

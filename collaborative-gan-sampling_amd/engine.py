@@ -517,6 +517,7 @@ class RefineEngine:
             self.theta, self.mom, self.best_theta = torch.empty(fs, **f32), torch.empty(fs, **f32), torch.empty(fs, **f32)
             self.logit, self.best_logit = torch.empty(B, **f32), torch.empty(B, **f32)
             self.default_logit, self.best_step = torch.empty(B, **f32), torch.empty(B, **f32)
+            self.tickets = torch.zeros(B, dtype=torch.int32, device=self.dev)      # cgs_refine_select2: zero between launches
             self.dlogits = torch.empty((B,) + tuple(self.d.out_shape), **f32)
             self.forced = torch.zeros(B, dtype=torch.int32, device=self.dev)
             self.images = torch.empty((B,) + tuple(A["img"]), **f32)
@@ -663,6 +664,7 @@ class RefineEngine:
         self.best_theta.copy_(th)
         self.images.copy_(render)
         self.best_step.fill_(1.0)                                   # collaborator.py:60 (starts at 1)
+        self.tickets.zero_()                                        # (already zero unless an earlier call died between its launches)
         forced = self.forced if probabilistic else None
         for i in range(steps):
             g = self.backward_to_feature()
@@ -670,7 +672,7 @@ class RefineEngine:
             self.forward_logits(th, self.logit)                     # the K-th gradient is never formed (Q4)
             # collaborator.py:88 renders G_tail(best_theta) once more at the end; the very same image was already
             # rendered in the step that selected it, so it is kept by the same row-select instead (bit-identical)
-            K.refine_select2(render, self.images, th, self.best_theta, self.logit, forced, i, self.best_logit, self.best_step)
+            K.refine_select2(render, self.images, th, self.best_theta, self.logit, forced, i, self.best_logit, self.best_step, self.tickets)
 
     @_entry
     def refine(self, feature0, steps, rate, method="momentum", mode="deterministic", indices=None,

@@ -662,11 +662,14 @@ def refine_select(theta, logit, forced, step_index, best_theta, best_logit, best
            _ptr(best_step), B, theta.numel() // B, _stream())
 
 
-def refine_select2(rows, best_rows, theta, best_theta, logit, forced, step_index, best_logit, best_step):
-    """refine_select_rows(rows) + refine_select(theta) with the two row copies in one launch."""
+def refine_select2(rows, best_rows, theta, best_theta, logit, forced, step_index, best_logit, best_step, tickets=None):
+    """refine_select_rows(rows) + refine_select(theta) with the two row copies in one launch; with ``tickets`` (int32 [B], zero: the call leaves
+    it zero) the scalars too -- otherwise they follow in a second launch."""
     B = theta.shape[0]
+    if tickets is not None and (tickets.dtype != torch.int32 or tickets.numel() < B or not tickets.is_contiguous() or tickets.device != theta.device):
+        raise L.CgsError("refine_select2: tickets must be a contiguous int32 device tensor of at least B elements")
     L.call("cgs_refine_select2", _ptr(rows), _ptr(best_rows), rows.numel() // B, _ptr(theta), _ptr(best_theta), theta.numel() // B, _ptr(logit),
-           _ptr(forced), step_index, _ptr(best_logit), _ptr(best_step), B, _stream())
+           _ptr(forced), step_index, _ptr(best_logit), _ptr(best_step), _ptr(tickets), B, _stream())
 
 
 def linear_out1_bce(x, w, bias, logits, dlogits, logit_mean):

@@ -76,7 +76,7 @@ SIGNATURES = {
     "cgs_refine_update": (_i, [_p, _p, _p, _f, _f, _i, _i, _f, _f, _z, _p]),
     "cgs_refine_select": (_i, [_p, _p, _p, _i, _p, _p, _p, _i, _i, _p]),
     "cgs_refine_select_rows": (_i, [_p, _p, _p, _i, _p, _p, _i, _i, _p]),
-    "cgs_refine_select2": (_i, [_p, _p, _i, _p, _p, _i, _p, _p, _i, _p, _p, _i, _p]),
+    "cgs_refine_select2": (_i, [_p, _p, _i, _p, _p, _i, _p, _p, _i, _p, _p, _p, _i, _p]),
     "cgs_linear_out1_bce": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _p]),
     "cgs_mlp2d_sigmoid_saliency": (_i, [_p, _p, _i, _i, _p, _p, _p, _i, _f, _p]),
     "cgs_refine2d": (_i, [_p, _p, _i, _i, _p, _f, _f, _i, _f, _i, _p, _p, _p, _i, _p]),

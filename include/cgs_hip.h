@@ -309,9 +309,11 @@ int cgs_refine_update(float* theta, float* m, const float* g, float rate, float 
 int cgs_refine_select(const float* theta, const float* logit, const int32_t* forced, int step_index,
                       float* best_theta, float* best_logit, float* best_step, int B, int F, void* stream);
 /* cgs_refine_select_rows(rows -> best_rows) followed by cgs_refine_select(theta -> best_theta, scalars) with the two row copies in one
- * launch: the per-step bookkeeping of the engine (the rendered image follows the selection of the refined map). */
+ * launch: the per-step bookkeeping of the engine (the rendered image follows the selection of the refined map).
+ * tickets: NULL, or B ints of device memory that are ZERO at the call and are left zero by it (the caller clears them once and hands the
+ * same buffer to every call on one stream): the scalars are then updated in the same launch, by the last block of each selected sample. */
 int cgs_refine_select2(const float* rows, float* best_rows, int Frows, const float* theta, float* best_theta, int F, const float* logit,
-                       const int32_t* forced, int step_index, float* best_logit, float* best_step, int B, void* stream);
+                       const int32_t* forced, int step_index, float* best_logit, float* best_step, int* tickets, int B, void* stream);
 /* The row copy of cgs_refine_select alone (same predicate, best_logit is only read): lets a second per-sample
  * tensor -- e.g. the rendered image of the step -- follow the same selection.  Call it BEFORE cgs_refine_select. */
 int cgs_refine_select_rows(const float* src, const float* logit, const int32_t* forced, int step_index, float* dst,

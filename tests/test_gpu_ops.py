@@ -275,8 +275,13 @@ def test_linear_fwd_bwd(B, K_, N):
     dy = rnd((B, N), 4)
     (y * dy).sum().backward()
     d = dev()
+    from cgs_amd import lib
     close(K.linear_fwd(x.detach().to(d), w.to(d), b.to(d)), y, 2e-5)
+    fwd_kernel = lib.last_kernel()
     close(K.linear_bwd_data(dy.to(d), w.to(d)), x.grad, 2e-5)
+    if (B, K_, N) in ((64, 6272, 1024), (33, 1024, 6272)):        # <= 64 (or > 64) rows, split over K: 64- (128-) row tiles
+        assert fwd_kernel == ("igemm_kernel<64, 128, 4, true, 32, false>" if B <= 64 else "igemm_kernel<128, 128, 4, true, 32, false>"), fwd_kernel
+        assert lib.last_kernel() == "igemm_kernel<64, 128, 4, true, 32, false>"
 
 
 @pytest.mark.parametrize("shape", [(64, 7, 7, 128), (64, 1024), (10, 16, 16, 128), (3, 4, 4, 512), (257, 8, 8, 256),
@@ -779,5 +784,11 @@ def test_fused_logit_head_and_row_selects_equal_their_parts():
         K.refine_select(theta, logit, forced, 2, a[1], a[2], a[3])
         K.refine_select2(rows, c[0], theta, c[1], logit, forced, 2, c[2], c[3])
         assert all(torch.equal(u, v) for u, v in zip(a, c))
+        # ... and with the scalars in the same launch (the last block of a selected sample writes them; the tickets come back zero)
+        e = [torch.zeros_like(rows), torch.zeros_like(theta), best.clone(), torch.ones(B, device=d)]
+        tickets = torch.zeros(B, dtype=torch.int32, device=d)
+        for _ in range(2):                 # (twice: the second call selects nothing new in deterministic mode, the same rows in forced mode)
+            K.refine_select2(rows, e[0], theta, e[1], logit, forced, 2, e[2], e[3], tickets)
+        assert all(torch.equal(u, v) for u, v in zip(a, e)) and not tickets.any()
         upd = (forced == 2) if forced is not None else (logit > best)
         assert torch.equal(c[3], torch.where(upd, torch.full_like(best, 3.0), torch.ones_like(best))) and upd.any() and not upd.all()
