@@ -390,7 +390,7 @@ def other_configs(dev, skip, want_cpu):
     return out
 
 
-def class_surface(dev, configs=(("dcgan64", 1024, 20, 6, 3), ("mnist", 64, 50, 24, 4))):
+def class_surface(dev, configs=(("dcgan64", 1024, 20, 6, 3), ("mnist", 64, 50, 24, 4), ("dcgan32", 64, 20, 24, 4))):
     """What a caller of the reference's CLASS SURFACE gets, as opposed to the engines the headline drives directly:
     ``model.GAN`` + ``collaborator.Refiner`` wired with the very lines of nsgan/GAN.py:171-181 -- a ``functools.partial`` of the
     discriminator and a local loss closure -- then per z batch ``input_to_feature`` (operator API) and ``build_refiner``: one batch
@@ -437,11 +437,11 @@ def class_surface(dev, configs=(("dcgan64", 1024, 20, 6, 3), ("mnist", 64, 50, 2
                          "hipgraph": bool(r.use_graph) if r.path == "engine" else False}
             if r.graph_fallback:
                 rec[name]["hipgraph_fallback"] = r.graph_fallback
-        if arch == "mnist":
+        if B == 64:
             # the reference's callers run the refiner one batch_size-64 batch per sess.run (nsgan/main.py:32, nsgan/GAN.py:270-272,398-426):
             # ``refiner.logical_batch = 64`` hands build_refiner G such batches at once -- one launch per layer, D's batch statistics and
             # the step bookkeeping per logical batch -- through the same verbatim wiring
-            Gf = FUSE[arch]
+            Gf = 32
             refiner.logical_batch = B
             zf = torch.from_numpy(np.random.RandomState(2020).uniform(-1, 1, (steps // 4 + 2, B * Gf) + nets.g_input_shape(A)).astype(np.float32)).to(dev)
             with torch.no_grad():

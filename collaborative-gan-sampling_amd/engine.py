@@ -13,6 +13,8 @@ layer lists of ``nets`` are compiled ONCE into a tape of stages over libcgs_hip.
 
 Only forward + backward-DATA exist: the weights are frozen, no weight gradient is ever formed.
 """
+import gc
+
 import numpy as np
 import torch
 
@@ -719,6 +721,12 @@ class RefineEngine:
                     torch.cuda.synchronize(self.dev)
                     # (thread-local capture: other threads of the process -- RCCL proxies, the distributed watchdog, a second engine's
                     # host thread -- may make HIP calls meanwhile without invalidating this capture)
+                    # (no cyclic garbage collection inside the capture: a finalizer that reaches HIP -- a dead engine's graph, stream or event
+                    # waiting in a reference cycle -- makes a call the capturing thread may not make, and the runtime ABORTS the process instead
+                    # of refusing the capture; seen once the GPU suite ran in one process: the 1,460 launches of a K=50 program allocate
+                    # enough small objects to trigger a collection.  torch.cuda.graph collects once itself BEFORE the capture begins.)
+                    gc_was_on = gc.isenabled()
+                    gc.disable()
                     try:
                         g = torch.cuda.CUDAGraph()
                         with torch.cuda.graph(g, stream=self._gstream, capture_error_mode="thread_local"):
@@ -727,6 +735,9 @@ class RefineEngine:
                         raise
                     except Exception as ex:                          # noqa: BLE001 (HIP / allocator / another thread's HIP call refused the capture)
                         raise L.GraphCaptureError(f"{type(ex).__name__}: {str(ex)[:300]}") from ex
+                    finally:
+                        if gc_was_on:
+                            gc.enable()
                     cur.wait_stream(self._gstream)
                     self._graphs[key] = g
                 g.replay()

@@ -52,12 +52,13 @@ def test_bench_line_small_config():
             assert 0 < o["roofline"]["frac"] <= 1.0 and 0 < o["roofline"]["step_executed_frac"] <= 1.0 and o["hbm"]
     # the class surface: the reference's verbatim wiring reaches the fused engine; the opaque-callable form stays generic
     cs = d["class_surface"]
-    for arch in ("dcgan64", "mnist"):
+    for arch in ("dcgan64", "mnist", "dcgan32"):
         e, g = cs[arch]["engine"], cs[arch]["generic"]
         assert e["path"] == "engine" and e["hipgraph"] is True and "hipgraph_fallback" not in e and g["path"] == "generic"
         assert e["samples_per_s"] > g["samples_per_s"] > 0
-    f = cs["mnist"]["fused"]                  # the reference's batch-64 calls, G per launch through the same wiring (Refiner.logical_batch)
-    assert f["path"] == "engine" and f["logical_batch"] == 64 and f["samples_per_s"] > 2.0 * cs["mnist"]["engine"]["samples_per_s"]
+    for arch in ("mnist", "dcgan32"):         # the reference's batch-64 calls, G per launch through the same wiring (Refiner.logical_batch)
+        f = cs[arch]["fused"]
+        assert cs[arch]["batch"] == 64 and f["path"] == "engine" and f["logical_batch"] == 64 and f["samples_per_s"] > 2.0 * cs[arch]["engine"]["samples_per_s"]
     f1 = d["f1"]                              # the evaluate fill loop (nsgan/GAN.py:384-426), measured
     assert f1["eval_size"] == 49984 and f1["accepted_samples_per_s"] > 0 and 0 < f1["efficiency"] <= 1.0 and 0 <= f1["host_chain_share_of_wall"] < 1
     assert len(d["lib"]["source_sha16"]) == 16
