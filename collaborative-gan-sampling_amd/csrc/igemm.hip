@@ -1026,11 +1026,12 @@ static int choose_splitk(const IgemmParams& p) {
         if (p.cls[i].R * p.cls[i].C > 0 && nk < nk_min) nk_min = nk;
     }
     // (splitting grids of 256-1023 blocks as well was measured on dcgan32, B = 256: -10 % with two batches in flight)
-    if (blocks == 0 || blocks >= 256 || nk_min < 8) return 1;
-    long target = 512;
+    long target = 512, maxb = 256;
 #ifdef CGS_EXPERIMENT
     if (getenv("CGS_SPLITK_TARGET")) target = atol(getenv("CGS_SPLITK_TARGET"));
+    if (getenv("CGS_SPLITK_MAXBLOCKS")) maxb = atol(getenv("CGS_SPLITK_MAXBLOCKS"));
 #endif
+    if (blocks == 0 || blocks >= maxb || nk_min < 8) return 1;
     long s = (target + blocks - 1) / blocks;
     if (s > nk_min / 4) s = nk_min / 4;
     if (s > 64) s = 64;
