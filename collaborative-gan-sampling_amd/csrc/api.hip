@@ -28,7 +28,7 @@ int cgs_set_error(int code, const char* fmt, ...) {
 
 extern "C" {
 
-int cgs_version(void) { return 105; }
+int cgs_version(void) { return 106; }
 const char* cgs_last_error(void) { return g_err; }
 const char* cgs_last_kernel(void) { return g_last_kernel; }
 double cgs_last_executed_flops(void) { return g_last_flops; }

@@ -171,7 +171,14 @@ __global__ __launch_bounds__(64 * NW, 2) void igemm_kernel(IgemmParams p) {
     // the same image groups for every pixel, so the tap overlap between neighbouring pixels hits in its L2 too.
     const int nblk_n = p.Np / BN;
     unsigned wi = blockIdx.x;
-    const int cls_i = blockIdx.y;
+    int cls_i = blockIdx.y;
+    if (p.xcd_map == 2) {        // the parity classes of a tile back to back on ONE XCD (ids 8 * (tile * classes + class) + xcd): they read the same input patch
+        const unsigned xcd = wi & 7u;
+        unsigned q = wi >> 3;
+        cls_i = (int)(q % (unsigned)p.nclasses);
+        q /= (unsigned)p.nclasses;
+        wi = (q << 3) | xcd;
+    }
     // tail split: the block ids from tail_from on (last class) are (tail tile, K slice) pairs -- tail_s consecutive ids per tile
     int tsplit = 1, tz = 0, ttile = 0;
     if (p.tail_s > 1 && cls_i == p.nclasses - 1 && wi >= (unsigned)p.tail_from) {
@@ -1241,8 +1248,17 @@ static int launch_cfg(const IgemmParams& p, hipStream_t s) {
         if ((long)p.tail_from + p.tail_n != gx) return cgs_set_error(CGS_EINVAL, "igemm: tail split planned for another grid (%d + %d != %ld)", p.tail_from, p.tail_n, gx);
         gx = (long)p.tail_from + (long)p.tail_n * p.tail_s;
     }
+    unsigned gy = (unsigned)p.nclasses;
+#ifdef CGS_EXPERIMENT
+    if (getenv("CGS_CLS_INTER") && atoi(getenv("CGS_CLS_INTER")) && q.xcd_map == 1 && (mtiles % 8) == 0 && p.nclasses > 1 && p.tail_s <= 1 && p.splitk == 1 && !p.pix_major &&
+        gx >= atol(getenv("CGS_CLS_INTER"))) {
+        bool eq = true;
+        for (int i = 1; i < p.nclasses; ++i) eq = eq && p.cls[i].R * p.cls[i].C == p.cls[0].R * p.cls[0].C;
+        if (eq) { q.xcd_map = 2; gx *= p.nclasses; gy = 1; }
+    }
+#endif
     if (gx > 0x7fffffffL) return cgs_set_error(CGS_EINVAL, "igemm: grid too large");
-    hipLaunchKernelGGL((igemm_kernel<BM, BN, NW, VEC, TBK, PAR>), dim3((unsigned)gx, p.nclasses, p.splitk > 1 ? p.splitk : 1), dim3(64 * NW), smem, s, q);
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, NW, VEC, TBK, PAR>), dim3((unsigned)gx, gy, p.splitk > 1 ? p.splitk : 1), dim3(64 * NW), smem, s, q);
     CGS_CHECK_LAUNCH("igemm");
     if (p.tail_s > 1) {
         hipLaunchKernelGGL(tail_reduce_kernel, dim3((unsigned)p.tail_n, TAIL_RSPLIT), dim3(256), 0, s, q, BM, BN);

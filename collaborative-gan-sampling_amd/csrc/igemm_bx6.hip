@@ -131,8 +131,15 @@ __global__ __launch_bounds__(BM* BN / 128, BM* BN == 128 * 256 || BM * BN == 128
 
     // block id -> (m-tile, n-tile, class): as igemm_kernel (per-XCD decode, heaviest pixels first)
     const int nblk_n = p.Np / BN;
-    const unsigned wi = blockIdx.x;
-    const int cls_i = blockIdx.y;
+    unsigned wi = blockIdx.x;
+    int cls_i = blockIdx.y;
+    if (p.xcd_map == 2) {        // the parity classes of a tile back to back on ONE XCD (as igemm_kernel)
+        const unsigned xcd = wi & 7u;
+        unsigned q = wi >> 3;
+        cls_i = (int)(q % (unsigned)p.nclasses);
+        q /= (unsigned)p.nclasses;
+        wi = (q << 3) | xcd;
+    }
     int nb, mb;
     if (p.xcd_map) {
         const unsigned xcd = wi & 7u, q = wi >> 3;
@@ -590,9 +597,17 @@ static int launch_bx6(const IgemmParams& p, hipStream_t s) {
     const long mtiles = (maxM + BM - 1) / BM;
     IgemmParams q = p;
     q.xcd_map = (mtiles % 8 == 0 || mtiles >= 64) ? 1 : 0;
-    const long gx = (q.xcd_map ? (mtiles + 7) / 8 * 8 : mtiles) * (p.Np / BN);
+    long gx = (q.xcd_map ? (mtiles + 7) / 8 * 8 : mtiles) * (p.Np / BN);
+    unsigned gy = (unsigned)p.nclasses;
+#ifdef CGS_EXPERIMENT
+    if (getenv("CGS_CLS_INTER") && atoi(getenv("CGS_CLS_INTER")) && q.xcd_map == 1 && (mtiles % 8) == 0 && p.nclasses > 1 && !p.pix_major && gx >= atol(getenv("CGS_CLS_INTER"))) {
+        bool eq = true;
+        for (int i = 1; i < p.nclasses; ++i) eq = eq && p.cls[i].R * p.cls[i].C == p.cls[0].R * p.cls[0].C;
+        if (eq) { q.xcd_map = 2; gx *= p.nclasses; gy = 1; }
+    }
+#endif
     if (gx > 0x7fffffffL) return cgs_set_error(CGS_EINVAL, "igemm_bx6: grid too large");
-    hipLaunchKernelGGL((igemm_bx6_kernel<BM, BN, PAR>), dim3((unsigned)gx, p.nclasses, 1), dim3(NT), smem, s, q);
+    hipLaunchKernelGGL((igemm_bx6_kernel<BM, BN, PAR>), dim3((unsigned)gx, gy, 1), dim3(NT), smem, s, q);
     CGS_CHECK_LAUNCH("igemm_bx6");
     static thread_local char name[64];
     snprintf(name, sizeof(name), "igemm_bx6_kernel<%d, %d, %s>", BM, BN, PAR ? "true" : "false");

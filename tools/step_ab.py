@@ -33,12 +33,12 @@ def set_mode(m):
 
 # (workspace sizes are asked of the library once per call signature and cached: ask them under the environment of the call, before any mode
 # narrows it)
-RefineEngine(arch, P, B * G, d, bn_groups=G).refine_from_z(z, 1, 0.1)
+RefineEngine(arch, P, B * G, d, bn_groups=G, contraction=os.environ.get("CGS_CONTRACTION", "f32")).refine_from_z(z, 1, 0.1)
 torch.cuda.synchronize()
 engines = []
 for m in modes:
     set_mode(m)
-    e = RefineEngine(arch, P, B * G, d, use_graph=True, bn_groups=G)
+    e = RefineEngine(arch, P, B * G, d, use_graph=True, bn_groups=G, contraction=os.environ.get("CGS_CONTRACTION", "f32"))
     e.refine_from_z(z, K, 0.1); e.refine_from_z(z, K, 0.1)
     torch.cuda.synchronize()
     engines.append(e)
