@@ -1039,10 +1039,46 @@ static int choose_splitk(const IgemmParams& p) {
     if (getenv("CGS_SPLITK_MAXBLOCKS")) maxb = atol(getenv("CGS_SPLITK_MAXBLOCKS"));
 #endif
     if (blocks == 0 || blocks >= maxb || nk_min < 8) return 1;
-    long s = (target + blocks - 1) / blocks;
-    if (s > nk_min / 4) s = nk_min / 4;
-    if (s > 64) s = 64;
-    return s < 2 ? 1 : (int)s;
+    long cap = nk_min / 4;                       // at least four 32-deep K tiles per slice (in the class with the shortest K)
+    if (cap > 64) cap = 64;
+    if (cap < 2) return 1;
+#ifdef CGS_EXPERIMENT
+    if (getenv("CGS_SPLITK_MODEL") && atoi(getenv("CGS_SPLITK_MODEL")) == 0) {          // (A/B: the rule before round 5: aim at ``target`` blocks)
+        long s = (target + blocks - 1) / blocks;
+        if (s > cap) s = cap;
+        return s < 2 ? 1 : (int)s;
+    }
+#endif
+    // The factor with the least modelled time (round 5; calibrated on the batch-64 launches of dcgan32 / dcgan64 / mnist, tools/sessions/r05_q.sh:
+    // these launches are matrix-bound per block, every block on its own SIMDs).  In units of one 128x128x32 tile on an otherwise idle CU:
+    //   K loop  = (K tiles per slice) x (blocks on the fullest CU), x 1.41 if that is ONE block (nobody hides its load -> LDS -> MFMA latencies:
+    //             a lone block's tile takes 2.4 us against 1.7 us per block for two that share the SIMDs);
+    //   slices  = 0.3 per MB of partial sums (written by the epilogue, read back by the reduce pass at ~4 TB/s).
+    // The old rule (aim at 512 blocks) left 400 blocks on 256 CUs for dcgan32's 4x4 256->512 layer at batch 64 -- 144 CUs with two blocks of four K tiles,
+    // 50 slices of partial sums: 41.6 us -- where 29 slices of seven tiles, one block per CU, take 36.7 us; dcgan64's layers keep their two even rounds.
+    int nk_max = 0;
+    double slice_mb = 0.0;
+    long maxM = 0;
+    for (int i = 0; i < p.nclasses; ++i) {
+        const long m = (long)p.B * p.cls[i].R * p.cls[i].C;
+        if (m <= 0) continue;
+        const int nk = cgs_ceil_div(p.cls[i].K, BK);
+        if (nk > nk_max) nk_max = nk;
+        if (m > maxM) maxM = m;
+        slice_mb += (double)m * p.Np * 4e-6;
+    }
+    const double tile = (BN == 128 ? 1.0 : 0.5) * (maxM <= 64 ? 0.5 : 1.0);
+    int best = 1;
+    double best_cost = 1e30;
+    for (long s = 2; s <= cap; ++s) {
+        const long cps = (nk_max + s - 1) / s;
+        if ((nk_max + cps - 1) / cps != s) continue;            // (the same slices with fewer empty ones exist as a smaller s)
+        const long load = (blocks * s + 255) / 256;
+        const double cost = (load == 1 ? 1.41 : (double)load) * (double)cps * tile + 0.3 * slice_mb * (double)s;
+        if (cost < best_cost) { best_cost = cost; best = (int)s; }
+    }
+    (void)target;
+    return best;
 }
 
 // Block tile of a launch (the row policy and the split-K decision are made): 128 x 128 or 128 x 64 (``wide``), 32- or 16-deep K tiles
