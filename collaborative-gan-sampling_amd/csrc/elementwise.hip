@@ -304,6 +304,9 @@ int cgs_refine_select2(const float* rows, float* best_rows, int Frows, const flo
     if (B <= 0 || F <= 0 || Frows <= 0 || B > 65535) return cgs_set_error(CGS_EINVAL, "refine_select2: B=%d F=%d Frows=%d", B, F, Frows);
     int bx = cgs_ceil_div(F > Frows ? F : Frows, 256 * 4);
     if (bx < 1) bx = 1;
+    // (every block of a selected sample takes a ticket at ONE address: config 5's 64x64x256 maps made 2048 blocks per sample, and the serialised
+    // atomics cost 145 us per step -- 5 % of its call; the copy loop strides over the grid, so 64 blocks per sample and tensor copy the same rows)
+    if (tickets && bx > 64) bx = 64;
     hipLaunchKernelGGL(refine_select_copy2_kernel, dim3(bx, B, 2), dim3(256), 0, (hipStream_t)stream, rows, best_rows, Frows, theta, best_theta, F, logit, forced,
                        step_index, best_logit, best_step, tickets);
     if (!tickets)
