@@ -179,6 +179,11 @@ __global__ __launch_bounds__(64 * NW, 2) void igemm_kernel(IgemmParams p) {
         q /= (unsigned)p.nclasses;
         wi = (q << 3) | xcd;
     }
+    // Split launches of several parity classes (9 / 6 / 6 / 4 taps: their K slices differ 2.25x in length): the dispatcher deals workgroups to the
+    // 256 CUs round-robin in launch order, so with class = blockIdx.y the two (or more) blocks of a CU are the SAME class of K slices z and
+    // z + 256 / (blocks per slice) -- heavy CUs and light CUs.  Every other round of 256 blocks takes the classes in reverse order (per K slice, so
+    // the (class, slice) pairs stay a permutation): a CU gets a long and a short block.
+    if (p.cls_flip && ((((unsigned)blockIdx.z * gridDim.x * gridDim.y) >> 8) & 1u)) cls_i = p.nclasses - 1 - cls_i;
     // tail split: the block ids from tail_from on (last class) are (tail tile, K slice) pairs -- tail_s consecutive ids per tile
     int tsplit = 1, tz = 0, ttile = 0;
     if (p.tail_s > 1 && cls_i == p.nclasses - 1 && wi >= (unsigned)p.tail_from) {
@@ -1285,7 +1290,14 @@ static int launch_cfg(const IgemmParams& p, hipStream_t s) {
         gx = (long)p.tail_from + (long)p.tail_n * p.tail_s;
     }
     unsigned gy = (unsigned)p.nclasses;
+    // (image-major launches of two rounds only: measured per stage at 64 / 128 / 256 images, profiles/r05_ai_class_flip_ab.txt -- dcgan64 at batch 64: 102.5 -> 89.0,
+    // 95.2 -> 82.4, 89.9 -> 77.5 us; the pixel-major launches of 128- and 256-image batches, whose tiles differ by pixel as well, lose up to 14 % with it)
+    {
+        const long total = gx * (long)p.nclasses * (p.splitk > 1 ? p.splitk : 1);
+        q.cls_flip = (p.splitk > 1 && p.nclasses > 1 && !p.pix_major && total > 256 && total <= 512) ? 1 : 0;
+    }
 #ifdef CGS_EXPERIMENT
+    if (getenv("CGS_CLS_FLIP")) q.cls_flip = q.cls_flip && atoi(getenv("CGS_CLS_FLIP")) != 0;
     if (getenv("CGS_CLS_INTER") && atoi(getenv("CGS_CLS_INTER")) && q.xcd_map == 1 && (mtiles % 8) == 0 && p.nclasses > 1 && p.tail_s <= 1 && p.splitk == 1 && !p.pix_major &&
         gx >= atol(getenv("CGS_CLS_INTER"))) {
         bool eq = true;

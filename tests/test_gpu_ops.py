@@ -792,3 +792,14 @@ def test_fused_logit_head_and_row_selects_equal_their_parts():
         assert all(torch.equal(u, v) for u, v in zip(a, e)) and not tickets.any()
         upd = (forced == 2) if forced is not None else (logit > best)
         assert torch.equal(c[3], torch.where(upd, torch.full_like(best, 3.0), torch.ones_like(best))) and upd.any() and not upd.all()
+    # maps of more than 64 x 1024 elements per sample (config 5's 64x64x256): the ticketed launch strides 64 blocks per sample over the rows
+    B2 = 5
+    rows, theta, logit, best = rnd((B2, 32, 32, 3), 8).to(d), rnd((B2, 48, 48, 64), 9).to(d), rnd((B2,), 10).to(d), rnd((B2,), 11).to(d)
+    a = [torch.zeros_like(rows), torch.zeros_like(theta), best.clone(), torch.ones(B2, device=d)]
+    c = [t.clone() for t in a]
+    tickets = torch.zeros(B2, dtype=torch.int32, device=d)
+    K.refine_select2(rows, a[0], theta, a[1], logit, None, 6, a[2], a[3])
+    K.refine_select2(rows, c[0], theta, c[1], logit, None, 6, c[2], c[3], tickets)
+    upd = logit > best
+    assert all(torch.equal(u, v) for u, v in zip(a, c)) and not tickets.any() and upd.any() and not upd.all()
+    assert torch.equal(c[1][upd], theta[upd]) and not c[1][~upd].any() and torch.equal(c[3], torch.where(upd, torch.full_like(best, 7.0), torch.ones_like(best)))
