@@ -78,3 +78,25 @@ def test_parameter_gradients_match_autograd_on_the_oracle():
         V[k].requires_grad_(False)
     ops.reset_variables()
 
+
+
+def test_training_mode_bn_updates_the_moving_averages_with_decay_09():
+    """nsgan/ops.py:19-26: contrib batch_norm(decay=0.9, updates_collections=None) moves moving_mean / moving_variance towards the BATCH
+    statistics (biased variance) in place at every training-mode call -- also during refinement, where D runs on batch statistics."""
+    from cgs_amd import ops
+    d = dev()
+    ops.reset_variables()
+    g = torch.Generator().manual_seed(5)
+    x = (torch.randn((6, 5, 5, 8), generator=g) * 2.0 + 0.7).float()
+    with ops.variable_scope("discriminator"):
+        ops.bn(x.to(d), is_training=True, scope="d_bn")
+    with ops.variable_scope("discriminator", reuse=True):
+        ops.bn(x.to(d), is_training=True, scope="d_bn", leak=0.2)
+    V = ops.variables()
+    mean, var = x.double().reshape(-1, 8).mean(0), x.double().reshape(-1, 8).var(0, unbiased=False)
+    mm, mv = torch.zeros(8, dtype=torch.float64), torch.ones(8, dtype=torch.float64)
+    for _ in range(2):
+        mm, mv = 0.9 * mm + 0.1 * mean, 0.9 * mv + 0.1 * var
+    assert torch.allclose(V["discriminator/d_bn/moving_mean"].cpu().double(), mm, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(V["discriminator/d_bn/moving_variance"].cpu().double(), mv, rtol=1e-5, atol=1e-6)
+    ops.reset_variables()
