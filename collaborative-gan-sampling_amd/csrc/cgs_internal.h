@@ -74,7 +74,7 @@ struct IgemmParams {
     float* slab;         // [class][split][M_c][Np]
     int tap_parity;      // VEC K order visits the taps even offsets first, then odd, per axis (stride-2 F direction)
     int xcd_map;         // block id -> (XCD, local index) decode: an m-tile's n-tiles run on one XCD (see igemm_kernel)
-    int cls_flip;        // split launches of several parity classes: every other round of 256 blocks takes the classes in reverse order (igemm_kernel)
+    int cls_flip;        // two-round launches of several parity classes: in the odd round every group of cls_flip consecutive classes runs in reverse order (0 = off; igemm_kernel)
     int uni;             // uniform-tile K loop allowed (host policy, see cgs_igemm_launch)
     int lpt;             // pixel-major only: m-tiles visit the pixels in perm[] order (most valid taps first)
     unsigned* sign_out;  // != null: sign bitmask of the stored output (layout: cgs_hip.h, "sign masks"); wide epilogue, N % 32 == 0, no split-K

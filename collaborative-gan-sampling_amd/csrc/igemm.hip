@@ -183,7 +183,12 @@ __global__ __launch_bounds__(64 * NW, 2) void igemm_kernel(IgemmParams p) {
     // 256 CUs round-robin in launch order, so with class = blockIdx.y the two (or more) blocks of a CU are the SAME class of K slices z and
     // z + 256 / (blocks per slice) -- heavy CUs and light CUs.  Every other round of 256 blocks takes the classes in reverse order (per K slice, so
     // the (class, slice) pairs stay a permutation): a CU gets a long and a short block.
-    if (p.cls_flip && ((((unsigned)blockIdx.z * gridDim.x * gridDim.y) >> 8) & 1u)) cls_i = p.nclasses - 1 - cls_i;
+    // (unsplit launches of two rounds, 128 blocks per class: round 0 holds classes 0, 1 and round 1 classes 2, 3 -- a CU's pair was (0, 2) or (1, 3),
+    // 15 against 10 taps; with the second round's classes swapped it is (0, 3) or (1, 2).  cls_flip = classes per group that is reversed.)
+    if (p.cls_flip && (((((unsigned)blockIdx.z * gridDim.y + (unsigned)cls_i) * gridDim.x) >> 8) & 1u)) {
+        const int grp = cls_i / p.cls_flip;
+        cls_i = grp * p.cls_flip + (p.cls_flip - 1 - (cls_i - grp * p.cls_flip));
+    }
     // tail split: the block ids from tail_from on (last class) are (tail tile, K slice) pairs -- tail_s consecutive ids per tile
     int tsplit = 1, tz = 0, ttile = 0;
     if (p.tail_s > 1 && cls_i == p.nclasses - 1 && wi >= (unsigned)p.tail_from) {
@@ -1293,11 +1298,19 @@ static int launch_cfg(const IgemmParams& p, hipStream_t s) {
     // (image-major launches of two rounds only: measured per stage at 64 / 128 / 256 images, profiles/r05_ai_class_flip_ab.txt -- dcgan64 at batch 64: 102.5 -> 89.0,
     // 95.2 -> 82.4, 89.9 -> 77.5 us; the pixel-major launches of 128- and 256-image batches, whose tiles differ by pixel as well, lose up to 14 % with it)
     {
+        // (the flip decides per CLASS range of gx blocks which round it lies in: those ranges must not straddle a round -- gx divides 256 --
+        // and a group of classes that is reversed must lie inside one round)
         const long total = gx * (long)p.nclasses * (p.splitk > 1 ? p.splitk : 1);
-        q.cls_flip = (p.splitk > 1 && p.nclasses > 1 && !p.pix_major && total > 256 && total <= 512) ? 1 : 0;
+        q.cls_flip = 0;
+        if (p.nclasses > 1 && !p.pix_major && total > 256 && total <= 512 && gx > 0 && (256 % gx) == 0 && p.tail_s <= 1) {
+            const long per_round = 256 / gx;                          // class ranges per round of 256 blocks
+            if (p.splitk > 1 && (per_round % p.nclasses) == 0) q.cls_flip = p.nclasses;                 // whole K slices per round: reverse all classes
+            else if (p.splitk == 1 && per_round < p.nclasses && (p.nclasses % per_round) == 0) q.cls_flip = (int)per_round;      // several rounds per slice
+        }
     }
 #ifdef CGS_EXPERIMENT
-    if (getenv("CGS_CLS_FLIP")) q.cls_flip = q.cls_flip && atoi(getenv("CGS_CLS_FLIP")) != 0;
+    if (getenv("CGS_CLS_FLIP") && atoi(getenv("CGS_CLS_FLIP")) == 0) q.cls_flip = 0;
+    if (getenv("CGS_CLS_FLIP") && atoi(getenv("CGS_CLS_FLIP")) == 2 && p.splitk == 1) q.cls_flip = 0;      // (2 = split launches only, as first adopted)
     if (getenv("CGS_CLS_INTER") && atoi(getenv("CGS_CLS_INTER")) && q.xcd_map == 1 && (mtiles % 8) == 0 && p.nclasses > 1 && p.tail_s <= 1 && p.splitk == 1 && !p.pix_major &&
         gx >= atol(getenv("CGS_CLS_INTER"))) {
         bool eq = true;
