@@ -81,10 +81,13 @@ THREE_CHANNEL = ("convt_rows_kernel", "conv_patch2_kernel", "conv_patch_kernel",
 
 
 def lib_stamp():
-    """Which library produced the line: the sha256 of the kernel sources the in-tree .so is built from (``lib.source_hash``: the key
-    profiles/traffic.json is valid for), the ABI version the loaded object reports, and whether CGS_LIB pointed the run at another build."""
+    """Which library produced the line: the sha256 of the kernel sources the LOADED .so was built from -- its embedded stamp
+    (``cgs_source_sha``, csrc/stamp.hip), not a hash of whatever sources lie beside it: the key profiles/traffic.json is valid for --,
+    whether that stamp differs from the tree (``stale``: only loadable at all under CGS_LIB / CGS_ALLOW_STALE), the ABI version the
+    loaded object reports, and whether CGS_LIB pointed the run at another build."""
     from cgs_amd import lib as L
-    return {"source_sha16": L.source_hash()[:16], "cgs_version": int(L.load().cgs_version()), "so": os.path.relpath(L.LIB_PATH, ROOT),
+    lib = L.load()
+    return {"source_sha16": L.built_from()[:16], "stale": L.stale, "cgs_version": int(lib.cgs_version()), "so": os.path.relpath(L.LIB_PATH, ROOT),
             "cgs_lib_override": bool(os.environ.get("CGS_LIB"))}
 
 
@@ -92,12 +95,12 @@ def _traffic_table():
     """profiles/traffic.json -- or {} when it was collected on other kernel sources than the ones this run executes (a stale
     number is worse than none), or when CGS_LIB points the run at some other build of the library."""
     try:
-        from cgs_amd.lib import source_hash
+        from cgs_amd.lib import built_from
         if os.environ.get("CGS_LIB"):
             return {}
         with open(TRAFFIC_JSON) as f:
             t = json.load(f)
-        return t if t.get("_source_sha256") == source_hash() else {}
+        return t if t.get("_source_sha256") == built_from() else {}
     except (OSError, ValueError):
         return {}
 
@@ -154,6 +157,7 @@ def profile_records(prof, prof_ms, step_ms, timing_note, with_traffic, prof_step
             "nominal": round(fl / ms / 1e9, 2), "nominal_frac": round(fl / ms / 1e9 / peak, 4),
             "traffic": tr, "algorithmic_bytes": int(nb / n), "traffic_over_algorithmic": round(tr / (nb / n), 3) if tr else None,
             "launches": n, "avg_launch_us": round(1e3 * ms / n, 2), "share_of_step": round(ms / prof_ms, 3), "timing": timing_note,
+            "profile_passes": {"kept": "median", "wall_ms": list(PROFILE_PASSES_MS)} if PROFILE_PASSES_MS else None,
             "flop_per_launch": round(ex / n, 0), "nominal_flop_per_launch": round(fl / n, 0),
             "step_executed_tflops": round(ex_total / prof_steps / step_ms / 1e9, 2),
             "step_executed_frac": round(ideal_ms / prof_steps / step_ms, 4),
@@ -166,6 +170,7 @@ def profile_records(prof, prof_ms, step_ms, timing_note, with_traffic, prof_step
     return roof, per, hbm, ex_total / prof_steps
 
 
+PROFILE_PASSES_MS = []          # walls of the last profile_one_step's three passes (the median one is the record)
 _CPU_THREADS = [None]          # the calibrated thread count of the headline's cpu_baseline, reused for the other configs
 
 
@@ -207,6 +212,7 @@ def cpu_baseline(arch, refine_steps, rate, seconds=15.0, max_batch=512):
     batch = int(min(max_batch, max(unit, unit * round(seconds / pilot))))
     dt = run(batch, refine_steps) if batch != unit else pilot
     return {"value": round(batch / dt, 3), "unit": "samples/s", "cores": best_n, "kind": "port",
+            "sample_short": f"oracle (torch-CPU fp32) {arch} batch {batch} K={refine_steps}, {dt:.1f} s, {best_n} of {ncpu} threads",
             "sample": f"oracle.collaborative_refine (torch-CPU fp32), {arch}, batch {batch}, K={refine_steps}, "
                       f"{dt:.1f} s wall, {best_n} of {ncpu} host threads (fastest of a 8/16/32/64/all calibration; a reported "
                       f"baseline that moves 10-20 % from run to run with the box's other tenants, never a target)"}
@@ -272,6 +278,7 @@ def cpu_baseline_synthetic2d(S, Ws, bs, x, real, B, Ksteps, rate, reps=20):
             S.refine_2d(fake, rb, d_fn, Ksteps, rate, "ladam")
         c = (time.time() - t) / reps
         return {"value": round(B / c, 1), "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+                "sample_short": f"oracle.refine_2d (torch-CPU D) batch {B} K={Ksteps}, {reps} reps",
                 "sample": f"oracle.refine_2d (refiner_cpu.manipulate_sample restated; torch-CPU D), batch {B}, K={Ksteps}, {reps} reps"}
     finally:
         torch.set_num_threads(keep)
@@ -292,7 +299,7 @@ def bench_synthetic2d(args, dev, rank, world):
                "roofline": None, "lib": lib_stamp()}
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_synthetic2d(S, Ws, bs, x, real, B, Ksteps, args.rate)
-        print(json.dumps(out), flush=True)
+        emit(out, args.detail)
 
 
 def profile_one_step(arch, P, B, G, Ksteps, rate, z1, dev, stream, by_layer=False, sync_bn=None, engine=None):
@@ -308,11 +315,12 @@ def profile_one_step(arch, P, B, G, Ksteps, rate, z1, dev, stream, by_layer=Fals
         with torch.cuda.stream(stream):
             eng.refine_from_z(z1, Ksteps, rate)                         # (untimed first pass: packs weights, sizes workspaces)
         torch.cuda.synchronize(dev)
-        # two profiled passes, the faster one kept: a single pass now and then catches a transient (round 5: one kernel at 1.5x its
-        # usual time in ONE pass of one run, 749 -> 1109 us, nothing of it in the timed region or in the rocprofv3 table of the same
-        # box) and the roofline record of a whole run should not hang on it; the averages are those of the kept pass
-        best = None
-        for _ in range(2):
+        # three profiled passes, the MEDIAN one (by wall time) kept: a single pass now and then catches a transient (round 5: one kernel
+        # at 1.5x its usual time in ONE pass of one run, 749 -> 1109 us, nothing of it in the timed region or in the rocprofv3 table of
+        # the same box); the fastest of several would bias the roofline upward against the mean-based headline it explains.
+        # The averages are those of the kept pass; `profile_passes` in the record lists all three walls.
+        passes = []
+        for _ in range(3):
             K.PROFILE, K.PROFILE_BY_LAYER = {}, by_layer
             tp = time.perf_counter()
             with torch.cuda.stream(stream):
@@ -320,9 +328,10 @@ def profile_one_step(arch, P, B, G, Ksteps, rate, z1, dev, stream, by_layer=Fals
             torch.cuda.synchronize(dev)
             ms = (time.perf_counter() - tp) * 1e3
             prof, K.PROFILE = K.PROFILE, None
-            if best is None or ms < best[1]:
-                best = (prof, ms)
-        prof, ms = best
+            passes.append((ms, prof))
+        passes.sort(key=lambda t: t[0])
+        ms, prof = passes[1]
+        PROFILE_PASSES_MS[:] = [round(t[0], 2) for t in passes]
     finally:
         K.PROFILE = None
         eng.use_graph = was_graph
@@ -371,7 +380,7 @@ def other_configs(dev, skip, want_cpu):
         del engines
         # (traffic: the PMC passes of THIS configuration at these very launch sizes, profiles/traffic.json `_by_arch`; null while the
         # table belongs to other kernel sources)
-        roof, _, hbm, _ = profile_records(prof, prof_ms, 1e3 * dt / steps, "an extra eager single-stream step (the faster of two passes)", True, traffic_arch=arch)
+        roof, _, hbm, _ = profile_records(prof, prof_ms, 1e3 * dt / steps, "an extra eager single-stream step (the median of three passes)", True, traffic_arch=arch)
         roof.pop("note")
         out[arch]["roofline"] = roof
         out[arch]["hbm"] = {k: {f: v[f] for f in ("avg_us", "achieved", "frac", "share_of_step", "traffic", "traffic_over_algorithmic")} for k, v in hbm.items()}
@@ -610,7 +619,7 @@ def bx6_line(args, P, B, G, Ksteps, z, dev, n_flight, streams, flops_per_sample)
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
     prof, prof_ms = profile_one_step(args.arch, P, B, G, Ksteps, args.rate, z[args.warmup], dev, streams[0], engine=engines[0])
-    roof, kern, _, ex_step = profile_records(prof, prof_ms, 1e3 * dt / args.steps, "an extra eager single-stream step right after this mode's timed steps (the faster of two passes)",
+    roof, kern, _, ex_step = profile_records(prof, prof_ms, 1e3 * dt / args.steps, "an extra eager single-stream step right after this mode's timed steps (the median of three passes)",
                                              args.arch == "dcgan64" and B == 1024 and G == 1)
     value = B * G * args.steps / dt
     return {"value": round(value, 2), "unit": "samples/s", "ms_per_step": round(1e3 * dt / args.steps, 3), "steps": args.steps,
@@ -622,6 +631,87 @@ def bx6_line(args, P, B, G, Ksteps, z, dev, n_flight, streams, flops_per_sample)
                         "size of an fp32 fma chain's own; the full parity suite (operator tests at 2e-5, reference goldens, full-size "
                         "oracle cases) runs in this mode too (tests/conftest.py, `contraction`): identical bars except two that measure chaotic "
                         "amplification of rounding over K steps (K-step image drift 60x instead of 25x the trajectory tolerance; K=50 trajectory 1.25e-2)"}
+
+
+LINE_BUDGET = 6000          # bytes: the driver keeps 8 kB of stdout tail (BENCH_r05's 22 kB line was cut and parsed as null)
+DETAIL_PATH = os.path.join(ROOT, "bench_detail.json")
+ROOF_KEYS = ("kernel", "bound", "achieved", "peak", "unit", "frac", "nominal_frac", "traffic", "algorithmic_bytes", "traffic_over_algorithmic",
+             "launches", "avg_launch_us", "share_of_step", "step_executed_frac", "profile_passes")
+DIST_KEYS = ("backend", "world_size", "ranks_seen", "pool_bytes", "pool_buffers_per_rank", "pool_bytes_per_rank_total", "device_mem_free_before_pools",
+             "device_mem_total", "gathers_per_step", "gather_ms_per_step", "per_rank_samples_per_s", "hipgraph_ranks", "pool_rows_match_ranks",
+             "pool_rank_sums_distinct", "rank0_profile_step_wall_s")
+
+
+def _short_cpu(c):
+    """cpu_baseline with a sample description of <= 120 characters (the long form stays in the sidecar)."""
+    return {"value": c["value"], "unit": c["unit"], "cores": c["cores"], "kind": c["kind"], "sample": str(c.get("sample_short") or c["sample"])[:120]}
+
+
+def compact_line(full, detail_path=None):
+    """The ONE stdout line the driver parses, from the full record of a run: the contract keys, the dominant kernel's `roofline`,
+    `cpu_baseline`, `lib`, `dist` (N > 1) and a `summary` of ONE number per extra measurement.  Everything else (kernel / hbm tables,
+    per-configuration rooflines, notes) lives in the sidecar file the line names (`detail`).  Pure function of the record: the CPU suite
+    holds it to LINE_BUDGET on a canned record (tests/test_host_cpu.py)."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "ms_per_step_median", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "algorithmic_tflops", "executed_tflops")
+    line = {k: full[k] for k in keep if k in full}
+    cfg = dict(full.get("config", {}))
+    if len(cfg.get("workload", "")) > 240:
+        cfg["workload"] = cfg["workload"][:240]
+    if "hipgraph_fallback" in cfg:
+        cfg["hipgraph_fallback"] = str(cfg["hipgraph_fallback"])[:160]
+    line["config"] = cfg
+    r = full.get("roofline")
+    line["roofline"] = {k: r[k] for k in ROOF_KEYS if k in r} if r else None
+    if full.get("cpu_baseline"):
+        line["cpu_baseline"] = _short_cpu(full["cpu_baseline"])
+    if "lib" in full:
+        line["lib"] = full["lib"]
+    if full.get("dist"):
+        line["dist"] = {k: full["dist"][k] for k in DIST_KEYS if k in full["dist"]}
+    s = {}
+    if "bx6" in full:
+        s["bx6"] = {"samples_per_s": full["bx6"]["value"], "roofline_frac": full["bx6"]["roofline"]["frac"],
+                    "step_executed_frac": full["bx6"]["roofline"]["step_executed_frac"]}
+    for arch, o in full.get("other_configs", {}).items():
+        e = {"samples_per_s": o["samples_per_s"]}
+        if o.get("roofline"):
+            e["roofline_frac"] = o["roofline"]["frac"]
+            e["step_executed_frac"] = o["roofline"]["step_executed_frac"]
+        if o.get("bx6"):
+            e["bx6_samples_per_s"] = o["bx6"]["samples_per_s"]
+        if o.get("cpu_baseline"):
+            e["cpu_samples_per_s"] = o["cpu_baseline"]["value"]
+        s.setdefault("other_configs", {})[arch] = e
+    for name, o in full.get("class_surface", {}).items():
+        if isinstance(o, dict):
+            s.setdefault("class_surface", {})[name] = {k: o[k]["samples_per_s"] for k in ("engine", "generic", "fused") if k in o}
+    if "f1" in full:
+        s["f1"] = {"accepted_samples_per_s": full["f1"]["accepted_samples_per_s"], "proposals_per_s": full["f1"]["proposals_per_s"],
+                   "efficiency": full["f1"]["efficiency"]}
+    if "shaping" in full:
+        s["shaping_iteration_ms"] = {a: o["iteration_ms"] for a, o in full["shaping"].items() if isinstance(o, dict)}
+    if s:
+        line["summary"] = s
+    if detail_path:
+        line["detail"] = detail_path
+    return line
+
+
+def emit(full, detail_path):
+    """Write the full record to the sidecar (best effort: a read-only tree costs the sidecar, not the line) and print the compact line."""
+    rel = None
+    if detail_path:
+        try:
+            with open(detail_path, "w") as f:
+                json.dump(full, f, indent=1)
+            rel = os.path.relpath(detail_path, ROOT)
+        except OSError as ex:
+            print(f"[bench] could not write {detail_path}: {ex}", file=sys.stderr, flush=True)
+    line = compact_line(full, rel)
+    text = json.dumps(line)
+    assert len(text) < LINE_BUDGET + 2000, f"bench line grew to {len(text)} bytes: move the new object into the sidecar"
+    print(text, flush=True)
 
 
 def self_launch(n_gpus):
@@ -678,6 +768,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the mnist / dcgan32 / synthetic2d samples/s that are measured after the headline's timed region")
+    ap.add_argument("--detail", default=DETAIL_PATH,
+                    help="sidecar file for the full record (kernel / hbm tables, per-configuration rooflines, class surface, f1, shaping: everything the "
+                         "compact stdout line summarises in one number each); '' = do not write it")
     ap.add_argument("--by-layer", action="store_true", help="key the per-kernel timing records by layer shape too (diagnostic)")
     args = ap.parse_args()
     if args.steps <= 0:
@@ -833,7 +926,7 @@ def main():
         prof, prof_ms = profile_one_step(args.arch, P, B, G, Ksteps, args.rate, z[args.warmup], dev, streams[0], args.by_layer, sync,
                                          engine=engines[0])
         prof_wall_s = time.perf_counter() - t_prof       # (ranks 1.. wait in the all-gather below meanwhile: must stay far below the collective timeout)
-        prof_note = "HIP events around every launch of an extra single-stream step right after the timed region (the faster of two passes)" + (" (launched eagerly; the timed region replays hipGraphs)" if args.graph else "")
+        prof_note = "HIP events around every launch of an extra single-stream step right after the timed region (the median of three passes)" + (" (launched eagerly; the timed region replays hipGraphs)" if args.graph else "")
     dist_rec = None
     if use_dist:
         # what the collective layer really saw (all ranks take part in these two small all-gathers)
@@ -903,7 +996,7 @@ def main():
             out["shaping"] = shaping_record(dev)
         if cpu is not None:
             out["cpu_baseline"] = cpu
-        print(json.dumps(out), flush=True)
+        emit(out, args.detail)
     if use_dist:
         dist.destroy_process_group()
 

@@ -23,6 +23,7 @@ _ll = C.c_longlong
 # name -> (restype, argtypes); mirrors include/cgs_hip.h one to one
 SIGNATURES = {
     "cgs_version": (_i, []),
+    "cgs_source_sha": (C.c_char_p, []),
     "cgs_last_error": (C.c_char_p, []),
     "cgs_last_kernel": (C.c_char_p, []),
     "cgs_last_executed_flops": (C.c_double, []),
@@ -93,6 +94,8 @@ SIGNATURES = {
 }
 
 _lib = None
+stale = None          # after load(): False = the library's embedded source stamp equals the sources beside it; True = it differs (only
+                      # tolerated under CGS_LIB / CGS_ALLOW_STALE); None = no sources beside the library to compare with (a binary-only install)
 
 
 class CgsError(RuntimeError):
@@ -120,8 +123,36 @@ def load():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)          # AttributeError if the ABI and this table diverge
             fn.restype, fn.argtypes = res, args
+        _check_stamp(lib)
         _lib = lib
     return _lib
+
+
+class StaleLibraryError(CgsError):
+    """The prebuilt library was built from other kernel sources than the ones shipped beside it."""
+
+
+def built_from():
+    """The sha256 of the sources the LOADED library was built from (its embedded stamp, ``cgs_source_sha``)."""
+    return load().cgs_source_sha().decode()
+
+
+def _check_stamp(lib, here=None):
+    """Compare the library's embedded source stamp with the sources found beside it.  A mismatch means the git-ignored prebuilt .so
+    is not the build of this tree (every number measured on it would be filed under the wrong sources): refused, unless the run
+    points at another build on purpose (CGS_LIB: experiment builds; CGS_ALLOW_STALE=1) -- then ``lib.stale`` records it and bench.py
+    stamps it into its line."""
+    global stale
+    embedded = lib.cgs_source_sha().decode()
+    have = source_hash(here)
+    if have is None:
+        stale = None
+        return
+    stale = embedded != have
+    if stale and not (os.environ.get("CGS_LIB") or os.environ.get("CGS_ALLOW_STALE")):
+        raise StaleLibraryError(f"{LIB_PATH} was built from sources {embedded[:16]}..., the tree beside it hashes to {have[:16]}...: rebuild it "
+                                "(`make -C collaborative-gan-sampling_amd/csrc` or `python -c 'import __graft_entry__ as g; g.build()'`); "
+                                "CGS_ALLOW_STALE=1 loads it anyway")
 
 
 def call(name, *args):
@@ -164,15 +195,19 @@ def bn_ws_bytes(m, c):
     return int(load().cgs_bn_ws_bytes(m, c))
 
 
-def source_hash():
-    """sha256 over the kernel sources (csrc/*.hip, *.h and include/cgs_hip.h): identifies the code measured numbers such as
-    profiles/traffic.json belong to (bench.py reports ``roofline.traffic`` only while it matches)."""
+def source_hash(here=None):
+    """sha256 over the kernel sources beside the library (csrc/*.hip, *.h and include/cgs_hip.h; the Makefile embeds the same hash
+    into the library it builds: ``built_from``): identifies the code measured numbers such as profiles/traffic.json belong to.
+    None when there are no sources (a binary-only install)."""
     import glob
     import hashlib
+    here = here or _HERE
     h = hashlib.sha256()
-    files = sorted(glob.glob(os.path.join(_HERE, "csrc", "*.hip")) + glob.glob(os.path.join(_HERE, "csrc", "*.h")))
-    files.append(os.path.join(os.path.dirname(_HERE), "include", "cgs_hip.h"))
-    for f in files:
+    files = sorted(glob.glob(os.path.join(here, "csrc", "*.hip")) + glob.glob(os.path.join(here, "csrc", "*.h")))
+    header = os.path.join(os.path.dirname(here), "include", "cgs_hip.h")
+    if not files or not os.path.exists(header):
+        return None
+    for f in files + [header]:
         h.update(os.path.basename(f).encode())
         with open(f, "rb") as fh:
             h.update(fh.read())

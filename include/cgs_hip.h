@@ -55,6 +55,10 @@ extern "C" {
 #define CGS_DECONV_BWD_DATA 3   /* its input gradient                  sampling/collaborator.py:31 */
 
 int cgs_version(void);
+/* sha256 (64 hex digits) of the kernel sources this library was built from (every .hip and .h file of csrc/, then include/cgs_hip.h), embedded at
+ * build time (csrc/Makefile, csrc/stamp.hip).  The host binding refuses a library whose stamp differs from the sources it ships with
+ * (cgs_amd/lib.py::load); bench.py reports this embedded value, so a measured number names the code that produced it. */
+const char* cgs_source_sha(void);
 const char* cgs_last_error(void);
 /* Name of the compute kernel the calling thread's most recent conv-family call launched (for profiling). */
 const char* cgs_last_kernel(void);

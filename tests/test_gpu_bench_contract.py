@@ -22,19 +22,40 @@ def free_port():
         return so.getsockname()[1]
 
 
-def run_bench(*extra):
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", *extra], cwd=ROOT, capture_output=True,
-                         text=True, timeout=900)
+LINE_BUDGET = 6000          # bytes (bench.LINE_BUDGET): the driver keeps 8 kB of stdout tail
+
+
+def run_bench(*extra, detail=None):
+    """One `python bench.py --gpus 1 ...` run -> the ONE stdout line (held to the size budget), and with ``detail`` the sidecar record too."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", *extra] + (["--detail", str(detail)] if detail else ["--detail", ""])
+    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, out.stdout
-    return json.loads(lines[0])
+    assert len(lines) == 1 and out.stdout.strip().splitlines()[-1] == lines[0], out.stdout
+    assert len(lines[0]) < LINE_BUDGET, len(lines[0])
+    line = json.loads(lines[0])
+    if detail:
+        with open(detail) as f:
+            return line, json.load(f)
+    return line
 
 
-def test_bench_line_small_config():
-    d = run_bench("--arch", "mnist", "--steps", "2", "--warmup", "1", "--refine-steps", "5")
+def test_bench_line_small_config(tmp_path):
+    """The compact line (contract keys + roofline + cpu_baseline + lib + one-number summary, < 6 kB: VERDICT r5 #1) and the full record
+    in the sidecar it names."""
+    line, d = run_bench("--arch", "mnist", "--steps", "2", "--warmup", "1", "--refine-steps", "5", detail=tmp_path / "bench_detail.json")
+    for k in REQUIRED + ["lib", "summary", "detail"]:
+        assert k in line, k
     for k in REQUIRED:
         assert k in d, k
+    assert line["value"] == d["value"] and line["ms_per_step"] == d["ms_per_step"] and line["roofline"]["frac"] == d["roofline"]["frac"]
+    assert "kernels" not in line and "hbm" not in line and "other_configs" not in line and "note" not in line["roofline"]
+    assert len(line["cpu_baseline"]["sample"]) <= 120 and line["cpu_baseline"]["value"] == d["cpu_baseline"]["value"]
+    sm = line["summary"]
+    assert set(sm["other_configs"]) == {"dcgan32", "cyclegan256", "synthetic2d"} and set(sm["class_surface"]) >= {"dcgan64", "mnist", "dcgan32"}
+    assert sm["other_configs"]["dcgan32"]["samples_per_s"] == d["other_configs"]["dcgan32"]["samples_per_s"]
+    assert sm["f1"]["accepted_samples_per_s"] == d["f1"]["accepted_samples_per_s"] and set(sm["shaping_iteration_ms"]) == {"mnist", "dcgan64"}
+    assert d["roofline"]["profile_passes"]["kept"] == "median" and len(d["roofline"]["profile_passes"]["wall_ms"]) == 3
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True
     assert d["unit"] == "samples/s" and d["value"] > 0 and d["dtype"] == "f32" and d["data"] == "synthetic"
     assert "workload" in d["config"] and "model" not in d["config"]

@@ -284,6 +284,45 @@ def test_c_abi_library_exports_every_declared_symbol():
     assert lib.bn_ws_bytes(1000, 128) > 0
 
 
+def test_the_library_is_tied_to_the_sources_it_was_built_from(tmp_path, monkeypatch):
+    """the prebuilt .so is git-ignored and travels to the GPU box as a file, so nothing used to stop a stale binary from
+    being measured under the hash of the sources lying next to it.  The Makefile embeds sha256(sources) into the library
+    (``cgs_source_sha``, csrc/stamp.hip); ``lib.load`` compares it with the tree and refuses a mismatch.  Here: the in-tree library
+    matches its tree; against a temp copy of the sources with one touched .hip file the check raises (and records ``stale`` instead
+    under CGS_ALLOW_STALE / CGS_LIB); a binary-only install (no sources) skips the comparison."""
+    import shutil
+    from cgs_amd import lib
+    l = lib.load()
+    emb = l.cgs_source_sha().decode()
+    assert re.fullmatch(r"[0-9a-f]{64}", emb) and emb == lib.source_hash() == lib.built_from() and lib.stale is False
+    pkg = tmp_path / "pkg"
+    shutil.copytree(os.path.join(ROOT, "collaborative-gan-sampling_amd", "csrc"), pkg / "csrc", ignore=shutil.ignore_patterns("*.o", ".source_sha"))
+    shutil.copytree(os.path.join(ROOT, "include"), tmp_path / "include")
+    assert lib.source_hash(str(pkg)) == emb                            # the copy hashes like the tree ...
+    lib._check_stamp(l, here=str(pkg))
+    assert lib.stale is False
+    with open(pkg / "csrc" / "elementwise.hip", "a") as f:             # ... until a kernel source moves on
+        f.write("\n// touched\n")
+    assert lib.source_hash(str(pkg)) != emb
+    monkeypatch.delenv("CGS_LIB", raising=False)
+    monkeypatch.delenv("CGS_ALLOW_STALE", raising=False)
+    with pytest.raises(lib.StaleLibraryError, match="rebuild"):
+        lib._check_stamp(l, here=str(pkg))
+    assert lib.stale is True
+    monkeypatch.setenv("CGS_ALLOW_STALE", "1")
+    lib._check_stamp(l, here=str(pkg))                                  # tolerated on request, and recorded
+    assert lib.stale is True
+    # the Makefile of the touched copy would stamp the NEW hash: same file list, same byte order as lib.source_hash
+    import subprocess
+    sha = subprocess.run(["make", "-C", str(pkg / "csrc"), "-n", "stamp.o"], capture_output=True, text=True).stdout
+    assert lib.source_hash(str(pkg)) in sha, sha[-400:]
+    lib._check_stamp(l, here=str(tmp_path / "nothing_here"))            # binary-only install: nothing to compare with
+    assert lib.stale is None
+    monkeypatch.delenv("CGS_ALLOW_STALE")
+    lib._check_stamp(l)
+    assert lib.stale is False
+
+
 def test_contraction_mode_is_per_thread_host_state():
     """cgs_set_contraction (include/cgs_hip.h): thread-local, validated, and the family query answers for the mode in force --
     host arithmetic only (no launch)."""
@@ -439,6 +478,61 @@ def test_bench_self_launches_its_ranks_as_child_processes(monkeypatch):
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
     assert cmd[-6:] == ["--gpus", "2", "--steps", "2", "--warmup", "1"] and cmd[-7].endswith("bench.py")
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_bench_final_line_stays_small_and_carries_the_contract(tmp_path, capsys):
+    """BENCH_r05.json parsed as null because the one stdout line had grown to 22 kB (the driver keeps 8 kB of tail).
+    ``bench.compact_line`` builds the line from the full record; here from a canned one -- round 5's 22 kB line, the largest record a
+    default run has produced, plus a `dist` object as an N > 1 run adds -- it must stay under ``LINE_BUDGET`` (6 kB), keep every
+    contract key, the dominant kernel's roofline and the cpu_baseline, summarise every extra in one number, and ``emit`` must write
+    the full record to the sidecar the line names."""
+    import importlib
+    import json
+    import sys
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    canned = os.path.join(ROOT, "profiles", "r05_ag_final_default_hipgraph_bench.log")
+    full = json.loads([l for l in open(canned) if l.startswith("{")][-1])
+    assert len(json.dumps(full)) > 20000                                   # (the record that did not parse)
+    full["dist"] = {"backend": "nccl", "world_size": 8, "ranks_seen": 8, "devices": "one per rank", "pool_bytes": 402653184, "pool_buffers_per_rank": 2,
+                    "pool_bytes_per_rank_total": 805306368, "device_mem_free_before_pools": 300000000000, "device_mem_total": 309220868096,
+                    "gathers_per_step": 1, "gather_ms_per_step": 2.3012, "gather": "all_gather_into_tensor on the step's stream, HIP events around it",
+                    "per_rank_samples_per_s": [6501.2, 6733.9], "hipgraph_ranks": 8, "pool_rows_match_ranks": True, "pool_rank_sums_distinct": True,
+                    "rank0_profile_step_wall_s": 1.234}
+    full["config"]["hipgraph_fallback"] = "RuntimeError: " + "x" * 400
+    line = bench.compact_line(full, "bench_detail.json")
+    text = json.dumps(line)
+    assert len(text) < bench.LINE_BUDGET == 6000, len(text)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "ms_per_step_median", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline", "lib", "dist", "summary", "detail"):
+        assert k in line, k
+    assert line["value"] == full["value"] and line["ms_per_step"] == full["ms_per_step"] and "workload" in line["config"]
+    r = line["roofline"]
+    for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "nominal_frac", "traffic", "algorithmic_bytes", "traffic_over_algorithmic",
+              "launches", "avg_launch_us", "share_of_step", "step_executed_frac"):
+        assert r[k] == full["roofline"][k], k
+    assert "note" not in r and "timing" not in r
+    c = line["cpu_baseline"]
+    assert set(c) == {"value", "unit", "cores", "kind", "sample"} and len(c["sample"]) <= 120 and c["value"] == full["cpu_baseline"]["value"]
+    s = line["summary"]
+    assert s["bx6"]["samples_per_s"] == full["bx6"]["value"]
+    assert set(s["other_configs"]) == {"mnist", "dcgan32", "cyclegan256", "synthetic2d"}
+    for a in ("mnist", "dcgan32", "cyclegan256"):
+        assert s["other_configs"][a]["samples_per_s"] == full["other_configs"][a]["samples_per_s"]
+        assert s["other_configs"][a]["step_executed_frac"] == full["other_configs"][a]["roofline"]["step_executed_frac"]
+    assert s["class_surface"]["mnist"] == {k: full["class_surface"]["mnist"][k]["samples_per_s"] for k in ("engine", "generic", "fused")}
+    assert s["f1"]["accepted_samples_per_s"] == full["f1"]["accepted_samples_per_s"]
+    assert s["shaping_iteration_ms"] == {"mnist": full["shaping"]["mnist"]["iteration_ms"], "dcgan64": full["shaping"]["dcgan64"]["iteration_ms"]}
+    # emit: ONE stdout line (the compact one), the full record in the sidecar
+    side = tmp_path / "detail.json"
+    bench.emit(full, str(side))
+    out = [l for l in capsys.readouterr().out.splitlines() if l.strip()]
+    assert len(out) == 1 and len(out[0]) < bench.LINE_BUDGET and json.loads(out[0])["value"] == full["value"]
+    assert json.loads(side.read_text())["other_configs"]["mnist"]["roofline"] == full["other_configs"]["mnist"]["roofline"]
+    # a tree that cannot be written costs the sidecar, never the line
+    bench.emit(full, str(tmp_path / "no_such_dir" / "detail.json"))
+    cap = capsys.readouterr()
+    assert "detail" not in json.loads(cap.out.strip()) and "could not write" in cap.err
 
 
 def test_tf_checkpoint_converter_runs_against_the_checkpoint_reader_interface(tmp_path, monkeypatch):

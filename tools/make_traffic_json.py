@@ -70,7 +70,7 @@ def main():
         wrows += [r for r in wrows2 if "igemm_bx6" in r["Kernel_Name"]]
     out = table(F, W)
     sys.path.insert(0, ROOT)
-    from cgs_amd.lib import source_hash
+    from cgs_amd.lib import source_hash  # (== the stamp embedded in the library built from this tree: lib.built_from())
     out["_source_sha256"] = source_hash()        # bench.py prints roofline.traffic = null once the kernel sources move on
     out["_tag"] = tag
     out["_by_arch"] = by_arch
