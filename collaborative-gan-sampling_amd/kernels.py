@@ -119,6 +119,9 @@ class _WsCache:
         self._d = {}
         self._family = {}
         self.epoch = 0        # bumped by invalidate(): engines compare it with the epoch their packed copies / folded affines belong to
+        self.clears = 0       # bumped by clear()
+        self.record = None    # a list: every weight tensor asked for is appended as a weak reference (the generic path's hipGraph capture
+                              # learns which weights its recorded program reads, sampling/collaborator.py::_GenericGraph)
 
     def plan(self, op, B, H, W, cin, ho, wo, cout, kh, kw, sh, sw, epilogue):
         """(kernel family, workspace bytes) of a call; asked of the library once per distinct call signature."""
@@ -139,6 +142,8 @@ class _WsCache:
         ``ptrs``: every device pointer of the call; if one is not 16-byte aligned the library may pick another family than
         the planned one, so such calls get a scratch workspace and always re-pack."""
         fam, nbytes = self.plan(op, bhw[0], bhw[1], bhw[2], cin, out_hw[0], out_hw[1], cout, kh, kw, sh, sw, epilogue)
+        if self.record is not None:
+            self.record.append(weakref.ref(w))
         aligned = not any(p is not None and (p & 15) for p in ptrs)
         if not aligned:
             fam = -1
@@ -169,6 +174,7 @@ class _WsCache:
 
     def clear(self):
         self._d.clear()
+        self.clears += 1      # (the buffers a captured generic-path hipGraph points into are gone: it compares this counter)
 
 
 WS = _WsCache()

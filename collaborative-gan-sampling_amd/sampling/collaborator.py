@@ -16,8 +16,14 @@ Execution paths (both all-HIP, no CPU fallback; ``refiner.path`` says which one 
              effects that merely evaluates to BCE-vs-ones must set ``refiner.force_generic = True``.
   * generic: any other callables built from ``cgs_amd.ops``; the loop below differentiates them with
              ``torch.autograd`` (each op's backward-data is a HIP kernel) and applies the fused
-             update / select kernels.  Several times slower at small batches (launch-bound): the first fall to this
-             path warns once with the reason.
+             update / select kernels.  Nothing is fused across layers; the first fall to this path warns once with the
+             reason.  With ``use_graph`` (default) the K-step loop of a (shape, K, mode, rate, clip) is CAPTURED into a
+             hipGraph during its second call and replayed from then on (round 6): the reference's ``build_refiner`` is
+             itself a graph BUILDER -- it calls ``discriminator`` / ``feature_to_data`` / ``func_loss`` K+1 times while the TF graph
+             is built and ``sess.run`` replays that graph (sampling/collaborator.py:41-88, nsgan/GAN.py:182-183,270) -- so
+             "the callables' Python runs once, the recorded device program runs per batch" is the reference's own contract.
+             ``ops.bn``'s moving-average update is part of the recorded program; a capture that is refused (a callable that
+             synchronises with the host, say) falls back to eager launches in the same process and ``graph_fallback`` says why.
 
 ``refiner.logical_batch = b`` (extension): ``build_refiner(feature[G*b], ...)`` is G reference calls at the reference's own
 batch size b (nsgan/main.py:32: 64) in ONE launch per layer -- D's batch statistics per logical batch (nsgan/GAN.py:175), the
@@ -52,6 +58,9 @@ class Refiner():
         self.indices_batch = None       # last probabilistic draw
         self.logical_batch = None       # b: build_refiner's rows are consecutive batches of b samples, each with the reference's per-batch
                                         # semantics (batch statistics, index draw); None = the rows are ONE batch (the reference's call)
+        self._generic_graphs = {}       # generic path: (shape, K, mode, rate, method, clip) -> _GenericGraph (captured loop + its static buffers)
+        self._generic_seen = set()      # ... keys that already ran once eagerly (the capture happens at the SECOND call of a key)
+        self._gstream = None            # ... the side stream the loops are warmed up and captured on (packed-weight workspaces are per stream)
         self.force_generic = False      # True: never take the engine (e.g. a func_loss with a custom backward that evaluates to BCE-vs-ones)
         self.why_generic = None         # why the last engine detection said no (None while the engine is taken)
 
@@ -235,19 +244,55 @@ class Refiner():
             warnings.warn("cgs_amd Refiner: this wiring runs on the generic (ops + autograd) path, several times slower than the fused "
                           f"engine at small batches -- {self.why_generic}", RuntimeWarning, stacklevel=2)
         if G == 1:
-            return self._build_generic(fake_feature, mode, self.indices_batch if mode == 'probabilistic' else None)
+            return self._run_generic(fake_feature, mode, self.indices_batch if mode == 'probabilistic' else None)
         b = B // G
         outs, attrs = [], {k: [] for k in ("default_logit", "optimal_logit", "optimal_step", "optimal_feature")}
         for j in range(G):                                    # G reference calls, one after the other
             idx = self.indices_batch[j * b:(j + 1) * b] if mode == 'probabilistic' else None
-            outs.append(self._build_generic(fake_feature[j * b:(j + 1) * b], mode, idx))
+            outs.append(self._run_generic(fake_feature[j * b:(j + 1) * b], mode, idx))
             for k in attrs:
                 attrs[k].append(getattr(self, k))
         for k, v in attrs.items():
             setattr(self, k, torch.cat(v))
         return torch.cat(outs)
 
-    def _build_generic(self, fake_feature, mode, indices):
+    # -- generic path: eager, or captured into a hipGraph and replayed ------------------------------
+    _ATTRS = ("default_logit", "optimal_logit", "optimal_step", "optimal_feature")
+
+    def _run_generic(self, fake_feature, mode, indices):
+        """One reference call on the generic path.  First call of a (shape, K, mode, rate, method, clip): eager (creates variables,
+        packs weights, sizes workspaces).  Second call: eager once more on the refiner's side stream (so the per-stream packed-weight
+        workspaces exist there), then the same loop CAPTURED on that stream; this and every later call replay the hipGraph.  The
+        graph is dropped when a weight it reads moves on (in-place update, ``ops.set_variables``, ``K.WS.invalidate``)."""
+        dev = fake_feature.device
+        if not (self.use_graph and dev.type == "cuda"):
+            return self._build_generic(fake_feature, mode, indices)
+        key = (tuple(fake_feature.shape), dev.index, self.forward_steps, mode, float(self.optimizer.lambda_), self.optimizer.method,
+               self.vmin, self.vmax)
+        gg = self._generic_graphs.get(key)
+        if gg is not None and not gg.valid():
+            del self._generic_graphs[key]               # a weight moved on: the recorded program reads stale packed copies
+            gg = None
+        if gg is None:
+            if key not in self._generic_seen:
+                self._generic_seen.add(key)
+                return self._build_generic(fake_feature, mode, indices)
+            try:
+                gg = _GenericGraph(self, fake_feature, mode)
+            except L.GraphCaptureError as ex:
+                self.graph_fallback = str(ex)
+                self.use_graph = False
+                try:
+                    torch.cuda.synchronize(dev)
+                except Exception:                                 # noqa: BLE001
+                    pass
+                return self._build_generic(fake_feature, mode, indices)
+            self._generic_graphs[key] = gg
+        return gg.run(self, fake_feature, indices)
+
+    def _build_generic(self, fake_feature, mode, indices, forced=None):
+        """collaborator.py:41-88 launched kernel by kernel.  ``forced`` (captured form): the device buffer the probabilistic step
+        indices are read from (filled before every replay) instead of a fresh upload of ``indices``."""
         K_steps = self.forward_steps
         self.current_feature = fake_feature.detach().clone().contiguous()
         self.current_logit, self.forward_grad = self.compute_forward_logits_and_grad(self.current_feature)
@@ -255,8 +300,7 @@ class Refiner():
         self.optimal_feature = self.current_feature.clone()
         self.optimal_logit = self.current_logit.clone().contiguous()
         self.optimal_step = torch.ones_like(self.optimal_logit)
-        forced = None
-        if mode == 'probabilistic':
+        if mode == 'probabilistic' and forced is None:
             forced = torch.as_tensor(indices, dtype=torch.int32).to(fake_feature.device)
 
         for i in range(K_steps):
@@ -271,3 +315,73 @@ class Refiner():
         self.optimizer.reset_moving_average()
         with torch.no_grad():
             return self.feature_to_data(self.optimal_feature)
+
+
+class _GenericGraph:
+    """The generic path's K-step loop of one call signature as a hipGraph: static input / index buffers, the loop's tensors in the
+    graph's private pool, the results copied out after every replay."""
+
+    def __init__(self, refiner, feature, mode):
+        import gc
+        dev = feature.device
+        self.dev = dev
+        self.feature = torch.empty_like(feature)                       # static input: filled before every replay
+        self.forced = torch.zeros(feature.shape[0], dtype=torch.int32, device=dev) if mode == 'probabilistic' else None
+        if refiner._gstream is None:
+            refiner._gstream = torch.cuda.Stream(dev)
+        st = refiner._gstream
+        cur = torch.cuda.current_stream(dev)
+        self.feature.copy_(feature)
+        st.wait_stream(cur)
+        # eager pass on the capture stream: packs the weights into THIS stream's workspaces, recording which weight tensors the
+        # callables read (their versions are what ``valid`` watches); its results are discarded (the replay below recomputes them)
+        K.WS.record = []
+        try:
+            with torch.cuda.stream(st):
+                refiner._build_generic(self.feature, mode, None, forced=self.forced)
+            torch.cuda.synchronize(dev)
+            self.weights = [(r, r()._version) for r in {id(r()): r for r in K.WS.record if r() is not None}.values()]
+        finally:
+            K.WS.record = None
+        from .. import ops
+        gc_was_on = gc.isenabled()
+        gc.disable()                     # (no finalizer that reaches HIP inside a capture: engine.RefineEngine.refine has the story)
+        try:
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph, stream=st, capture_error_mode="thread_local"):
+                img = refiner._build_generic(self.feature, mode, None, forced=self.forced)
+            self.out = (img,) + tuple(getattr(refiner, k) for k in Refiner._ATTRS)
+        except L.CgsError:
+            raise
+        except Exception as ex:          # noqa: BLE001 (HIP / allocator / a callable that synchronises refused the capture)
+            raise L.GraphCaptureError(f"{type(ex).__name__}: {str(ex)[:300]}") from ex
+        finally:
+            if gc_was_on:
+                gc.enable()
+        cur.wait_stream(st)
+        # the capture pass bumped no versions on the device, but in-place ops recorded in it (ops.bn's moving averages) bumped the
+        # tensors' version counters on the host: the state to compare with is the one AFTER the capture
+        self.weights = [(r, r()._version) for r, _ in self.weights]
+        self.stamp = (K.WS.epoch, K.WS.clears, ops.generation())
+
+    def valid(self):
+        from .. import ops
+        if self.stamp != (K.WS.epoch, K.WS.clears, ops.generation()):
+            return False
+        for r, ver in self.weights:
+            w = r()
+            if w is None or w._version != ver:
+                return False
+        return True
+
+    def run(self, refiner, feature, indices):
+        self.feature.copy_(feature)
+        if self.forced is not None:
+            self.forced.copy_(torch.as_tensor(np.asarray(indices), dtype=torch.int32))
+        self.graph.replay()
+        # the graph's own tensors are overwritten by the next replay: hand out copies (as the engine path does)
+        img, *attrs = [t.clone() for t in self.out]
+        for k, v in zip(Refiner._ATTRS, attrs):
+            setattr(refiner, k, v)
+        refiner.optimizer.reset_moving_average()
+        return img

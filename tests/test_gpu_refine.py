@@ -161,6 +161,92 @@ def test_refiner_class_generic_and_engine_paths(path):
     ops.reset_variables()
 
 
+@pytest.mark.parametrize("path", [p for p in G3 if "K5" in p or "mnist_B64_K50" in p], ids=lambda p: os.path.basename(p)[10:-4])
+def test_generic_path_replays_a_captured_hipgraph(path):
+    """wirings the engine detection cannot see through (lambdas, another D, another loss) ran ~1000 launches of Python +
+    autograd per call.  The reference's build_refiner is a graph BUILDER (its callables run once, sess.run replays the graph); here the
+    generic loop of a call signature is captured into a hipGraph at its second call and replayed afterwards.  Held to: the first
+    (eager), second (capturing) and third (replayed) call all reproduce the reference golden; replays are bit-equal to each other
+    and to the eager launch of the same kernels; ops.bn's moving-average update is part of the recorded program (it advances once per
+    call, eager or replayed); an in-place weight update drops the graph (the packed copies it reads would be stale); a refused
+    capture falls back to eager launches and says why."""
+    from cgs_amd import kernels as Kn
+    from cgs_amd import ops
+    from cgs_amd.model import GAN
+    from cgs_amd.sampling.collaborator import Refiner
+    g, arch, P, vmin, vmax = load_case(path)
+    d = dev()
+    ops.reset_variables()
+    gan = GAN(arch, batch_size=len(g["z"]), device=d, params=P)
+    mode = str(g["mode"][0])
+    idx = g["indices"] if mode == "probabilistic" else None
+    f0 = torch.from_numpy(golden_feature0(g, arch, P)).to(d)
+    real = torch.from_numpy(g["real"]).to(d)
+
+    def make():
+        r = Refiner(int(g["K"][0]), float(g["rate"][0]))
+        r.set_env(lambda x: gan.discriminator(x, is_training=True, reuse=True), lambda f: gan.feature_to_data(f), gan.loss_refine)
+        if vmin is not None:
+            r.set_constraints(vmin, vmax)
+        return r
+    ref = make()
+    mms = [v for k, v in ops.variables().items() if k.startswith("discriminator") and k.endswith("moving_mean")]
+    mm = mms[0] if mms else None                                                  # (a batch norm of D: the refiner runs it in training mode)
+    outs = []
+    for call in range(4):
+        before = None if mm is None else mm.clone()
+        img = ref.build_refiner(f0, real, mode, indices=idx)
+        assert ref.path == "generic" and ref.graph_fallback is None
+        check_against_golden(g, img, ref.default_logit, ref.optimal_logit, ref.optimal_step, ref.optimal_feature,
+                             render=lambda f: gan.feature_to_data(f))
+        outs.append([t.clone() for t in (img, ref.default_logit, ref.optimal_logit, ref.optimal_step, ref.optimal_feature)])
+        assert ref.optimizer.momentum is None
+        assert len(ref._generic_graphs) == (0 if call == 0 else 1)               # call 0 eager, call 1 captures, 2.. replay
+        if mm is not None:
+            assert not torch.equal(mm, before)                                    # the moving averages move at EVERY call (ops.py:19-26, decay 0.9)
+    for a, b in zip(outs[0], outs[2]):
+        assert torch.equal(a, b)                                                  # replay == eager launch of the same kernels
+    for a, b in zip(outs[2], outs[3]):
+        assert torch.equal(a, b)
+    # another input through the same graph == a fresh eager refiner on it
+    f1 = (f0 * 0.9 + 0.05).contiguous()
+    img_g = ref.build_refiner(f1, real, mode, indices=idx)
+    eager = make(); eager.use_graph = False
+    img_e = eager.build_refiner(f1, real, mode, indices=idx)
+    assert len(eager._generic_graphs) == 0 and torch.equal(img_g, img_e) and torch.equal(ref.optimal_step, eager.optimal_step)
+    assert torch.equal(ref.optimal_logit, eager.optimal_logit)
+    # a weight moves on in place: the recorded program would read the stale packed copy -> the graph is dropped and re-captured
+    key = [k for k in ops.variables() if k.startswith("discriminator") and k.endswith("/w")][0]
+    (gg,) = ref._generic_graphs.values()
+    assert gg.valid()
+    with torch.no_grad():
+        ops.variables()[key].mul_(1.01)
+    assert not gg.valid()
+    img_w = ref.build_refiner(f1, real, mode, indices=idx)                        # (eager warm-up on the capture stream + new capture)
+    (gg2,) = ref._generic_graphs.values()
+    assert gg2 is not gg and gg2.valid()
+    img_w2 = eager.build_refiner(f1, real, mode, indices=idx)
+    assert torch.equal(img_w, img_w2) and not torch.equal(img_w, img_g)
+    with torch.no_grad():
+        ops.variables()[key].div_(1.01)
+    # a callable that synchronises with the host cannot be captured: eager launches in the same process, and the refiner says why
+    bad = Refiner(int(g["K"][0]), float(g["rate"][0]))
+
+    def syncing_d(x):
+        y = gan.discriminator(x, is_training=True, reuse=True)
+        float(y.sum().item())                                                     # a host read-back: legal eagerly, refused inside a capture
+        return y
+    bad.set_env(syncing_d, lambda f: gan.feature_to_data(f), gan.loss_refine)
+    if vmin is not None:
+        bad.set_constraints(vmin, vmax)
+    for call in range(3):
+        img_b = bad.build_refiner(f0, real, mode, indices=idx)
+        check_against_golden(g, img_b, bad.default_logit, bad.optimal_logit, bad.optimal_step, bad.optimal_feature,
+                             render=lambda f: gan.feature_to_data(f))
+    assert bad.graph_fallback and bad.use_graph is False and len(bad._generic_graphs) == 0
+    ops.reset_variables()
+
+
 @pytest.mark.parametrize("path", G3, ids=lambda p: os.path.basename(p)[10:-4])
 def test_reference_verbatim_wiring_takes_the_engine(path):
     """The four lines of nsgan/GAN.py:174-181 written against cgs_amd exactly as the reference writes them -- a
