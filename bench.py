@@ -404,8 +404,9 @@ def class_surface(dev, configs=(("dcgan64", 1024, 20, 6, 3), ("mnist", 64, 50, 2
     ``model.GAN`` + ``collaborator.Refiner`` wired with the very lines of nsgan/GAN.py:171-181 -- a ``functools.partial`` of the
     discriminator and a local loss closure -- then per z batch ``input_to_feature`` (operator API) and ``build_refiner``: one batch
     at a time on one stream, hipGraph replay (Refiner.use_graph's default).  ``generic``: the same wiring with the discriminator
-    wrapped in a lambda, which the engine detection cannot see through: the ops + torch.autograd loop (the same HIP kernels
-    launched one by one, nothing fused across layers).  Timed after and outside the headline's timed region."""
+    wrapped in a lambda, which the engine detection cannot see through: the ops + torch.autograd loop (the same HIP kernels,
+    nothing fused across layers), captured into a hipGraph at its second call and replayed (round 6: the two untimed warm-up
+    calls are the eager one and the capturing one).  Timed after and outside the headline's timed region."""
     from functools import partial
     from cgs_amd import nets, ops
     from cgs_amd.model import GAN
@@ -443,7 +444,7 @@ def class_surface(dev, configs=(("dcgan64", 1024, 20, 6, 3), ("mnist", 64, 50, 2
                 torch.cuda.synchronize(dev)
             dt = time.perf_counter() - t0
             rec[name] = {"samples_per_s": round(B * k / dt, 1), "ms_per_batch": round(1e3 * dt / k, 3), "steps": k, "path": r.path,
-                         "hipgraph": bool(r.use_graph) if r.path == "engine" else False}
+                         "hipgraph": bool(r.use_graph) if r.path == "engine" else bool(r._generic_graphs)}
             if r.graph_fallback:
                 rec[name]["hipgraph_fallback"] = r.graph_fallback
         if B == 64:

@@ -81,6 +81,17 @@ struct IgemmParams {
     long sign_plane;     // words per 32-channel plane of the mask = pixels of the WHOLE tensor (a launch may be one batch chunk of it)
     float* stat_part;    // != null: per-(m-tile, wave row) column sums / sums of squares of the output, [class][2 * m-tiles][2][N] (fused norm statistics)
     int stat_cls_rows;   // partial rows per parity class = 2 * m-tiles of a class (the launcher sets it)
+    // Norm-BACKWARD statistics (round 6; stat_part != null and ns_mean != null, CGS_EPI_NONE, ep_aux = x): the launch is the backward-data
+    // pass that produces the gradient dy w.r.t. the OUTPUT of a norm (+ lrelu) whose input x has the shape of this launch's result; the
+    // partial rows then hold [sum d | sum d * xhat] with d = dy * lrelu'(scale * x + shift), xhat = (x - mean) * invstd -- the two column
+    // sums the norm's backward pass otherwise takes in a pass of its own over dy and x (bn.hip, bn_partial_kernel<1>).
+    // ns_mean / ns_inv are [groups][N], ns_gamma / ns_beta [N]; ns_gimg = images per statistics group (0: the whole batch is one group).
+    const float* ns_mean = nullptr;
+    const float* ns_inv = nullptr;
+    const float* ns_gamma = nullptr;
+    const float* ns_beta = nullptr;
+    float ns_leak = 1.f;
+    int ns_gimg = 0;
     int vec;             // the 32-channel-chunk K order / 16-byte row gathers apply: Cred % 32 == 0 and at most 16 taps per axis
     int prio_t[3];       // progress thresholds (1/256 of the block's K tiles) at which a block steps its wave priority down; 0 = off
     // tail split (igemm.hip, "tail split"): the LAST tail_n tiles of the launch (the end of the last class in dispatch order) are each

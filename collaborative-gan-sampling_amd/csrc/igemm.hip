@@ -812,8 +812,14 @@ __global__ __launch_bounds__(64 * NW, 2) void igemm_kernel(IgemmParams p) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             if (n < p.N) {
                 const int* rp = rowpix + wm * (BM / WM) + ph * ER;
-                if (p.stat_part) {        // (only with CGS_EPI_NONE: the statistics are those of the stored tensor)
-                    epilogue_rows<CGS_EPI_NONE, ER, RPP, LDE, true>(p, E, rp, rsub, c4, n, bias, ea, eb, &st_a, &st_b);
+                if (p.stat_part && p.ns_mean) {   // norm-BACKWARD statistics of the gradient this launch produces (IgemmParams::ns_*)
+                    // a wave's 64 rows lie in ONE statistics group (cgs_conv_stat_layout admits only such launches): its parameters once per wave and pass
+                    const int mw = m0 + wm * (BM / WM);
+                    const int grp = p.ns_gimg <= 0 ? 0 : (p.pix_major ? (mw % p.B) : (mw / RC)) / p.ns_gimg;
+                    const NsLane ns = ns_lane_params(p, grp, n);
+                    epilogue_rows<CGS_EPI_NONE, ER, RPP, LDE, 2>(p, E, rp, rsub, c4, n, bias, ea, eb, &st_a, &st_b, &ns);
+                } else if (p.stat_part) {        // (only with CGS_EPI_NONE: the statistics are those of the stored tensor)
+                    epilogue_rows<CGS_EPI_NONE, ER, RPP, LDE, 1>(p, E, rp, rsub, c4, n, bias, ea, eb, &st_a, &st_b);
                 } else if (p.sign_out) {  // (N % 32 == 0: every lane of the wave is inside N, the ballots see whole rows)
                     if (p.epilogue == CGS_EPI_AFFINE_RELU) epilogue_rows_signs<CGS_EPI_AFFINE_RELU, ER, RPP, LDE, true>(p, E, rp, rsub, c4, n, bias, ea, eb);
                     else epilogue_rows_signs<CGS_EPI_LRELU, ER, RPP, LDE, true>(p, E, rp, rsub, c4, n, bias, ea, eb);
@@ -958,8 +964,20 @@ __global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(IgemmParams p)
             const size_t o = (size_t)((b * p.Hout + r * p.So + c.py) * p.Wout + cc * p.So + c.px) * p.N + n;
             const f32x4 y = a + bias;
             *(f32x4*)(p.out + o) = y;
+            if (p.ns_mean) {             // norm-backward statistics (the block's 64 rows lie in one statistics group; same arithmetic as the one-pass epilogue)
+                const int grp = p.ns_gimg <= 0 ? 0 : b / p.ns_gimg;
+                const NsLane ns = ns_lane_params(p, grp, n);
+                const f32x4 xv = *(const f32x4*)(p.ep_aux + o);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { sa[e] += y[e]; sb[e] = fmaf(y[e], y[e], sb[e]); }
+                for (int e = 0; e < 4; ++e) {
+                    const float u = fmaf(xv[e], ns.sc[e], ns.sh[e]);
+                    const float d = y[e] * (u > 0.f ? 1.f : ns.leak);
+                    sa[e] += d; sb[e] = fmaf(d, (xv[e] - ns.mu[e]) * ns.inv[e], sb[e]);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { sa[e] += y[e]; sb[e] = fmaf(y[e], y[e], sb[e]); }
+            }
         }
     }
     red[0][rl][cq] = sa; red[1][rl][cq] = sb;
@@ -1094,12 +1112,30 @@ static int choose_splitk(const IgemmParams& p) {
 // Block tile of a launch (the row policy and the split-K decision are made): 128 x 128 or 128 x 64 (``wide``), 32- or 16-deep K tiles
 // (``deep``); ``mid`` = a mid-size grid that took the narrow tile to fill the block slots.  One function: the launcher and the
 // workspace sizing (tail split) must agree on it.
-struct IgemmTiles { bool wide, mid, deep, tall; };
-static IgemmTiles igemm_choose_tiles(const IgemmParams& p) {
+struct IgemmTiles { bool wide, mid, deep, tall, wide_for_tail; };
+struct IgemmTail { int from, n, s; };
+static IgemmTail igemm_choose_tail(const IgemmParams& p, const IgemmTiles& t);
+
+// The launch-shape rules below that reason about "rounds" of workgroups (the tail split, the class flip, the one-round balancing) are
+// written for the 256 compute units of an MI355X: the kernel's flip decode shifts by 8 and the planners deal blocks modulo 256.  The
+// count is asked of the device once; on any other part those rules are switched off (results do not depend on them, only speed).
+#define IGEMM_CUS 256
+static bool igemm_round_rules_apply() {
+    static int cus = -1;
+    if (cus < 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+        cus = n;
+    }
+    return cus == IGEMM_CUS || cus == 0;         // (0: no device visible -- host-only planning queries, e.g. workspace sizing in the CPU suite)
+}
+
+// ``tail_wide``: may the rule "wide tiles + tail split" be taken (the launcher asks again without it when the caller's slab is too small)
+static IgemmTiles igemm_choose_tiles(const IgemmParams& p, bool tail_wide = true) {
     const bool vec = p.vec != 0;
     int maxRC = 0;
     for (int i = 0; i < p.nclasses; ++i) maxRC = p.cls[i].R * p.cls[i].C > maxRC ? p.cls[i].R * p.cls[i].C : maxRC;
-    bool wide = (p.Np % 128) == 0;
+    bool wide = (p.Np % 128) == 0, wide_for_tail = false;
     if (wide && p.lpt && maxRC <= 64) {   // uneven tiles (9..25 valid taps on grids <= 8x8) need >= 2 rounds of blocks over the 512 block slots to balance: halve BN if short
         long blocks = 0;
         for (int i = 0; i < p.nclasses; ++i) blocks += ((long)p.B * p.cls[i].R * p.cls[i].C / 128) * (p.Np / 128);
@@ -1107,9 +1143,13 @@ static IgemmTiles igemm_choose_tiles(const IgemmParams& p) {
         // ... unless the wide tiles make ONE partial round that the tail split evens out (igemm_choose_tail: 512 < T <= 1024 tiles at four
         // per CU, a remainder of at most 176 over whole CUs, no statistics / sign mask to leave): mnist's 7x7 128<-64 backward-data, 784
         // tiles, 200.2 us as 1568 narrow tiles -> 183.4 us (0.72 -> 0.79 of peak; profiles/r05_e_wide_tail_ab.txt)
-        if (!wide && vec && p.splitk == 1 && !p.stat_part && !p.sign_out && (p.N & 3) == 0 && p.nclasses == 1 && blocks >= 512 && blocks <= 1024 &&
-            (blocks % 256) != 0 && (blocks % 256) <= 176)
+        // -- and only if the tail planner, asked about exactly that tiling, does split it (it can still say no: an m-tile count that the per-XCD
+        // decode pads, fewer than eight K tiles): otherwise the launch would run the partial round of wide tiles the rule above avoids
+        if (!wide && tail_wide && vec && p.splitk == 1 && !p.stat_part && !p.sign_out && (p.N & 3) == 0 && p.nclasses == 1 && blocks >= 512 && blocks <= 1024 &&
+            (blocks % 256) != 0 && (blocks % 256) <= 176 && igemm_choose_tail(p, IgemmTiles{true, false, false, false, true}).s > 1) {
             wide = true;
+            wide_for_tail = true;
+        }
 #ifdef CGS_EXPERIMENT
         if (getenv("CGS_FORCE_WIDE")) wide = atoi(getenv("CGS_FORCE_WIDE")) != 0;      // (A/B: 0 = the narrow tiles, 1 = the wide ones, whatever the rules above said)
 #endif
@@ -1173,7 +1213,7 @@ static IgemmTiles igemm_choose_tiles(const IgemmParams& p) {
         }
 #endif
     }
-    return IgemmTiles{wide, mid, deep, tall};
+    return IgemmTiles{wide, mid, deep, tall, wide_for_tail && wide};
 }
 
 // blocks of this tile shape a CU holds at once (LDS: 2 * 128 * (TBK + 4) + 2 * TBK * BN floats + the row map; registers allow as many)
@@ -1190,9 +1230,9 @@ static int igemm_blocks_per_cu(bool wide, bool deep) { return deep ? (wide ? 2 :
 // are NOT split: +2 % / +-0 / +4.5 % on three of them, -3.4 % and -1.3 % on two (dcgan32 16x16 64<-128, dcgan64 32x32 64<-128: their
 // last round already overlaps the tail of the one before, and the slices pay a prologue, a raw 32 KB store and the reduce pass each);
 // experiment builds keep that plan behind CGS_TAIL_MULTI=1.
-struct IgemmTail { int from, n, s; };
 static IgemmTail igemm_choose_tail(const IgemmParams& p, const IgemmTiles& t) {
     IgemmTail none{0, 0, 0};
+    if (!igemm_round_rules_apply()) return none;
     if (!p.vec || p.splitk > 1 || p.stat_part || p.sign_out || (p.N & 3) || t.tall) return none;
 #ifdef CGS_EXPERIMENT
     if (getenv("CGS_TAIL") && atoi(getenv("CGS_TAIL")) == 0) return none;
@@ -1302,7 +1342,7 @@ static int launch_cfg(const IgemmParams& p, hipStream_t s) {
         // and a group of classes that is reversed must lie inside one round)
         const long total = gx * (long)p.nclasses * (p.splitk > 1 ? p.splitk : 1);
         q.cls_flip = 0;
-        if (p.nclasses > 1 && !p.pix_major && total > 256 && total <= 512 && gx > 0 && (256 % gx) == 0 && p.tail_s <= 1) {
+        if (igemm_round_rules_apply() && p.nclasses > 1 && !p.pix_major && total > 256 && total <= 512 && gx > 0 && (256 % gx) == 0 && p.tail_s <= 1) {
             const long per_round = 256 / gx;                          // class ranges per round of 256 blocks
             if (p.splitk > 1 && (per_round % p.nclasses) == 0) q.cls_flip = p.nclasses;                 // whole K slices per round: reverse all classes
             else if (p.splitk == 1 && per_round < p.nclasses && (p.nclasses % per_round) == 0) q.cls_flip = (int)per_round;      // several rounds per slice
@@ -1428,6 +1468,8 @@ int cgs_igemm_launch(const IgemmParams& p_in, void* slab, size_t slab_bytes, hip
         return cgs_set_error(CGS_EINVAL, "igemm: a tensor of one launch exceeds 2 GiB (the caller splits the batch)");
     if (p.stat_part && ((p.N & 3) || p.epilogue != CGS_EPI_NONE))
         return cgs_set_error(CGS_EINVAL, "igemm: fused statistics need N %% 4 == 0 and no epilogue");
+    if (p.stat_part && p.ns_mean && (!p.ns_inv || !p.ns_gamma || !p.ns_beta || !p.ep_aux || p.ns_gimg < 0))
+        return cgs_set_error(CGS_EINVAL, "igemm: norm-backward statistics need x (ep_aux), mean, invstd, gamma and beta");
     p.stat_cls_rows = 0;
     if (p.stat_part) {        // one partial row per (128-row tile, wave row), the parity classes back to back (equal M: cgs_conv_stat_layout)
         const long M0 = (long)p.B * p.cls[0].R * p.cls[0].C;
@@ -1454,17 +1496,21 @@ int cgs_igemm_launch(const IgemmParams& p_in, void* slab, size_t slab_bytes, hip
         }
     }
     const bool vec = p.vec != 0;
-    const IgemmTiles tiles = igemm_choose_tiles(p);
+    IgemmTiles tiles = igemm_choose_tiles(p);
+    IgemmTail tl = igemm_choose_tail(p, tiles);
+    bool tail_fits = tl.s > 1 && slab && slab_bytes >= igemm_tail_bytes(tl, tiles.wide);
+    if (tiles.wide_for_tail && !tail_fits) {         // wide tiles were chosen FOR the tail split and the caller's slab has no room for it: the narrow plan
+        tiles = igemm_choose_tiles(p, false);
+        tl = igemm_choose_tail(p, tiles);
+        tail_fits = tl.s > 1 && slab && slab_bytes >= igemm_tail_bytes(tl, tiles.wide);
+    }
     bool wide = tiles.wide, deep = tiles.deep;
     const bool tall = tiles.tall;
     if (tall) cgs_igemm_row_policy(p, 256);          // (whole 256-image tiles of one pixel: lpt needs B % 256 == 0)
     cgs_igemm_count_flops(p, tall ? 256 : 128);
-    {   // tail split (see igemm_choose_tail), if the caller's workspace has room for the partial tiles
-        const IgemmTail tl = igemm_choose_tail(p, tiles);
-        if (tl.s > 1 && slab && slab_bytes >= igemm_tail_bytes(tl, wide)) {
-            p.tail_from = tl.from; p.tail_n = tl.n; p.tail_s = tl.s; p.slab = (float*)slab;
-            cgs_note_tail(tl.n, tl.s);
-        }
+    if (tail_fits) {   // tail split (see igemm_choose_tail), if the caller's workspace has room for the partial tiles
+        p.tail_from = tl.from; p.tail_n = tl.n; p.tail_s = tl.s; p.slab = (float*)slab;
+        cgs_note_tail(tl.n, tl.s);
     }
 #ifdef CGS_EXPERIMENT
     if (getenv("CGS_PLAN_PRINT")) {
@@ -1482,9 +1528,10 @@ int cgs_igemm_launch(const IgemmParams& p_in, void* slab, size_t slab_bytes, hip
         //  (b) the pixel-major tiles have 9..25 valid taps each and the dispatcher hands workgroups to the 32 CUs of an XCD
         //      round-robin, so the heaviest-first order alone gives the first CUs several 25-tap tiles; instead the tiles are
         //      dealt to the CUs by greedy bin packing (heaviest tile to the least loaded CU with a free slot).
-        const int bn_sel = wide ? 128 : 64, per_cu = (vec && !deep) ? 4 : 2;
+        // (block slots per CU: the one model the tail planner uses too, igemm_blocks_per_cu)
+        const int bn_sel = wide ? 128 : 64, per_cu = vec ? igemm_blocks_per_cu(wide, deep) : 2;
         const long total_blocks = igemm_blocks(p, bn_sel);
-        const bool one_round = vec && p.splitk == 1 && !tall && total_blocks <= 256L * per_cu && total_blocks >= 256;
+        const bool one_round = igemm_round_rules_apply() && vec && p.splitk == 1 && !tall && total_blocks <= (long)IGEMM_CUS * per_cu && total_blocks >= IGEMM_CUS;
         // (a) measured per layer at batch 1024: +2..4 % on every pixel-major layer (one or two rounds of 128x128 / 128x64 blocks),
         // -3 % on the transposed 128x64 layers with their 8192 short blocks (a fresh block at priority 3 starves the ones about
         // to finish), neutral elsewhere -> pixel-major launches only

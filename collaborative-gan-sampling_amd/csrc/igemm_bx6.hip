@@ -523,7 +523,7 @@ __global__ __launch_bounds__(BM* BN / 128, BM* BN == 128 * 256 || BM * BN == 128
         if (n < p.N) {
             const int* rp = rowpix + wm * 128 + tm * ER;
             if (p.stat_part) {
-                epilogue_rows<CGS_EPI_NONE, ER, 4, LDE, true>(p, E, rp, rsub, c4, n, bias, ea, eb, &st_a, &st_b);
+                epilogue_rows<CGS_EPI_NONE, ER, 4, LDE, 1>(p, E, rp, rsub, c4, n, bias, ea, eb, &st_a, &st_b);
             } else if (p.sign_out) {      // (N % 64 == 0: every lane of the wave is inside N, the ballots see whole rows; same mask layout as igemm.hip)
                 if (p.epilogue == CGS_EPI_AFFINE_RELU) epilogue_rows_signs<CGS_EPI_AFFINE_RELU, ER, 4, LDE, true>(p, E, rp, rsub, c4, n, bias, ea, eb);
                 else epilogue_rows_signs<CGS_EPI_LRELU, ER, 4, LDE, true>(p, E, rp, rsub, c4, n, bias, ea, eb);

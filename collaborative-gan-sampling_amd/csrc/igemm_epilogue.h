@@ -39,9 +39,25 @@ __device__ __forceinline__ void epilogue_rows_signs(const IgemmParams& p, const 
     }
 }
 
-template <int EPI, int ROWS, int RPP, int LDE, bool ST = false>
+// per-lane parameters of the norm-backward statistics (IgemmParams::ns_*): this lane's four channels of its wave tile's statistics group
+struct NsLane { f32x4 mu, inv, sc, sh; float leak; };
+__device__ __forceinline__ NsLane ns_lane_params(const IgemmParams& p, int group, int n) {
+    NsLane L;
+    L.mu = *(const f32x4*)(p.ns_mean + (size_t)group * p.N + n);
+    L.inv = *(const f32x4*)(p.ns_inv + (size_t)group * p.N + n);
+    const f32x4 g = *(const f32x4*)(p.ns_gamma + n), b = *(const f32x4*)(p.ns_beta + n);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { L.sc[e] = g[e] * L.inv[e]; L.sh[e] = fmaf(-L.mu[e], L.sc[e], b[e]); }      // (the affine as bn.hip's bn_affine4 forms it)
+    L.leak = p.ns_leak;
+    return L;
+}
+
+// ST: 0 = no statistics; 1 = fused norm statistics of the stored values (sum, sum of squares); 2 = norm-BACKWARD statistics: the stored
+// value y is a gradient w.r.t. the output of norm + lrelu over x = ep_aux (same shape): sums of d = y * lrelu'(sc * x + sh) and d * xhat.
+template <int EPI, int ROWS, int RPP, int LDE, int ST = 0>
 __device__ __forceinline__ void epilogue_rows(const IgemmParams& p, const float* E, const int* rowpix_tile, int rsub, int c4,
-                                              int n, f32x4 bias, f32x4 ea, f32x4 eb, f32x4* sa = nullptr, f32x4* sb = nullptr) {
+                                              int n, f32x4 bias, f32x4 ea, f32x4 eb, f32x4* sa = nullptr, f32x4* sb = nullptr,
+                                              const NsLane* ns = nullptr) {
 #pragma unroll
     for (int it = 0; it < ROWS / RPP; ++it) {
         const int lrow = it * RPP + rsub;
@@ -50,15 +66,22 @@ __device__ __forceinline__ void epilogue_rows(const IgemmParams& p, const float*
         const f32x4 v = *(const f32x4*)(E + lrow * LDE + c4);
         const size_t o = (size_t)pix * p.N + n;
         f32x4 aux = {0.f, 0.f, 0.f, 0.f};
-        if (EPI >= CGS_EPI_RELU_BWD_AFFINE) aux = *(const f32x4*)(p.ep_aux + o);
+        if (EPI >= CGS_EPI_RELU_BWD_AFFINE || ST == 2) aux = *(const f32x4*)(p.ep_aux + o);
         f32x4 y;
 #pragma unroll
         for (int e = 0; e < 4; ++e) y[e] = epilogue_apply(v[e] + bias[e], EPI, ea[e], eb[e], aux[e]);
         *(f32x4*)(p.out + o) = y;
-        if (ST) {        // fused batch-norm statistics: this lane's 4 channels, summed over its rows
+        if (ST == 1) {   // fused batch-norm statistics: this lane's 4 channels, summed over its rows
 #pragma unroll
             for (int e = 0; e < 4; ++e) { (*sa)[e] += y[e]; (*sb)[e] = fmaf(y[e], y[e], (*sb)[e]); }
         }
+        if (ST == 2) {   // the arithmetic of bn_partial_kernel<1>, element by element
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float u = fmaf(aux[e], ns->sc[e], ns->sh[e]);
+                const float d = y[e] * (u > 0.f ? 1.f : ns->leak);
+                (*sa)[e] += d; (*sb)[e] = fmaf(d, (aux[e] - ns->mu[e]) * ns->inv[e], (*sb)[e]);
+            }
+        }
     }
 }
-

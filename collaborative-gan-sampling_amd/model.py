@@ -103,6 +103,11 @@ class GAN(object):
             self.discriminator(self.generator(z, is_training=False, reuse=False), is_training=False, reuse=False)
         return ops.variables()
 
+    @staticmethod
+    def _engine_key(batch_size, use_graph, contraction="f32", bn_groups=1):
+        """The one place the engine cache's key is written."""
+        return (int(batch_size), bool(use_graph), contraction, int(bn_groups))
+
     def engine(self, batch_size=None, use_graph=False, contraction="f32", bn_groups=1):
         """The fused device program for this net at a batch size (compiled once, cached).  ``contraction``: "f32" (exact fp32 MFMA,
         the default) or the opt-in "bx6" (include/cgs_hip.h, cgs_set_contraction).  ``bn_groups`` = G: ``batch_size`` holds G
@@ -110,20 +115,32 @@ class GAN(object):
         per logical batch (nsgan/GAN.py:175 at the reference's own batch size, nsgan/main.py:32), so the result is that of G calls."""
         from .engine import RefineEngine
         B = int(batch_size or self.batch_size)
-        key = (B, use_graph, contraction, int(bn_groups))
+        key = self._engine_key(B, use_graph, contraction, bn_groups)
         hit = self._engines.get(key)
         if hit is None or hit[1] != ops.generation():       # a checkpoint was loaded since: re-fold the G bn affines, re-pack
             hit = self._engines[key] = (RefineEngine(self.A, self.build_variables(), B, self.device, use_graph=use_graph, contraction=contraction,
                                                      bn_groups=int(bn_groups)), ops.generation())
         return hit[0]
 
-    @staticmethod
-    def _engines_generation():
-        return ops.generation()
-
     def drop_engine(self, batch_size, use_graph, contraction="f32", bn_groups=1):
         """Forget a cached engine (its activation buffers are freed with it)."""
-        self._engines.pop((int(batch_size), use_graph, contraction, int(bn_groups)), None)
+        self._engines.pop(self._engine_key(batch_size, use_graph, contraction, bn_groups), None)
+
+    def demote_engine_to_eager(self, batch_size, contraction="f32", bn_groups=1):
+        """A hipGraph capture of the cached graph engine was refused: keep the SAME engine (and its buffers), launched kernel by
+        kernel from now on, under the eager key -- unless an eager engine of that signature is already cached, which is then the one
+        to use (the demoted one is dropped).  Returns the engine to run."""
+        gkey = self._engine_key(batch_size, True, contraction, bn_groups)
+        ekey = self._engine_key(batch_size, False, contraction, bn_groups)
+        hit = self._engines.pop(gkey, None)
+        have = self._engines.get(ekey)
+        if have is not None and have[1] == ops.generation():
+            return have[0]
+        if hit is None:
+            return self.engine(batch_size, use_graph=False, contraction=contraction, bn_groups=bn_groups)
+        hit[0].use_graph = False
+        self._engines[ekey] = (hit[0], ops.generation())
+        return hit[0]
 
     def build_refiner(self, rollout_steps, rollout_rate, rollout_method="momentum"):
         """nsgan/GAN.py:179-181."""

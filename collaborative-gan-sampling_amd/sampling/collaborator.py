@@ -223,9 +223,7 @@ class Refiner():
                     torch.cuda.synchronize(fake_feature.device)
                 except Exception:                                 # noqa: BLE001
                     pass
-                eng.use_graph = False
-                owner.drop_engine(B, True, self.contraction, G)
-                owner._engines[(B, False, self.contraction, G)] = (eng, owner._engines_generation())
+                eng = owner.demote_engine_to_eager(B, self.contraction, G)      # (the one place the cache's key layout lives: model.GAN)
                 out = eng.refine(*args)
             img, d_l, o_l, o_s, o_f = out
             # the engine returns its own (cached, reused) buffers: hand out copies, so that a second build_refiner -- the
