@@ -63,6 +63,8 @@ HBM_OPS = {
     # behind its linear layer -- the forward kernels' per-launch averages mix the two tensor sizes: an approximation there)
     "groupnorm_lrelu_fwd_from_partials": ["bn_finalize_kernel<0>", "bn_apply_fwd_kernel"],
     "instnorm_lrelu_bwd_data": ["bn_partial_kernel<1>", "bn_finalize_kernel<1>", "bn_apply_bwd_kernel"],
+    # (round 6: the sums pass rides on the backward-data launch of the conv above the norm -- cgs_*_bwd_data_nstats -- where the library offers it)
+    "norm_lrelu_bwd_from_partials": ["bn_finalize_kernel<1>", "bn_apply_bwd_kernel"],
     "refine_update": ["refine_update_kernel"],
     "linear_out1_fwd": ["linear_out1_fwd_kernel"],
     "linear_out1_bwd": ["linear_out1_bwd_kernel"],

@@ -89,10 +89,13 @@ static int choose_family(const CgsLayer& L, bool dirT, int B, int epilogue, bool
     return CGS_FAMILY_IGEMM;
 }
 
+// norm-backward statistics of a backward-data call (IgemmParams::ns_*; x rides in ep_aux)
+struct NsArgs { const float *mean, *invstd, *gamma, *beta; float leak; int group_images; };
+
 static int run_dir(const CgsLayer& L, bool dirT, int B, const float* in, const float* w, const float* bias, float* out,
                    int epilogue, const float* ep_a, const float* ep_b, const float* ep_aux, void* ws, size_t ws_bytes,
                    int prepacked, hipStream_t s, const char* who, float* stat_part = nullptr, unsigned* sign_out = nullptr,
-                   const unsigned* aux_signs = nullptr) {
+                   const unsigned* aux_signs = nullptr, const NsArgs* ns = nullptr) {
     cgs_note_flops(0.0);
     cgs_note_tail(0, 0);
     if (B <= 0) return cgs_set_error(CGS_EINVAL, "%s: B=%d", who, B);
@@ -106,6 +109,7 @@ static int run_dir(const CgsLayer& L, bool dirT, int B, const float* in, const f
                            ((uintptr_t)ep_aux & 15));
     const int fam = choose_family(L, dirT, B, epilogue, ws != nullptr, ws_bytes, !((uintptr_t)in & 15), !((uintptr_t)ws & 15), rest_al);
     if (stat_part && fam != CGS_FAMILY_IGEMM && fam != CGS_FAMILY_IGEMM_BX6) return cgs_set_error(CGS_EINVAL, "%s: fused statistics are an implicit-GEMM feature (see cgs_conv_stat_partials)", who);
+    if (ns && (!stat_part || fam != CGS_FAMILY_IGEMM)) return cgs_set_error(CGS_EINVAL, "%s: norm-backward statistics are a feature of the exact-fp32 implicit GEMM (see cgs_conv_stat_layout)", who);
     if (sign_out && fam != CGS_FAMILY_IGEMM && fam != CGS_FAMILY_IGEMM_BX6) return cgs_set_error(CGS_EINVAL, "%s: this call cannot leave a sign mask (see cgs_conv_signs_ok)", who);
     if (aux_signs && fam != CGS_FAMILY_PATCH && fam != CGS_FAMILY_TAPS) return cgs_set_error(CGS_EINVAL, "%s: this call cannot take a sign mask (see cgs_conv_signs_ok)", who);
     if (((uintptr_t)sign_out & 3) || ((uintptr_t)aux_signs & 3)) return cgs_set_error(CGS_EINVAL, "%s: sign mask must be 4-byte aligned", who);
@@ -127,6 +131,7 @@ static int run_dir(const CgsLayer& L, bool dirT, int B, const float* in, const f
     IgemmParams p;
     p.in = in; p.bias = bias; p.ep_a = ep_a; p.ep_b = ep_b; p.ep_aux = ep_aux; p.out = out; p.B = B; p.epilogue = epilogue;
     p.stat_part = stat_part;
+    if (ns) { p.ns_mean = ns->mean; p.ns_inv = ns->invstd; p.ns_gamma = ns->gamma; p.ns_beta = ns->beta; p.ns_leak = ns->leak; p.ns_gimg = ns->group_images >= B ? 0 : ns->group_images; }
     p.sign_out = sign_out;
     p.sign_plane = (long)B * (dirT ? L.Hb * L.Wb : L.Hs * L.Ws);
     if (dirT) cgs_geom_T(L, p); else cgs_geom_F(L, p);
@@ -250,16 +255,19 @@ int cgs_conv_stat_partials(int B, int H, int W, int Cin, int Cout, int kh, int k
 // pixel-major launches (whole 128-image tiles): a segment per (class, base pixel).  Returns the total row count, 0 = unavailable.
 int cgs_conv_stat_layout(int op, int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int sh, int sw, int group_images,
                          size_t ws_bytes, int* rows_per_seg, int* nseg, int* seg_stride) {
-    if ((op != CGS_CONV_FWD && op != CGS_DECONV_FWD) || B <= 0 || group_images <= 0 || (B % group_images) || (Cout & 3) || !rows_per_seg || !nseg ||
-        !seg_stride)
+    if (op < CGS_CONV_FWD || op > CGS_DECONV_BWD_DATA || B <= 0 || group_images <= 0 || (B % group_images) || !rows_per_seg || !nseg || !seg_stride)
         return 0;
-    const bool dirT = op == CGS_DECONV_FWD;
+    // the launch's direction and the channel count of the tensor it WRITES (the statistics' columns): the forward ops write Cout channels,
+    // the backward-data ops (norm-backward statistics, cgs_*_bwd_data_nstats) the gradient w.r.t. their input: Cin channels
+    const bool deconv = (op == CGS_DECONV_FWD || op == CGS_DECONV_BWD_DATA), bwd = (op == CGS_CONV_BWD_DATA || op == CGS_DECONV_BWD_DATA);
+    const bool dirT = (op == CGS_CONV_BWD_DATA || op == CGS_DECONV_FWD);
+    if ((bwd ? Cin : Cout) & 3) return 0;
     CgsLayer L;
-    if (!dirT) { if (make_layer(L, kh, kw, sh, sw, H, W, Cin, cgs_ceil_div(H, sh > 0 ? sh : 1), cgs_ceil_div(W, sw > 0 ? sw : 1), Cout, "conv_stat_layout")) return 0; }
+    if (!deconv) { if (make_layer(L, kh, kw, sh, sw, H, W, Cin, cgs_ceil_div(H, sh > 0 ? sh : 1), cgs_ceil_div(W, sw > 0 ? sw : 1), Cout, "conv_stat_layout")) return 0; }
     else if (make_layer(L, kh, kw, sh, sw, Ho, Wo, Cout, H, W, Cin, "conv_stat_layout")) return 0;
     if (dirT && (sh > 2 || sw > 2)) return 0;
     const int fam = choose_family(L, dirT, B, CGS_EPI_NONE, ws_bytes > 0, ws_bytes, true, true, true);
-    if (fam != CGS_FAMILY_IGEMM && fam != CGS_FAMILY_IGEMM_BX6) return 0;
+    if (fam != CGS_FAMILY_IGEMM && (bwd || fam != CGS_FAMILY_IGEMM_BX6)) return 0;           // (the backward sums: the exact-fp32 kernel only)
     const size_t per = (size_t)(L.Hb * L.Wb * L.Cb > L.Hs * L.Ws * L.Cs ? L.Hb * L.Wb * L.Cb : L.Hs * L.Ws * L.Cs) * 4;
     if ((size_t)B * per > 0x7fffffffUL) return 0;                    // the entry point would split the batch
     IgemmParams p;
@@ -272,6 +280,10 @@ int cgs_conv_stat_layout(int op, int B, int H, int W, int Cin, int Ho, int Wo, i
     const long M = (long)B * RC;
     const long cls_rows = 2 * ((M + 127) / 128);
     if (cls_rows * p.nclasses > 0x7fffffffL) return 0;
+    if (group_images == B) {                                         // one group: every partial row belongs to it, whatever the row order
+        *rows_per_seg = (int)(cls_rows * p.nclasses); *nseg = 1; *seg_stride = 0;
+        return (int)(cls_rows * p.nclasses);
+    }
     const int order = cgs_igemm_row_order(p);
     if (order == 0) {                                                // rows (image, pixel): a group's rows are contiguous inside every class
         if (((long)group_images * RC) % 64) return 0;
@@ -283,6 +295,50 @@ int cgs_conv_stat_layout(int op, int B, int H, int W, int Cin, int Ho, int Wo, i
         return 0;
     }
     return (int)(cls_rows * p.nclasses);
+}
+
+// Backward-data of a conv / deconv whose result is the gradient w.r.t. the OUTPUT of a norm (+ lrelu) over x_norm (same shape as the
+// result): the launch also leaves the norm backward's two column sums as partial rows (cgs_conv_stat_layout with the *_BWD_DATA op says
+// where a group's rows lie; cgs_norm_lrelu_bwd_from_partials consumes them).  The result itself is the plain backward-data (no epilogue).
+static int nstats_check(const char* who, int G, int C, const float* x_norm, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                        float* stat_part, size_t stat_part_bytes) {
+    if (G == 0) return cgs_set_error(CGS_EINVAL, "%s: not available for this call (cgs_conv_stat_layout == 0)", who);
+    if (!x_norm || !mean || !invstd || !gamma || !beta) return cgs_set_error(CGS_EINVAL, "%s: null statistics argument", who);
+    if (((uintptr_t)x_norm | (uintptr_t)mean | (uintptr_t)invstd | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)stat_part) & 15)
+        return cgs_set_error(CGS_EINVAL, "%s: pointers must be 16-byte aligned", who);
+    if (!stat_part || stat_part_bytes < (size_t)G * 2 * C * sizeof(float))
+        return cgs_set_error(CGS_EWORKSPACE, "%s: partials buffer %zu < %zu bytes", who, stat_part_bytes, (size_t)G * 2 * C * sizeof(float));
+    return CGS_OK;
+}
+
+int cgs_conv2d_nhwc_bwd_data_nstats(const float* dy, const float* w, float* dx, int B, int H, int W, int Cin, int Cout, int kh, int kw, int sh,
+                                    int sw, const float* x_norm, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                    float leak, int group_images, void* ws, size_t ws_bytes, int ws_prepacked, float* stat_part,
+                                    size_t stat_part_bytes, void* stream) {
+    CgsLayer L;
+    int rc = make_layer(L, kh, kw, sh, sw, H, W, Cin, cgs_ceil_div(H, sh > 0 ? sh : 1), cgs_ceil_div(W, sw > 0 ? sw : 1), Cout, "conv2d_nhwc_bwd_data_nstats");
+    if (rc) return rc;
+    int a, b, c;
+    const int G = cgs_conv_stat_layout(CGS_CONV_BWD_DATA, B, H, W, Cin, 0, 0, Cout, kh, kw, sh, sw, group_images, ws_bytes, &a, &b, &c);
+    if ((rc = nstats_check("conv2d_nhwc_bwd_data_nstats", G, Cin, x_norm, mean, invstd, gamma, beta, stat_part, stat_part_bytes))) return rc;
+    const NsArgs ns{mean, invstd, gamma, beta, leak, group_images};
+    return run_dir(L, true, B, dy, w, nullptr, dx, CGS_EPI_NONE, nullptr, nullptr, x_norm, ws, ws_bytes, ws_prepacked, (hipStream_t)stream,
+                   "conv2d_nhwc_bwd_data_nstats", stat_part, nullptr, nullptr, &ns);
+}
+
+int cgs_deconv2d_nhwc_bwd_data_nstats(const float* dy, const float* w, float* dx, int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int kh,
+                                      int kw, int sh, int sw, const float* x_norm, const float* mean, const float* invstd, const float* gamma,
+                                      const float* beta, float leak, int group_images, void* ws, size_t ws_bytes, int ws_prepacked,
+                                      float* stat_part, size_t stat_part_bytes, void* stream) {
+    CgsLayer L;
+    int rc = make_layer(L, kh, kw, sh, sw, Ho, Wo, Cout, H, W, Cin, "deconv2d_nhwc_bwd_data_nstats");
+    if (rc) return rc;
+    int a, b, c;
+    const int G = cgs_conv_stat_layout(CGS_DECONV_BWD_DATA, B, H, W, Cin, Ho, Wo, Cout, kh, kw, sh, sw, group_images, ws_bytes, &a, &b, &c);
+    if ((rc = nstats_check("deconv2d_nhwc_bwd_data_nstats", G, Cin, x_norm, mean, invstd, gamma, beta, stat_part, stat_part_bytes))) return rc;
+    const NsArgs ns{mean, invstd, gamma, beta, leak, group_images};
+    return run_dir(L, false, B, dy, w, nullptr, dx, CGS_EPI_NONE, nullptr, nullptr, x_norm, ws, ws_bytes, ws_prepacked, (hipStream_t)stream,
+                   "deconv2d_nhwc_bwd_data_nstats", stat_part, nullptr, nullptr, &ns);
 }
 
 int cgs_deconv2d_nhwc_fwd_stats(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int Cin, int Ho, int Wo,

@@ -187,6 +187,16 @@ __global__ void bn_finalize_slices_kernel(const double* __restrict__ slices, int
     mean_out[c] = (float)mean; invstd_out[c] = invstd;
 }
 
+// ... and for the two backward column sums (stat2 = {mean(dy'), mean(dy' * xhat)}) when the producing backward-data launch left them
+// as partial rows (cgs_norm_lrelu_bwd_from_partials).
+__global__ void bn_finalize2_slices_kernel(const double* __restrict__ slices, int M, int C, float* __restrict__ stat2) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double a = 0.0, b = 0.0;
+    for (int i = 0; i < BNF_SLICES; ++i) { a += slices[((size_t)i * 2 + 0) * C + c]; b += slices[((size_t)i * 2 + 1) * C + c]; }
+    stat2[c] = (float)(a / M); stat2[C + c] = (float)(b / M);
+}
+
 // The two streaming passes of a norm.  A thread walks the tensor with a stride of gridDim.x * 256 float4; whenever that stride is a
 // whole number of channel rows (C | 1024 * gridDim.x: every power-of-two channel count), its four channels never change, so the
 // per-channel parameters are loaded ONCE per thread (and group) instead of with every element -- the element loop then issues one
@@ -661,6 +671,36 @@ int cgs_groupnorm_lrelu_fwd_from_partials(const float* x, const float* part, int
     const size_t n4 = (size_t)groups * M_group * C / 4, gn4 = (size_t)M_group * C / 4;
     hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3(ew_blocks(n4)), dim3(256), 0, s, x, stat, leak, y, n4, C, gn4);
     CGS_CHECK_LAUNCH("groupnorm_lrelu_fwd_from_partials");
+    return CGS_OK;
+}
+
+// Backward-data of a norm (+ lrelu) over groups of rows whose two column sums the PRODUCING backward-data launch left as partial rows
+// (cgs_conv2d_nhwc_bwd_data_nstats / cgs_deconv2d_nhwc_bwd_data_nstats, layout = cgs_conv_stat_layout of that call): finalize + apply --
+// the sums pass over dy and x (2 of the 5 tensor passes of cgs_bn_train_lrelu_bwd_data / cgs_instnorm_lrelu_bwd_data) is gone.
+// ws: >= groups * 2 * C floats (+ 16 * 2 * C doubles for groups == 1 with >= 1024 partial rows); cgs_bn_ws_bytes / cgs_instnorm_ws_bytes cover it.
+int cgs_norm_lrelu_bwd_from_partials(const float* dy, const float* x, const float* part, int groups, int rows_per_seg, int nseg, int seg_stride,
+                                     const float* gamma, const float* beta, const float* mean, const float* invstd, float leak, float* dx,
+                                     int M_group, int C, void* ws, size_t ws_bytes, void* stream) {
+    if (groups <= 0 || groups > 65535 || M_group <= 0 || C <= 0 || (C & 3) || rows_per_seg <= 0 || nseg <= 0 || seg_stride < 0 || !part || !dy || !x || !dx)
+        return cgs_set_error(CGS_EINVAL, "norm bwd from partials: groups=%d M=%d C=%d rows=%d x %d", groups, M_group, C, rows_per_seg, nseg);
+    const bool sliced = groups == 1 && nseg == 1 && rows_per_seg >= 1024 && !((uintptr_t)ws & 7);
+    const size_t need = (size_t)groups * 2 * C * sizeof(float) + (sliced ? (size_t)BNF_SLICES * 2 * C * sizeof(double) : 0);
+    if (!ws || ws_bytes < need) return cgs_set_error(CGS_EWORKSPACE, "norm bwd from partials: workspace %zu < %zu", ws_bytes, need);
+    hipStream_t s = (hipStream_t)stream;
+    float* stat2;
+    if (sliced) {
+        double* slices = (double*)ws;
+        stat2 = (float*)(slices + (size_t)BNF_SLICES * 2 * C);
+        hipLaunchKernelGGL(bn_slice_sums_kernel, dim3(cgs_ceil_div(C, BNF_CH), BNF_SLICES), dim3(256), 0, s, part, rows_per_seg, C, slices);
+        hipLaunchKernelGGL(bn_finalize2_slices_kernel, dim3(cgs_ceil_div(C, 64)), dim3(64), 0, s, slices, M_group, C, stat2);
+    } else {
+        stat2 = (float*)ws;                                                   // [groups][2][C]
+        hipLaunchKernelGGL(bn_finalize_kernel<1>, dim3(cgs_ceil_div(C, BNF_CH), groups), dim3(256), 0, s, part, rows_per_seg, M_group, C, nullptr, nullptr, 0.f,
+                           stat2, nullptr, nullptr, nseg, seg_stride);
+    }
+    const size_t n4 = (size_t)groups * M_group * C / 4, gn4 = (size_t)M_group * C / 4;
+    hipLaunchKernelGGL(bn_apply_bwd_kernel, dim3(ew_blocks(n4)), dim3(256), 0, s, dy, x, mean, invstd, gamma, beta, stat2, leak, dx, n4, C, gn4);
+    CGS_CHECK_LAUNCH("norm_lrelu_bwd_from_partials");
     return CGS_OK;
 }
 

@@ -28,6 +28,9 @@ class _Stage:
     out = None
     bwd_epi = (L.EPI_NONE, None, None)   # (mode, a, aux): activation gradient of the stage BELOW, folded into this stage's bwd-data
     pre_folded = False                   # True: the stage ABOVE already applied this stage's activation gradient
+    bwd_nstat = None                     # conv / deconv stages: a K.NormBwdStats -- this stage's backward-data also leaves the column sums of
+                                         # the norm stage right below (whose output gradient it produces); link_norm_backward_stats
+    bstat = None                         # norm stages: the same object -- backward = finalize + one pass from those sums
 
     def fwd(self, x):
         raise NotImplementedError
@@ -92,7 +95,7 @@ class _Conv(_Stage):
             elif self.epi == L.EPI_TANH:
                 dy = K.tanh_bwd(dy, self.out, out=dy)
         e, a, aux = self.bwd_epi
-        return K.conv2d_bwd_data(dy, self.w, self.in_hw, self.s, self.s, out=self.dx, epilogue=e, ep_a=a, ep_aux=aux)
+        return K.conv2d_bwd_data(dy, self.w, self.in_hw, self.s, self.s, out=self.dx, epilogue=e, ep_a=a, ep_aux=aux, nstat=self.bwd_nstat)
 
 
 class _Deconv(_Stage):
@@ -131,7 +134,7 @@ class _Deconv(_Stage):
                 dy = K.tanh_bwd(dy, self.out, out=dy)
         e, a, aux = self.bwd_epi
         return K.deconv2d_bwd_data(dy, self.w, self.in_hw, self.s, self.s, out=self.dx, epilogue=e, ep_a=a, ep_aux=aux,
-                                   ep_signs=self.bwd_signs)
+                                   ep_signs=self.bwd_signs, nstat=self.bwd_nstat)
 
     def call_dims(self):
         """(B, H, W, Cin, Ho, Wo, Cout, kh, kw) of the forward call."""
@@ -190,6 +193,8 @@ class _BnTrainLrelu(_Stage):
 
     def fwd(self, x):
         self.x = x
+        if self.bstat is not None:
+            self.bstat.x = x
         if self.groups > 1:
             if self.part is not None:
                 K.groupnorm_lrelu_fwd_from_partials(x, self.part, self.part_layout, self.groups, self.gamma, self.beta, self.leak,
@@ -212,6 +217,8 @@ class _BnTrainLrelu(_Stage):
         return self.out
 
     def bwd(self, dy):
+        if self.bstat is not None:           # the backward-data launch above left the two column sums: finalize + one pass
+            return K.norm_lrelu_bwd_from_partials(dy, self.x, self.bstat, self.groups, out=dy)
         if self.groups > 1:
             K.instnorm_lrelu_bwd_data(self._g(dy), self._g(self.x), self.gamma, self.beta, self.mean, self.invstd, self.leak,
                                       out=self._g(dy))
@@ -272,6 +279,8 @@ class _InstNormAct(_Stage):
 
     def fwd(self, x):
         self.x = x
+        if self.bstat is not None:
+            self.bstat.x = x
         if self.part is not None:
             K.groupnorm_lrelu_fwd_from_partials(x, self.part, self.part_layout, x.shape[0], self.scale, self.offset, self.leak,
                                                 out=self.out, stats=(self.mean, self.invstd))
@@ -280,6 +289,8 @@ class _InstNormAct(_Stage):
         return self.out
 
     def bwd(self, dy):
+        if self.bstat is not None:
+            return K.norm_lrelu_bwd_from_partials(dy, self.x, self.bstat, dy.shape[0], out=dy)
         return K.instnorm_lrelu_bwd_data(dy, self.x, self.scale, self.offset, self.mean, self.invstd, self.leak, out=dy)
 
 
@@ -448,6 +459,42 @@ def link_backward_fusion(stages):
         below.pre_folded = True
 
 
+def link_norm_backward_stats(stages, B):
+    """For each norm stage (batch statistics, per logical batch or per sample) whose successor is a conv / deconv stage: that stage's
+    backward-data launch produces the gradient at the norm's output, so it can leave the norm backward's two column sums in its
+    epilogue (include/cgs_hip.h, cgs_*_bwd_data_nstats) -- the norm's own sums pass over dy and x, 2 of its 5 tensor passes, is gone.
+    Only where the library offers it for the call (exact-fp32 implicit GEMM, groups that end on 64-row boundaries of the launch's row
+    order); everything else keeps the three-kernel backward.  Call after the norms' groups are final (set_groups re-allocates the
+    saved statistics)."""
+    import os
+    if os.environ.get("CGS_NO_FUSED_BN_BWD_STATS"):           # (A/B switch for measurements)
+        return
+    for below, above in zip(stages[:-1], stages[1:]):
+        if isinstance(below, _Residual):
+            link_norm_backward_stats(below.inner, B)
+        if not isinstance(above, (_Conv, _Deconv)) or above.bwd_epi[0] != L.EPI_NONE or above.bwd_nstat is not None:
+            continue
+        if isinstance(below, _BnTrainLrelu) and below.sync is None:
+            gamma, beta, gimg = below.gamma, below.beta, B // below.groups
+        elif isinstance(below, _InstNormAct):
+            gamma, beta, gimg = below.scale, below.offset, 1
+        else:
+            continue
+        C = below.out.shape[-1]
+        if isinstance(above, _Conv):
+            H, W, Cin = above.dx.shape[1:]
+            kh, kw, _, Cout = above.w.shape
+            lay = K.conv_stat_layout(L.CONV_BWD_DATA, B, H, W, Cin, 0, 0, Cout, kh, kw, above.s, above.s, gimg)
+        else:
+            lay = K.conv_stat_layout(L.DECONV_BWD_DATA, *above.call_dims(), above.s, above.s, gimg)
+        if lay is None:
+            continue
+        part = torch.empty((lay[0], 2, C), dtype=torch.float32, device=below.out.device)
+        below.bstat = above.bwd_nstat = K.NormBwdStats(None, below.mean, below.invstd, gamma, beta, below.leak, gimg, part, lay)
+    if stages and isinstance(stages[-1], _Residual):
+        link_norm_backward_stats(stages[-1].inner, B)
+
+
 class Tape:
     """A compiled layer list: forward keeps what backward-data needs; no weight gradients."""
 
@@ -570,6 +617,8 @@ class RefineEngine:
                 if isinstance(st, _Residual):
                     drop_partials(st.inner)
         drop_partials(self.d.stages); drop_partials(self.g_tail.stages)
+        # the norm backward's column sums ride on the backward-data launch of the conv above (across the G-tail / D seam too)
+        link_norm_backward_stats(self.g_tail.stages + self.d.stages, B)
 
     # -- parameters changed under the engine ---------------------------------------------------
     def _sync_weights(self):

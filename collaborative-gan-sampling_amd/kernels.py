@@ -285,9 +285,25 @@ def bn_train_lrelu_fwd_from_partials(x, part, gamma, beta, leak=LEAK, eps=BN_EPS
     return y, mean, invstd
 
 
-def conv2d_bwd_data(dy, w, in_hw, sh=2, sw=2, out=None, epilogue=L.EPI_NONE, ep_a=None, ep_aux=None):
+class NormBwdStats:
+    """What a backward-data call needs to ALSO leave the two column sums of the norm (+ lrelu) whose output gradient it produces
+    (include/cgs_hip.h, cgs_*_bwd_data_nstats): the norm's input ``x`` (same shape as the call's result), its saved ``mean`` / ``invstd``
+    ([groups, C]), ``gamma`` / ``beta``, the lrelu ``leak``, the images per statistics group, and the partial-row buffer ``part``
+    ([rows, 2, C]) with its ``layout`` = conv_stat_layout(<the *_BWD_DATA op>, ...).  ``norm_lrelu_bwd_from_partials`` consumes it."""
+    __slots__ = ("x", "mean", "invstd", "gamma", "beta", "leak", "group_images", "part", "layout")
+
+    def __init__(self, x, mean, invstd, gamma, beta, leak, group_images, part, layout):
+        self.x, self.mean, self.invstd, self.gamma, self.beta = x, mean, invstd, gamma, beta
+        self.leak, self.group_images, self.part, self.layout = float(leak), int(group_images), part, layout
+
+    def args(self):
+        return (_ptr(self.x), _ptr(self.mean), _ptr(self.invstd), _ptr(self.gamma), _ptr(self.beta), self.leak, self.group_images)
+
+
+def conv2d_bwd_data(dy, w, in_hw, sh=2, sw=2, out=None, epilogue=L.EPI_NONE, ep_a=None, ep_aux=None, nstat=None):
     """Input gradient of conv2d_fwd (Conv2DBackpropInput; sampling/collaborator.py:31).
-    ``epilogue`` = one of the *_BWD modes folds the activation gradient of the layer below in."""
+    ``epilogue`` = one of the *_BWD modes folds the activation gradient of the layer below in.
+    ``nstat`` (a NormBwdStats; no epilogue): the result is the gradient at the output of a norm -- leave that norm's backward sums too."""
     _chk(dy, "dy"); _chk(w, "w")
     kh, kw, Cin, Cout = w.shape
     B = dy.shape[0]
@@ -296,9 +312,16 @@ def conv2d_bwd_data(dy, w, in_hw, sh=2, sw=2, out=None, epilogue=L.EPI_NONE, ep_
     ws, pre = WS.get(w, L.CONV_BWD_DATA, kh, kw, sh, sw, Cin, Cout, (B, H, W), epilogue,
                      ptrs=(_ptr(dy), _ptr(dx), _ptr(ep_a), _ptr(ep_aux)))
     Ho, Wo = dy.shape[1], dy.shape[2]
-    pr = _Prof(2.0 * B * Ho * Wo * Cout * kh * kw * Cin, f"conv_bwd {H}x{W} {Cin}<-{Cout}", _nb(dy, w, dx, ep_aux)) if PROFILE is not None else None
-    L.call("cgs_conv2d_nhwc_bwd_data", _ptr(dy), _ptr(w), _ptr(dx), B, H, W, Cin, Cout, kh, kw, sh, sw,
-           epilogue, _ptr(ep_a), _ptr(ep_aux), _ptr(ws), ws.numel() * 4, pre, _stream())
+    pr = _Prof(2.0 * B * Ho * Wo * Cout * kh * kw * Cin, f"conv_bwd {H}x{W} {Cin}<-{Cout}",
+               _nb(dy, w, dx, ep_aux, nstat.x if nstat is not None else None)) if PROFILE is not None else None
+    if nstat is not None:
+        if epilogue != L.EPI_NONE:
+            raise L.CgsError("conv2d_bwd_data: norm-backward statistics come with no epilogue")
+        L.call("cgs_conv2d_nhwc_bwd_data_nstats", _ptr(dy), _ptr(w), _ptr(dx), B, H, W, Cin, Cout, kh, kw, sh, sw, *nstat.args(),
+               _ptr(ws), ws.numel() * 4, pre, _ptr(nstat.part), nstat.part.numel() * 4, _stream())
+    else:
+        L.call("cgs_conv2d_nhwc_bwd_data", _ptr(dy), _ptr(w), _ptr(dx), B, H, W, Cin, Cout, kh, kw, sh, sw,
+               epilogue, _ptr(ep_a), _ptr(ep_aux), _ptr(ws), ws.numel() * 4, pre, _stream())
     if pr is not None:
         pr.done()
     return dx
@@ -341,9 +364,10 @@ def deconv2d_fwd(x, w, bias, out_hw, sh=2, sw=2, epilogue=L.EPI_NONE, ep_a=None,
     return y
 
 
-def deconv2d_bwd_data(dy, w, in_hw, sh=2, sw=2, out=None, epilogue=L.EPI_NONE, ep_a=None, ep_aux=None, ep_signs=None):
+def deconv2d_bwd_data(dy, w, in_hw, sh=2, sw=2, out=None, epilogue=L.EPI_NONE, ep_a=None, ep_aux=None, ep_signs=None, nstat=None):
     """Input gradient of deconv2d_fwd: a strided 'SAME' conv of dy with the deconv weights.
-    ``ep_signs``: the sign mask of the saved activation instead of ``ep_aux`` (relu' / lrelu' epilogues, where ``conv_signs_ok``)."""
+    ``ep_signs``: the sign mask of the saved activation instead of ``ep_aux`` (relu' / lrelu' epilogues, where ``conv_signs_ok``).
+    ``nstat``: as in conv2d_bwd_data."""
     _chk(dy, "dy"); _chk(w, "w")
     kh, kw, Cout, Cin = w.shape
     B, Ho, Wo, _ = dy.shape
@@ -352,8 +376,13 @@ def deconv2d_bwd_data(dy, w, in_hw, sh=2, sw=2, out=None, epilogue=L.EPI_NONE, e
     ws, pre = WS.get(w, L.DECONV_BWD_DATA, kh, kw, sh, sw, Cin, Cout, (B, H, W), epilogue, (Ho, Wo),
                      ptrs=(_ptr(dy), _ptr(dx), _ptr(ep_a), _ptr(ep_aux)))
     pr = _Prof(2.0 * B * H * W * Cin * kh * kw * Cout, f"deconv_bwd {H}x{W} {Cin}<-{Cout}",
-               _nb(dy, w, dx, ep_aux if ep_signs is None else ep_signs)) if PROFILE is not None else None
-    if ep_signs is not None:
+               _nb(dy, w, dx, ep_aux if ep_signs is None else ep_signs, nstat.x if nstat is not None else None)) if PROFILE is not None else None
+    if nstat is not None:
+        if epilogue != L.EPI_NONE or ep_signs is not None:
+            raise L.CgsError("deconv2d_bwd_data: norm-backward statistics come with no epilogue")
+        L.call("cgs_deconv2d_nhwc_bwd_data_nstats", _ptr(dy), _ptr(w), _ptr(dx), B, H, W, Cin, Ho, Wo, Cout, kh, kw, sh, sw, *nstat.args(),
+               _ptr(ws), ws.numel() * 4, pre, _ptr(nstat.part), nstat.part.numel() * 4, _stream())
+    elif ep_signs is not None:
         L.call("cgs_deconv2d_nhwc_bwd_data_signs", _ptr(dy), _ptr(w), _ptr(dx), B, H, W, Cin, Ho, Wo, Cout, kh, kw, sh, sw,
                epilogue, _ptr(ep_a), ep_signs.data_ptr(), _ptr(ws), ws.numel() * 4, pre, _stream())
     else:
@@ -525,6 +554,23 @@ def instnorm_lrelu_bwd_data(dy, x, scale, offset, mean, invstd, leak=1.0, out=No
     pr = _Prof(0.0, "", _nb(dy, x, dy, x, dx), op="instnorm_lrelu_bwd_data") if PROFILE is not None else None
     L.call("cgs_instnorm_lrelu_bwd_data", _ptr(dy), _ptr(x), _ptr(scale), _ptr(offset), _ptr(mean), _ptr(invstd), leak, _ptr(dx),
            B, HW, C, _ptr(ws), ws.numel() * 4, _stream())
+    if pr is not None:
+        pr.done()
+    return dx
+
+
+def norm_lrelu_bwd_from_partials(dy, x, nstat, groups, out=None):
+    """Backward-data of batch / instance norm (+ lrelu) from the column sums the producing backward-data call left in ``nstat.part``
+    (cgs_norm_lrelu_bwd_from_partials): finalize + one pass over dy and x.  dy / x: [groups * M_group, ..., C] (groups = 1: batch norm)."""
+    _chk(dy, "dy"); _chk(x, "x")
+    C_ = x.shape[-1]
+    Mg = x.numel() // (groups * C_)
+    dx = out if out is not None else torch.empty_like(x)
+    ws = _in_workspace(groups, Mg, C_, x.device) if groups > 1 else _bn_workspace(Mg, C_, x.device)
+    lay = nstat.layout
+    pr = _Prof(0.0, "", _nb(dy, x, dx), op="norm_lrelu_bwd_from_partials") if PROFILE is not None else None
+    L.call("cgs_norm_lrelu_bwd_from_partials", _ptr(dy), _ptr(x), _ptr(nstat.part), groups, lay[1], lay[2], lay[3], _ptr(nstat.gamma), _ptr(nstat.beta),
+           _ptr(nstat.mean), _ptr(nstat.invstd), nstat.leak, _ptr(dx), Mg, C_, _ptr(ws), ws.numel() * 4, _stream())
     if pr is not None:
         pr.done()
     return dx

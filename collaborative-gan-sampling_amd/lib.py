@@ -39,6 +39,9 @@ SIGNATURES = {
     "cgs_conv2d_nhwc_fwd_stats": (_i, [_p] * 4 + [_i] * 9 + [_p, _z, _i, _p, _z, _p]),
     "cgs_conv_stat_layout": (_i, [_i] * 13 + [_z, _p, _p, _p]),
     "cgs_deconv2d_nhwc_fwd_stats": (_i, [_p] * 4 + [_i] * 11 + [_p, _z, _i, _p, _z, _p]),
+    "cgs_conv2d_nhwc_bwd_data_nstats": (_i, [_p] * 3 + [_i] * 9 + [_p] * 5 + [_f, _i, _p, _z, _i, _p, _z, _p]),
+    "cgs_deconv2d_nhwc_bwd_data_nstats": (_i, [_p] * 3 + [_i] * 11 + [_p] * 5 + [_f, _i, _p, _z, _i, _p, _z, _p]),
+    "cgs_norm_lrelu_bwd_from_partials": (_i, [_p] * 3 + [_i] * 4 + [_p] * 4 + [_f, _p, _i, _i, _p, _z, _p]),
     "cgs_groupnorm_lrelu_fwd_from_partials": (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _f, _f, _p, _p, _p, _i, _i, _p, _z, _p]),
     "cgs_bn_train_lrelu_fwd_from_partials": (_i, [_p, _p, _i, _p, _p, _f, _f, _p, _p, _p, _i, _i, _p, _z, _p]),
     "cgs_conv2d_nhwc_bwd_data": (_i, [_p] * 3 + [_i] * 9 + [_i, _p, _p, _p, _z, _i, _p]),

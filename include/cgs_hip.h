@@ -142,7 +142,8 @@ int cgs_conv2d_nhwc_fwd_stats(const float* x, const float* w, const float* bias,
  * reference ships no code for them), and D's batch norm (nsgan/GAN.py:65,67 -> nsgan/ops.py:19-26) when several logical batches
  * share one launch (a group = one logical batch: every batch keeps the statistics the reference computes for it alone).
  * cgs_conv_stat_layout says where a group's partial rows lie in the [rows][2][Cout] buffer that cgs_conv2d_nhwc_fwd_stats
- * (op = CGS_CONV_FWD; Ho, Wo ignored) / cgs_deconv2d_nhwc_fwd_stats (op = CGS_DECONV_FWD) fill: group g owns, for every segment
+ * (op = CGS_CONV_FWD; Ho, Wo ignored) / cgs_deconv2d_nhwc_fwd_stats (op = CGS_DECONV_FWD) fill (and, with the *_BWD_DATA ops, the
+ * [rows][2][Cin] buffer of the *_bwd_data_nstats entry points below): group g owns, for every segment
  * s < *nseg, the *rows_per_seg rows starting at row s * *seg_stride + g * *rows_per_seg.  Returns the buffer's row count; 0 = not
  * available (another kernel family, Cout % 4 != 0, a split batch, parity classes of unequal size, a group that does not end on
  * a 64-row boundary of the launch's row order).  cgs_groupnorm_lrelu_fwd_from_partials (below) consumes it. */
@@ -152,6 +153,33 @@ int cgs_deconv2d_nhwc_fwd_stats(const float* x, const float* w, const float* bia
                                 int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int sh, int sw,
                                 void* ws, size_t ws_bytes, int ws_prepacked,
                                 float* stat_part, size_t stat_part_bytes, void* stream);
+
+/* The BACKWARD half of the same fusion (round 6).  tf.gradients through D's batch norm (sampling/collaborator.py:31 over
+ * nsgan/ops.py:19-26, nsgan/GAN.py:65,67) needs two column sums over the gradient dy that arrives at the norm's output:
+ * sum d and sum d * xhat, d = dy * lrelu'(gamma * xhat + beta), xhat = (x - mean) * invstd.  dy is the RESULT of the backward-data
+ * pass of the convolution above the norm, so that launch can leave them: cgs_conv2d_nhwc_bwd_data_nstats /
+ * cgs_deconv2d_nhwc_bwd_data_nstats are cgs_conv2d_nhwc_bwd_data / cgs_deconv2d_nhwc_bwd_data (no epilogue) that also read
+ * x_norm -- the norm's input, same shape as dx -- and write the sums as partial rows [rows][2][Cin] (one per 64 GEMM rows):
+ * cgs_conv_stat_layout with op = CGS_CONV_BWD_DATA / CGS_DECONV_BWD_DATA (same argument meaning as the entry point's) says where
+ * the rows of every group of group_images consecutive images lie (group_images = B: batch norm over the whole batch; 1: instance
+ * norm; b: fused logical batches), 0 = not available (then: the plain backward-data + cgs_bn_train_lrelu_bwd_data /
+ * cgs_instnorm_lrelu_bwd_data).  mean / invstd are [B / group_images][Cin], gamma / beta [Cin].
+ * cgs_norm_lrelu_bwd_from_partials finishes the norm's backward-data from them: finalize + ONE pass over dy and x (the sums pass of
+ * cgs_bn_train_lrelu_bwd_data -- 2 of its 5 tensor passes -- is gone); dy / x are [groups][M_group][C], dx may be dy.
+ * ws: cgs_bn_ws_bytes(M, C) / cgs_instnorm_ws_bytes(groups, M_group, C) cover it.  Deterministic (fixed reduction trees). */
+int cgs_conv2d_nhwc_bwd_data_nstats(const float* dy, const float* w, float* dx,
+                                    int B, int H, int W, int Cin, int Cout, int kh, int kw, int sh, int sw,
+                                    const float* x_norm, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                    float leak, int group_images, void* ws, size_t ws_bytes, int ws_prepacked,
+                                    float* stat_part, size_t stat_part_bytes, void* stream);
+int cgs_deconv2d_nhwc_bwd_data_nstats(const float* dy, const float* w, float* dx,
+                                      int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int sh, int sw,
+                                      const float* x_norm, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                      float leak, int group_images, void* ws, size_t ws_bytes, int ws_prepacked,
+                                      float* stat_part, size_t stat_part_bytes, void* stream);
+int cgs_norm_lrelu_bwd_from_partials(const float* dy, const float* x, const float* part, int groups, int rows_per_seg, int nseg,
+                                     int seg_stride, const float* gamma, const float* beta, const float* mean, const float* invstd,
+                                     float leak, float* dx, int M_group, int C, void* ws, size_t ws_bytes, void* stream);
 
 /* conv2d backward-data: dx[B,H,W,Cin] = d/dx of the conv above applied to dy[B,Ho,Wo,Cout].
  * Replaces the Conv2DBackpropInput node tf.gradients emits (sampling/collaborator.py:31).

@@ -595,6 +595,100 @@ def test_fused_statistics_per_group_of_images(case, contraction):
     assert torch.equal(part, part2)
 
 
+@pytest.mark.parametrize("case", [
+    # (op of the layer ABOVE the norm, B, H of the gradient it produces, C of that gradient, channels above, k, stride, group_images, leak)
+    ("conv", 10, 16, 64, 128, 5, 2, 10, 0.2),        # batch norm over the whole batch (D's bn1 <- conv2's backward-data), image-major, ragged last tile
+    ("conv", 256, 8, 128, 256, 5, 2, 256, 0.2),      # pixel-major whole tiles, one group
+    ("conv", 256, 16, 64, 128, 5, 2, 64, 0.2),       # pixel-major, four logical batches of 64 (fused batches)
+    ("conv", 8, 32, 64, 128, 4, 2, 1, 0.2),          # instance norm: a group per sample (PatchGAN), image-major, four parity classes
+    ("conv", 8, 16, 64, 64, 3, 1, 1, 0.0),           # stride 1 (the 3x3 convolutions of a residual block), relu
+    ("conv", 6, 16, 32, 36, 3, 2, 2, 1.0),           # groups of two samples, plain norm (leak 1), channel count off the 64 grid above
+    ("deconv", 8, 16, 64, 32, 3, 2, 1, 0.0),         # the layer above is a transposed conv (up-sampling): its backward-data is a strided conv
+    ("deconv", 256, 8, 64, 32, 4, 2, 64, 0.2),       # ... pixel-major
+    ("deconv", 4, 8, 128, 64, 5, 2, 4, 0.2),
+    ("conv", 64, 8, 256, 512, 5, 2, 64, 0.2),        # batch 64: an under-filled grid, split over K -- the reduce pass leaves the sums
+    ("conv", 64, 4, 256, 512, 5, 2, 64, 0.2),
+], ids=lambda c: "-".join(str(v) for v in c))
+def test_backward_data_leaves_the_norm_backward_sums(case):
+    """Round 6 (VERDICT r5 #5a): the backward-data launch of the layer ABOVE a norm produces the gradient at the norm's output, so it
+    leaves the norm backward's two column sums -- sum d, sum d * xhat with d = dy * lrelu'(gamma * xhat + beta) -- per group of images
+    (cgs_conv_stat_layout with the *_BWD_DATA op, cgs_*_bwd_data_nstats); cgs_norm_lrelu_bwd_from_partials then needs one pass over
+    dy and x instead of two.  Held to: the gradient itself is the plain backward-data's (2e-6: another tile plan may sum in another order); the rows the layout assigns to a
+    group sum to that group's float64 sums; the norm's input gradient equals the separate-pass kernels' (which the oracle pins,
+    test_bn_train_lrelu_fwd_bwd) to 1e-5 and the float64 formula to 2e-5; run-to-run bit-identical."""
+    from cgs_amd import kernels as K, lib
+    op, B, H, C, Cabove, k, s_, grp, leak = case
+    d = dev()
+    groups = B // grp
+    x = rnd((B, H, H, C), 1).to(d)                                   # the norm's input (= output of the layer below it)
+    gamma, beta = (rnd((C,), 4, 0.2) + 1).to(d), rnd((C,), 5, 0.1).to(d)
+    _, mean, invstd = K.instnorm_lrelu_fwd(x.view(groups, -1, C), gamma, beta, leak)         # the statistics the forward pass saved
+    if op == "conv":       # above: conv [B,H,H,C] -> [B,Ho,Ho,Cabove]; its backward-data maps g [B,Ho,Ho,Cabove] -> dy [B,H,H,C]
+        Ho = -(-H // s_)
+        w = rnd((k, k, C, Cabove), 2, 0.05).to(d)
+        g = rnd((B, Ho, Ho, Cabove), 3).to(d)
+        lay = K.conv_stat_layout(lib.CONV_BWD_DATA, B, H, H, C, 0, 0, Cabove, k, k, s_, s_, grp)
+        plain = lambda: K.conv2d_bwd_data(g, w, (H, H), s_, s_)
+        fused = lambda ns: K.conv2d_bwd_data(g, w, (H, H), s_, s_, nstat=ns)
+    else:                  # above: deconv [B,H,H,C] -> [B,H*s,H*s,Cabove]; its backward-data is a strided conv of g
+        Ho = H * s_
+        w = rnd((k, k, Cabove, C), 2, 0.05).to(d)
+        g = rnd((B, Ho, Ho, Cabove), 3).to(d)
+        lay = K.conv_stat_layout(lib.DECONV_BWD_DATA, B, H, H, C, Ho, Ho, Cabove, k, k, s_, s_, grp)
+        plain = lambda: K.deconv2d_bwd_data(g, w, (H, H), s_, s_)
+        fused = lambda ns: K.deconv2d_bwd_data(g, w, (H, H), s_, s_, nstat=ns)
+    assert lay is not None
+    part = torch.full((lay[0], 2, C), float("nan"), device=d)
+    ns = K.NormBwdStats(x, mean, invstd, gamma, beta, leak, grp, part, lay)
+    dy = fused(ns)
+    assert lib.last_kernel().startswith("igemm_kernel")
+    dy_plain = plain()
+    close(dy, dy_plain, 2e-6)                                        # the gradient itself (a launch that leaves statistics may take another tile / split plan: same products, another summation order)
+    # the partial rows of every group against float64 sums of the definition
+    rows, rps, nseg, stride = lay
+    xg, dyg = x.double().view(groups, -1, C), dy.double().view(groups, -1, C)
+    mu, inv = mean.double().view(groups, 1, C), invstd.double().view(groups, 1, C)
+    xhat = (xg - mu) * inv
+    dmask = dyg * torch.where(gamma.double() * xhat + beta.double() > 0, 1.0, float(leak))
+    for gi in range(groups):
+        idx = torch.tensor([sg * stride + gi * rps + i for sg in range(nseg) for i in range(rps)], device=d)
+        sums = part[idx].double().sum(0)
+        assert torch.isfinite(sums).all()
+        scale = dmask[gi].abs().sum(0).max().item() + 1e-30         # (sums of signed terms: the bar is relative to the sum of magnitudes)
+        assert (sums[0] - dmask[gi].sum(0)).abs().max().item() <= 2e-6 * scale
+        assert (sums[1] - (dmask[gi] * xhat[gi]).sum(0)).abs().max().item() <= 2e-6 * (dmask[gi] * xhat[gi]).abs().sum(0).max().item() + 1e-30
+    # the norm's input gradient: from the partials == the separate-pass kernels == the float64 formula
+    got = K.norm_lrelu_bwd_from_partials(dy.clone(), x, ns, groups)
+    want = K.instnorm_lrelu_bwd_data(dy.view(groups, -1, C).clone(), x.view(groups, -1, C), gamma, beta, mean, invstd, leak)
+    close(got.reshape(-1), want.reshape(-1), 1e-5)
+    m1, m2 = dmask.mean(1, keepdim=True), (dmask * xhat).mean(1, keepdim=True)
+    ref = gamma.double() * inv * (dmask - m1 - xhat * m2)
+    close(got.reshape(-1), ref.reshape(-1).float(), 2e-5)
+    inplace = dy.clone()                                             # the engine runs it in place
+    assert K.norm_lrelu_bwd_from_partials(inplace, x, ns, groups, out=inplace) is inplace and torch.equal(inplace, got)
+    part2 = torch.full_like(part, float("nan"))                      # determinism
+    ns2 = K.NormBwdStats(x, mean, invstd, gamma, beta, leak, grp, part2, lay)
+    assert torch.equal(fused(ns2), dy) and torch.equal(part2, part)
+
+
+def test_norm_backward_sums_are_refused_where_unsupported():
+    from cgs_amd import kernels as K, lib
+    assert K.conv_stat_layout(lib.CONV_BWD_DATA, 8, 6, 6, 32, 0, 0, 64, 3, 3, 2, 2, 1) is None      # 9 pixels per sample and class: not whole 64-row pieces
+    assert K.conv_stat_layout(lib.CONV_BWD_DATA, 8, 64, 64, 3, 0, 0, 64, 5, 5, 2, 2, 8) is None     # a 3-channel gradient: another kernel family
+    assert K.conv_stat_layout(lib.CONV_BWD_DATA, 8, 16, 16, 6, 0, 0, 64, 3, 3, 1, 1, 8) is None     # C % 4 != 0
+    assert K.conv_stat_layout(lib.DECONV_BWD_DATA, 256, 8, 8, 64, 16, 16, 32, 4, 4, 2, 2, 32) is None   # pixel-major: a group of 32 shares a row
+    K.set_contraction("bx6_all")
+    try:       # the split-bf16 kernel does not leave them: the layout says so and the engine keeps the separate pass
+        assert K.conv_stat_layout(lib.CONV_BWD_DATA, 8, 16, 16, 64, 0, 0, 128, 3, 3, 1, 1, 1) is None
+    finally:
+        K.set_contraction("f32")
+    d = dev()
+    x = rnd((8, 6, 6, 32), 1).to(d)
+    ns = K.NormBwdStats(x, x[:, 0, 0], x[:, 0, 0], x[0, 0, 0], x[0, 0, 0], 0.2, 1, torch.empty((64, 2, 32), device=d), (64, 1, 1, 0))
+    with pytest.raises(lib.CgsError, match="not available"):
+        K.conv2d_bwd_data(rnd((8, 3, 3, 64), 2).to(d), rnd((3, 3, 32, 64), 3).to(d), (6, 6), 2, 2, nstat=ns)
+
+
 def test_group_statistics_layout_is_refused_where_a_group_does_not_own_whole_rows():
     from cgs_amd import kernels as K, lib
     assert K.conv_stat_layout(lib.CONV_FWD, 8, 6, 6, 32, 0, 0, 64, 3, 3, 2, 2, 1) is None          # 9 pixels per sample: not a multiple of 64 rows
