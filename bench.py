@@ -401,7 +401,7 @@ def other_configs(dev, skip, want_cpu):
     return out
 
 
-def class_surface(dev, configs=(("dcgan64", 1024, 20, 6, 3), ("mnist", 64, 50, 24, 4), ("dcgan32", 64, 20, 24, 4))):
+def class_surface(dev, configs=(("dcgan64", 1024, 20, 6, 3), ("mnist", 64, 50, 24, 4), ("dcgan32", 64, 20, 24, 4), ("dcgan32", 256, 20, 16, 6))):
     """What a caller of the reference's CLASS SURFACE gets, as opposed to the engines the headline drives directly:
     ``model.GAN`` + ``collaborator.Refiner`` wired with the very lines of nsgan/GAN.py:171-181 -- a ``functools.partial`` of the
     discriminator and a local loss closure -- then per z batch ``input_to_feature`` (operator API) and ``build_refiner``: one batch
@@ -471,7 +471,8 @@ def class_surface(dev, configs=(("dcgan64", 1024, 20, 6, 3), ("mnist", 64, 50, 2
                             "how": f"refiner.logical_batch = {B}; build_refiner(feature[{B * Gf}], ...): one call, one stream"}
             refiner.logical_batch = None
             del zf
-        out[arch] = rec
+        # (keyed by the net; a second batch size of a net -- BASELINE config 2 at its literal batch 256, one call at a time -- as <net>_b<batch>)
+        out[arch if arch not in out else f"{arch}_b{B}"] = rec
         del self, refiner, generic, z, inputs
         ops.reset_variables()
         torch.cuda.empty_cache()

@@ -52,7 +52,10 @@ def test_bench_line_small_config(tmp_path):
     assert "kernels" not in line and "hbm" not in line and "other_configs" not in line and "note" not in line["roofline"]
     assert len(line["cpu_baseline"]["sample"]) <= 120 and line["cpu_baseline"]["value"] == d["cpu_baseline"]["value"]
     sm = line["summary"]
-    assert set(sm["other_configs"]) == {"dcgan32", "cyclegan256", "synthetic2d"} and set(sm["class_surface"]) >= {"dcgan64", "mnist", "dcgan32"}
+    assert set(sm["other_configs"]) == {"dcgan32", "cyclegan256", "synthetic2d"} and set(sm["class_surface"]) >= {"dcgan64", "mnist", "dcgan32", "dcgan32_b256"}
+    assert d["class_surface"]["dcgan32_b256"]["batch"] == 256 and d["class_surface"]["dcgan32_b256"]["engine"]["path"] == "engine"
+    for arch in ("mnist", "dcgan32"):         # the generic path replays its captured hipGraph (round 6)
+        assert d["class_surface"][arch]["generic"]["hipgraph"] is True
     assert sm["other_configs"]["dcgan32"]["samples_per_s"] == d["other_configs"]["dcgan32"]["samples_per_s"]
     assert sm["f1"]["accepted_samples_per_s"] == d["f1"]["accepted_samples_per_s"] and set(sm["shaping_iteration_ms"]) == {"mnist", "dcgan64"}
     assert d["roofline"]["profile_passes"]["kept"] == "median" and len(d["roofline"]["profile_passes"]["wall_ms"]) == 3

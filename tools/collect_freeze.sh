@@ -19,6 +19,11 @@ for A in mnist dcgan32 cyclegan256; do
 done
 cp $O/shaping/shaping_kernel_stats.csv profiles/${T}_shaping_kernel_stats.csv; grep "^{" $O/shaping_bench.log > profiles/${T}_shaping_bench.log
 grep "^{" $O/bench_default.log > profiles/${T}_final_default_hipgraph_bench.log
+# the full records behind the compact lines (round 6: the line names its sidecar; kept per run)
+cp $O/bench_default_detail.json profiles/${T}_final_default_hipgraph_bench_detail.json
+cp $O/s1_bench_detail.json profiles/${T}_final_streams1_bench_detail.json
+cp $O/bx6_bench_detail.json profiles/${T}_final_bx6_streams1_bench_detail.json
+for A in mnist dcgan32 cyclegan256; do cp $O/${A}_bench_detail.json profiles/${T}_final_${A}_streams1_bench_detail.json; done
 python - "$T" <<'PY'
 import csv, sys
 T = sys.argv[1]
