@@ -139,8 +139,12 @@ int cgs_pack_weights(const IgemmParams& p, const CgsLayer& L, bool dirT, const f
 // NW waves per block, arranged 2 (M) x NW/2 (N); wave tile (BM/2) x (BN/(NW/2)).
 // PAR: parity-first tap order (a compile-time variant: the extra scalar decode slowed the natural-order layers by ~0.8 %
 // when it was a run-time flag).
-template <int BM, int BN, int NW, bool VEC, int TBK, bool PAR>
-__global__ __launch_bounds__(64 * NW, 2) void igemm_kernel(IgemmParams p) {
+// NS: the epilogue can also leave the norm-BACKWARD column sums (IgemmParams::ns_*).  A compile-time twin, not a run-time branch of the one
+// kernel: the branch's mere presence cost the launches that never take it 6 % (the dominant kernel of the headline 680 -> 724 us per launch in
+// alternating processes on one box, profiles/r06_l_nstat_branch_presence_ab.txt) -- so igemm_kernel is compiled without it, exactly as
+// before round 6, and only the launches that want the sums run igemm_ns_kernel.
+template <int BM, int BN, int NW, bool VEC, int TBK, bool PAR, bool NS>
+__device__ __forceinline__ void igemm_body(const IgemmParams& p) {
     constexpr int BK = TBK;                       // K tile (shadows the packing granule; TBK divides it)
     constexpr int LDA = BK + 4;                   // padded A row (floats): keeps the b128 fragment reads conflict-free
     constexpr int NT = 64 * NW;                   // threads per block
@@ -812,12 +816,12 @@ __global__ __launch_bounds__(64 * NW, 2) void igemm_kernel(IgemmParams p) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             if (n < p.N) {
                 const int* rp = rowpix + wm * (BM / WM) + ph * ER;
-                if (p.stat_part && p.ns_mean) {   // norm-BACKWARD statistics of the gradient this launch produces (IgemmParams::ns_*)
+                if constexpr (NS) {               // norm-BACKWARD statistics of the gradient this launch produces (IgemmParams::ns_*; the launcher picks this twin for them only)
                     // a wave's 64 rows lie in ONE statistics group (cgs_conv_stat_layout admits only such launches): its parameters once per wave and pass
                     const int mw = m0 + wm * (BM / WM);
                     const int grp = p.ns_gimg <= 0 ? 0 : (p.pix_major ? (mw % p.B) : (mw / RC)) / p.ns_gimg;
                     const NsLane ns = ns_lane_params(p, grp, n);
-                    epilogue_rows<CGS_EPI_NONE, ER, RPP, LDE, 2>(p, E, rp, rsub, c4, n, bias, ea, eb, &st_a, &st_b, &ns);
+                    epilogue_rows<CGS_EPI_NONE, ER, RPP, LDE, 2, (VEC ? 4 : 1)>(p, E, rp, rsub, c4, n, bias, ea, eb, &st_a, &st_b, &ns);
                 } else if (p.stat_part) {        // (only with CGS_EPI_NONE: the statistics are those of the stored tensor)
                     epilogue_rows<CGS_EPI_NONE, ER, RPP, LDE, 1>(p, E, rp, rsub, c4, n, bias, ea, eb, &st_a, &st_b);
                 } else if (p.sign_out) {  // (N % 32 == 0: every lane of the wave is inside N, the ballots see whole rows)
@@ -889,6 +893,11 @@ __global__ __launch_bounds__(64 * NW, 2) void igemm_kernel(IgemmParams p) {
             }
     }
 }
+
+template <int BM, int BN, int NW, bool VEC, int TBK, bool PAR>
+__global__ __launch_bounds__(64 * NW, 2) void igemm_kernel(IgemmParams p) { igemm_body<BM, BN, NW, VEC, TBK, PAR, false>(p); }
+template <int BM, int BN, int NW, bool VEC, int TBK, bool PAR>
+__global__ __launch_bounds__(64 * NW, 2) void igemm_ns_kernel(IgemmParams p) { igemm_body<BM, BN, NW, VEC, TBK, PAR, true>(p); }
 
 // out[pix(m)][n] = epi(bias[n] + sum_s slab[s][m][n]): fixed summation order -> deterministic
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(IgemmParams p) {
@@ -1304,8 +1313,9 @@ size_t cgs_igemm_splitk_bytes(const IgemmParams& p) {
     return n * sizeof(float);
 }
 
-template <int BM, int BN, int NW, bool VEC, int TBK, bool PAR = false>
+template <int BM, int BN, int NW, bool VEC, int TBK, bool PAR, bool NS>
 static int launch_cfg(const IgemmParams& p, hipStream_t s) {
+    void (*const kern)(IgemmParams) = NS ? igemm_ns_kernel<BM, BN, NW, VEC, TBK, PAR> : igemm_kernel<BM, BN, NW, VEC, TBK, PAR>;
     constexpr int EH = (VEC && TBK == 16) ? 2 : 1;
     constexpr int WM = BM / 64;
     constexpr size_t kloop_f = (size_t)2 * BM * (TBK + 4) + 2 * TBK * BN, stage_f = (size_t)NW * (BM / WM / EH) * (BN / (NW / WM) + 4);
@@ -1315,8 +1325,7 @@ static int launch_cfg(const IgemmParams& p, hipStream_t s) {
     (void)hipGetDevice(&dev_);
     dev_ &= 63;
     if (!attr_done[dev_]) {
-        hipError_t e = hipFuncSetAttribute((const void*)igemm_kernel<BM, BN, NW, VEC, TBK, PAR>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return cgs_set_error(CGS_ELAUNCH, "igemm smem attr: %s", hipGetErrorString(e));
         attr_done[dev_] = true;
     }
@@ -1359,7 +1368,7 @@ static int launch_cfg(const IgemmParams& p, hipStream_t s) {
     }
 #endif
     if (gx > 0x7fffffffL) return cgs_set_error(CGS_EINVAL, "igemm: grid too large");
-    hipLaunchKernelGGL((igemm_kernel<BM, BN, NW, VEC, TBK, PAR>), dim3((unsigned)gx, gy, p.splitk > 1 ? p.splitk : 1), dim3(64 * NW), smem, s, q);
+    hipLaunchKernelGGL(kern, dim3((unsigned)gx, gy, p.splitk > 1 ? p.splitk : 1), dim3(64 * NW), smem, s, q);
     CGS_CHECK_LAUNCH("igemm");
     if (p.tail_s > 1) {
         hipLaunchKernelGGL(tail_reduce_kernel, dim3((unsigned)p.tail_n, TAIL_RSPLIT), dim3(256), 0, s, q, BM, BN);
@@ -1375,7 +1384,7 @@ static int launch_cfg(const IgemmParams& p, hipStream_t s) {
     }
     // the name rocprofv3 prints for this instantiation
     static char name[64];
-    snprintf(name, sizeof(name), "igemm_kernel<%d, %d, %d, %s, %d, %s>", BM, BN, NW, VEC ? "true" : "false", TBK, PAR ? "true" : "false");
+    snprintf(name, sizeof(name), "%s<%d, %d, %d, %s, %d, %s>", NS ? "igemm_ns_kernel" : "igemm_kernel", BM, BN, NW, VEC ? "true" : "false", TBK, PAR ? "true" : "false");
     cgs_note_kernel(name);
     return CGS_OK;
 }
@@ -1578,11 +1587,15 @@ int cgs_igemm_launch(const IgemmParams& p_in, void* slab, size_t slab_bytes, hip
 #ifdef CGS_EXPERIMENT
     if (getenv("CGS_BM64")) half = half && atoi(getenv("CGS_BM64")) != 0;
 #endif
-    if (half) return launch_cfg<64, 128, 4, true, 32>(p, s);
-    if (tall) return p.tap_parity ? launch_cfg<256, 64, 4, true, 16, true>(p, s) : launch_cfg<256, 64, 4, true, 16>(p, s);
-    if (vec && !deep && !p.tap_parity) return wide ? launch_cfg<128, 128, 4, true, 16>(p, s) : launch_cfg<128, 64, 4, true, 16>(p, s);
-    if (vec && !deep && p.tap_parity) return wide ? launch_cfg<128, 128, 4, true, 16, true>(p, s) : launch_cfg<128, 64, 4, true, 16, true>(p, s);
-    if (vec && p.tap_parity) return wide ? launch_cfg<128, 128, 4, true, 32, true>(p, s) : launch_cfg<128, 64, 4, true, 32, true>(p, s);
-    if (vec) return wide ? launch_cfg<128, 128, 4, true, 32>(p, s) : launch_cfg<128, 64, 4, true, 32>(p, s);
-    return wide ? launch_cfg<128, 128, 4, false, 16>(p, s) : launch_cfg<128, 64, 4, false, 16>(p, s);
+    // (a launch that leaves the norm-backward sums runs the igemm_ns_kernel twin of its tile; every other launch the kernel of the rounds before)
+    const bool ns = p.stat_part && p.ns_mean;
+#define LC(...) (ns ? launch_cfg<__VA_ARGS__, true>(p, s) : launch_cfg<__VA_ARGS__, false>(p, s))
+    if (half) return LC(64, 128, 4, true, 32, false);
+    if (tall) return p.tap_parity ? LC(256, 64, 4, true, 16, true) : LC(256, 64, 4, true, 16, false);
+    if (vec && !deep && !p.tap_parity) return wide ? LC(128, 128, 4, true, 16, false) : LC(128, 64, 4, true, 16, false);
+    if (vec && !deep && p.tap_parity) return wide ? LC(128, 128, 4, true, 16, true) : LC(128, 64, 4, true, 16, true);
+    if (vec && p.tap_parity) return wide ? LC(128, 128, 4, true, 32, true) : LC(128, 64, 4, true, 32, true);
+    if (vec) return wide ? LC(128, 128, 4, true, 32, false) : LC(128, 64, 4, true, 32, false);
+    return wide ? LC(128, 128, 4, false, 16, false) : LC(128, 64, 4, false, 16, false);
+#undef LC
 }

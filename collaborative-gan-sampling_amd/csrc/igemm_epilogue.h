@@ -54,10 +54,46 @@ __device__ __forceinline__ NsLane ns_lane_params(const IgemmParams& p, int group
 
 // ST: 0 = no statistics; 1 = fused norm statistics of the stored values (sum, sum of squares); 2 = norm-BACKWARD statistics: the stored
 // value y is a gradient w.r.t. the output of norm + lrelu over x = ep_aux (same shape): sums of d = y * lrelu'(sc * x + sh) and d * xhat.
-template <int EPI, int ROWS, int RPP, int LDE, int ST = 0>
+template <int EPI, int ROWS, int RPP, int LDE, int ST = 0, int NSU = 1>
 __device__ __forceinline__ void epilogue_rows(const IgemmParams& p, const float* E, const int* rowpix_tile, int rsub, int c4,
                                               int n, f32x4 bias, f32x4 ea, f32x4 eb, f32x4* sa = nullptr, f32x4* sb = nullptr,
                                               const NsLane* ns = nullptr) {
+    if constexpr (ST == 2 && NSU > 1) {
+        // Norm-backward statistics: x is needed for the SUMS only, not for the value stored, and the compiler may not move a load of
+        // ep_aux above an earlier store to out (it cannot know they do not overlap) -- so the rows go in groups of NSU: all x loads of a
+        // group are issued first, then its rows are stored and summed (load -> use -> store per row held the block's slot for a memory
+        // latency per row).  Same arithmetic, same order of additions per lane.  (NSU = 1, the generic-K kernels: row by row -- the group's
+        // registers would be those kernels' peak and cost them a resident block)
+        constexpr int ITERS = ROWS / RPP;
+        static_assert(ITERS % NSU == 0, "row groups");
+#pragma unroll
+        for (int it0 = 0; it0 < ITERS; it0 += NSU) {
+            f32x4 xs[NSU];
+            int pixs[NSU];
+#pragma unroll
+            for (int u = 0; u < NSU; ++u) {
+                pixs[u] = rowpix_tile[(it0 + u) * RPP + rsub];
+                xs[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (pixs[u] >= 0) xs[u] = *(const f32x4*)(p.ep_aux + (size_t)pixs[u] * p.N + n);
+            }
+#pragma unroll
+            for (int u = 0; u < NSU; ++u) {
+                if (pixs[u] < 0) continue;
+                const f32x4 v = *(const f32x4*)(E + ((it0 + u) * RPP + rsub) * LDE + c4);
+                f32x4 y;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[e] = v[e] + bias[e];
+                *(f32x4*)(p.out + (size_t)pixs[u] * p.N + n) = y;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {          // the arithmetic of bn_partial_kernel<1>, element by element
+                    const float uu = fmaf(xs[u][e], ns->sc[e], ns->sh[e]);
+                    const float d = y[e] * (uu > 0.f ? 1.f : ns->leak);
+                    (*sa)[e] += d; (*sb)[e] = fmaf(d, (xs[u][e] - ns->mu[e]) * ns->inv[e], (*sb)[e]);
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int it = 0; it < ROWS / RPP; ++it) {
         const int lrow = it * RPP + rsub;
@@ -75,7 +111,7 @@ __device__ __forceinline__ void epilogue_rows(const IgemmParams& p, const float*
 #pragma unroll
             for (int e = 0; e < 4; ++e) { (*sa)[e] += y[e]; (*sb)[e] = fmaf(y[e], y[e], (*sb)[e]); }
         }
-        if (ST == 2) {   // the arithmetic of bn_partial_kernel<1>, element by element
+        if (ST == 2) {   // (NSU == 1: row by row) the arithmetic of bn_partial_kernel<1>, element by element
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float u = fmaf(aux[e], ns->sc[e], ns->sh[e]);

@@ -459,12 +459,11 @@ def link_backward_fusion(stages):
         below.pre_folded = True
 
 
-# Largest norm input (bytes) whose backward sums ride on the backward-data launch above it.  The epilogue then reads x once more per block
-# while the block's slot is held: on the matrix-bound launches of the big batches that costs the kernel about what the separate sums pass
-# took (dcgan64 at batch 1024, 134 / 67 MB tensors: +-0.5 % of the step, and the dominant kernel's average duration --
-# the number its roofline fraction is computed from -- 7 % longer); the launch-latency-bound sizes are where it pays (a launch and a pass
-# less: dcgan64 at batch 64 -2.8 %, config 5's 8-image batches -1.4 %).  (CGS_NSTAT_MAX_MB overrides it for A/B measurements.)
-NSTAT_MAX_BYTES = 48 * 2 ** 20
+# Largest norm input (bytes) whose backward sums ride on the backward-data launch above it; None = no limit (the default).  With the sums
+# epilogue in a kernel twin of its own (csrc/igemm.hip, igemm_ns_kernel) the fusion is a gain or a wash at every size measured (same-process
+# A/B over limits, profiles/r06_m_*: dcgan64 at batch 1024 -0.2 %, cyclegan256 -0.7 %, dcgan64 at batch 64 -2.3 %, dcgan32 at batch 256 -2.4 %).
+# (CGS_NSTAT_MAX_MB overrides it for A/B measurements: 0 = never.)
+NSTAT_MAX_BYTES = None
 
 
 def link_norm_backward_stats(stages, B):
@@ -489,8 +488,9 @@ def link_norm_backward_stats(stages, B):
         else:
             continue
         C = below.out.shape[-1]
-        if below.out.numel() * 4 > NSTAT_MAX_BYTES * (float(os.environ["CGS_NSTAT_MAX_MB"]) / (NSTAT_MAX_BYTES / 2 ** 20) if os.environ.get("CGS_NSTAT_MAX_MB") else 1.0):
-            continue                      # (a large, matrix-bound launch: see NSTAT_MAX_BYTES)
+        limit = float(os.environ["CGS_NSTAT_MAX_MB"]) * 2 ** 20 if os.environ.get("CGS_NSTAT_MAX_MB") else NSTAT_MAX_BYTES
+        if limit is not None and below.out.numel() * 4 > limit:
+            continue
         if isinstance(above, _Conv):
             H, W, Cin = above.dx.shape[1:]
             kh, kw, _, Cout = above.w.shape

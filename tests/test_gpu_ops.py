@@ -641,7 +641,7 @@ def test_backward_data_leaves_the_norm_backward_sums(case):
     part = torch.full((lay[0], 2, C), float("nan"), device=d)
     ns = K.NormBwdStats(x, mean, invstd, gamma, beta, leak, grp, part, lay)
     dy = fused(ns)
-    assert lib.last_kernel().startswith("igemm_kernel")
+    assert lib.last_kernel().startswith("igemm_ns_kernel")            # the twin with the sums epilogue; every other launch keeps igemm_kernel
     dy_plain = plain()
     close(dy, dy_plain, 2e-6)                                        # the gradient itself (a launch that leaves statistics may take another tile / split plan: same products, another summation order)
     # the partial rows of every group against float64 sums of the definition

@@ -18,7 +18,7 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KEEP = ("igemm_kernel", "igemm_bx6", "convt_quad", "convt_rows", "conv_patch", "conv_smalln", "convt_smalln", "bn_", "refine_update", "linear_out1")
+KEEP = ("igemm_kernel", "igemm_ns_kernel", "igemm_bx6", "convt_quad", "convt_rows", "conv_patch", "conv_smalln", "convt_smalln", "bn_", "refine_update", "linear_out1")
 
 
 def short(name):

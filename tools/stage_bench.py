@@ -72,7 +72,7 @@ def show(best, info):
     out = []
     for t, (k, f, tn, ts) in zip(best, info):
         out.append(f"{t:8.1f} us {f / t / 1e6 / 157.3:.3f}" + (f" tail {tn}x{ts}" if ts else ""))
-    return " | ".join(out) + "  " + info[0][0].replace("igemm_kernel", "ig")
+    return " | ".join(out) + "  " + info[0][0].replace("igemm_ns_kernel", "ig-ns").replace("igemm_kernel", "ig")
 
 
 tot = [0.0] * len(modes)
