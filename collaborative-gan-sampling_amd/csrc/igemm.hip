@@ -821,7 +821,9 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p) {
                     const int mw = m0 + wm * (BM / WM);
                     const int grp = p.ns_gimg <= 0 ? 0 : (p.pix_major ? (mw % p.B) : (mw / RC)) / p.ns_gimg;
                     const NsLane ns = ns_lane_params(p, grp, n);
-                    epilogue_rows<CGS_EPI_NONE, ER, RPP, LDE, 2, (VEC ? 4 : 1)>(p, E, rp, rsub, c4, n, bias, ea, eb, &st_a, &st_b, &ns);
+                    // (x loads of four rows in flight only in the 32-deep kernels -- the few-block launches, where a row's memory latency is exposed and the
+                    // registers are free (167 either way); in the 16-deep kernels the group's registers cost the fourth resident block: 140 against 122)
+                    epilogue_rows<CGS_EPI_NONE, ER, RPP, LDE, 2, ((VEC && TBK == 32) ? 4 : 1)>(p, E, rp, rsub, c4, n, bias, ea, eb, &st_a, &st_b, &ns);
                 } else if (p.stat_part) {        // (only with CGS_EPI_NONE: the statistics are those of the stored tensor)
                     epilogue_rows<CGS_EPI_NONE, ER, RPP, LDE, 1>(p, E, rp, rsub, c4, n, bias, ea, eb, &st_a, &st_b);
                 } else if (p.sign_out) {  // (N % 32 == 0: every lane of the wave is inside N, the ballots see whole rows)
