@@ -459,11 +459,12 @@ def link_backward_fusion(stages):
         below.pre_folded = True
 
 
-# Largest norm input (bytes) whose backward sums ride on the backward-data launch above it; None = no limit (the default).  With the sums
-# epilogue in a kernel twin of its own (csrc/igemm.hip, igemm_ns_kernel) the fusion is a gain or a wash at every size measured (same-process
-# A/B over limits, profiles/r06_m_*: dcgan64 at batch 1024 -0.2 %, cyclegan256 -0.7 %, dcgan64 at batch 64 -2.3 %, dcgan32 at batch 256 -2.4 %).
-# (CGS_NSTAT_MAX_MB overrides it for A/B measurements: 0 = never.)
-NSTAT_MAX_BYTES = None
+# Largest norm input (bytes) whose backward sums ride on the backward-data launch above it.  The fusion pays where launches are latency-bound
+# (the reference's batch 64, single calls of <= 256 images, config 5's 8-image batches: -0.7 ... -2.8 % per call); on the
+# matrix-bound launches of the big batches (dcgan64 at batch 1024: 67 / 134 MB norm inputs) it is a wash -- the sums twin's dearer epilogue and the
+# saved pass cancel, -0.2 % +- the noise of a same-process A/B (profiles/r06_m_*, r06_o_*) -- and those launches would merely move from the
+# headline's dominant kernel to its twin's name in every kernel table.  (CGS_NSTAT_MAX_MB overrides it for A/B measurements: 0 = never.)
+NSTAT_MAX_BYTES = 48 * 2 ** 20
 
 
 def link_norm_backward_stats(stages, B):
