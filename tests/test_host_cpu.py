@@ -372,8 +372,17 @@ def test_group_statistics_layout_is_host_arithmetic():
     assert layout(lib.DECONV_FWD, 8, 16, 64, 32, 32, 3, 2, 1) == (128, 4, 4, 32)
     # fused logical batches (4 x 64) of D's batch norm, pixel-major whole tiles: a row = 64 images of ONE of the 64 output pixels
     assert layout(lib.CONV_FWD, 256, 16, 32, 0, 64, 5, 2, 64) == (256, 1, 64, 4)
-    # the whole batch as one group is always a valid grouping of an available layout
-    assert layout(lib.CONV_FWD, 256, 16, 32, 0, 64, 5, 2, 256) == (256, 4, 64, 4)
+    # the whole batch as one group owns every partial row, whatever the row order (round 6: one segment of all rows -- also where a
+    # proper grouping is refused, e.g. 9 pixels per sample)
+    assert layout(lib.CONV_FWD, 256, 16, 32, 0, 64, 5, 2, 256) == (256, 256, 1, 0)
+    assert layout(lib.CONV_FWD, 8, 6, 32, 0, 64, 3, 2, 8) == (2, 2, 1, 0)
+    # round 6: the same question for the BACKWARD-DATA launches that leave a norm backward's column sums (cgs_*_bwd_data_nstats): the rows are
+    # those of the gradient the launch writes -- conv 32x32x32 -> 16x16x64, stride 2: its backward-data runs four parity classes of 16x16 pixels
+    # over the 32-channel input side, a sample's 4 rows in each class, classes 2 * ceil(8 * 256 / 128) = 32 rows apart
+    assert layout(lib.CONV_BWD_DATA, 8, 32, 32, 0, 64, 4, 2, 1) == (128, 4, 4, 32)
+    # ... a transposed conv's backward-data is a strided forward conv of the gradient: one class, 16 pixels of 256 images pixel-major
+    assert layout(lib.DECONV_BWD_DATA, 256, 4, 64, 8, 32, 4, 2, 64) == (64, 1, 16, 4)
+    assert layout(lib.CONV_BWD_DATA, 8, 64, 3, 0, 64, 5, 2, 8)[0] == 0           # a 3-channel gradient: another kernel family
     # refused: 9 pixels per sample; a logical batch of 32 under the pixel-major order; odd output (unequal parity classes); 3-channel family
     assert layout(lib.CONV_FWD, 8, 6, 32, 0, 64, 3, 2, 1)[0] == 0
     assert layout(lib.CONV_FWD, 256, 16, 32, 0, 64, 5, 2, 32)[0] == 0
