@@ -818,7 +818,9 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p) {
                 const int* rp = rowpix + wm * (BM / WM) + ph * ER;
                 if constexpr (NS) {               // norm-BACKWARD statistics of the gradient this launch produces (IgemmParams::ns_*; the launcher picks this twin for them only)
                     // a wave's 64 rows lie in ONE statistics group (cgs_conv_stat_layout admits only such launches): its parameters once per wave and pass
-                    const int mw = m0 + wm * (BM / WM);
+                    // (a wave whose 64 rows all lie past M -- the second half of a last tile with M % 128 == 64 -- stores nothing, but its parameter
+                    // loads must still hit a real group: row M - 1's.  Found by the topology fuzz: batch 3 x 64 pixels read the statistics of "sample 3")
+                    const int mw = min(m0 + wm * (BM / WM), M - 1);
                     const int grp = p.ns_gimg <= 0 ? 0 : (p.pix_major ? (mw % p.B) : (mw / RC)) / p.ns_gimg;
                     const NsLane ns = ns_lane_params(p, grp, n);
                     // (x loads of four rows in flight only in the 32-deep kernels -- the few-block launches, where a row's memory latency is exposed and the

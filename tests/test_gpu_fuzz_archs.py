@@ -148,6 +148,32 @@ def kink_flips(name, P, f0_ref, eng, fwd_tol=1e-4):
     return small, large
 
 
+def oracle_grad_on_engine_branch(name, P, f0_ref, eng):
+    """The oracle's refinement gradient with every relu / lrelu taking the side the ENGINE's forward took (the sign of its resident
+    activation output) instead of deciding it from its own pre-activation: the exact gradient of the piecewise-linear branch the GPU
+    evaluated.  Needed where D runs a BATCH norm: one element that lands on the other side of a kink in ONE sample changes that norm's
+    batch statistics' gradient, i.e. EVERY sample's gradient (found by a longer hunt in the split-bf16 mode, seed 1621: 10 of 16 samples
+    off by up to 16 % of max|grad| behind a single rounding-level flip) -- excusing the flipped sample alone is then not enough, and
+    excusing all of them would assert nothing.  On the evaluated branch the per-sample bar holds for all samples again."""
+    from oracle import ops_ref as R
+    masks = [(t.detach().cpu() > 0) for t in engine_kink_outputs(eng)]
+    relu0, lrelu0 = torch.relu, R.lrelu
+
+    def relu_f(x, *a, **k):
+        return x * masks.pop(0).to(x.dtype)
+
+    def lrelu_f(x, leak=0.2, *a, **k):
+        m = masks.pop(0).to(x.dtype)
+        return x * (m + (1.0 - m) * leak)
+    torch.relu, R.lrelu = relu_f, lrelu_f
+    try:
+        _, grad = S.forward_logits_and_grad(f0_ref, lambda f: N.feature_to_data(name, P, f), lambda x: N.discriminator(name, P, x))
+    finally:
+        torch.relu, R.lrelu = relu0, lrelu0
+    assert not masks, "activation sites do not line up"
+    return grad
+
+
 LAST = {"degenerate": False}      # set by run_topology: the oracle's gradient of the last topology was identically zero
 
 
@@ -189,13 +215,26 @@ def run_topology(seed, use_graph, contraction="f32"):
                 excused = (~ok) & small & ~large
                 print(f"fuzz seed {seed}: gradient off in samples {(~ok).nonzero().flatten().tolist()}, "
                       f"kink flips at rounding-level elements in {small.nonzero().flatten().tolist()}, at large ones in {large.nonzero().flatten().tolist()}")
-                assert bool((ok | excused).all()) and int(excused.sum()) <= max(1, B // 4), \
-                    f"grad: max rel {per.max().item():.3e}; failing samples {(~ok).nonzero().flatten().tolist()}, of which excused {excused.nonzero().flatten().tolist()}"
-                keep = ~excused
+                if bool((ok | excused).all()):
+                    assert int(excused.sum()) <= max(1, B // 4), f"too many kink-excused samples: {excused.nonzero().flatten().tolist()}"
+                    keep = ~excused
+                else:
+                    # samples WITHOUT a flip of their own are off too: legitimate only if a batch norm of D couples them to a flipped one --
+                    # then the whole batch is held to the oracle's gradient ON THE BRANCH THE ENGINE EVALUATED, at the same per-sample bar
+                    coupled = any(L[0] == "bn" for L in A["d"])
+                    assert coupled and bool(small.any()) and not bool(large.any()) and int(small.sum()) <= max(1, B // 4), \
+                        f"grad: max rel {per.max().item():.3e}; failing samples {(~ok).nonzero().flatten().tolist()}, of which excused {excused.nonzero().flatten().tolist()}"
+                    gb = oracle_grad_on_engine_branch(name, P, f0_ref, eng).double()
+                    per_b = ((g - gb).abs() / gb.abs().max()).reshape(B, -1)
+                    ok_b = ((per_b < 2e-3).double().mean(dim=1) > 0.95) & (per_b.max(dim=1).values < 0.3)
+                    print(f"fuzz seed {seed}: against the oracle's gradient on the evaluated branch: max rel {per_b.max().item():.3e}")
+                    assert bool(ok_b.all()), f"grad on the evaluated branch: max rel {per_b.max().item():.3e}; failing samples {(~ok_b).nonzero().flatten().tolist()}"
+                    keep = torch.zeros(B, dtype=torch.bool)          # (the K-step images of a coupled batch all follow the other branch)
         want = S.collaborative_refine(f0_ref, gt, dd, Ksteps, 0.1)
         img, dl, ol, os_, of = eng.refine(f0, Ksteps, 0.1)
         close(dl, want[1], 2e-4, "default logit")
-        close(img.cpu()[keep], want[0][keep], 5e-2, "images")   # two steps downstream of the kink effect above; a wrong kernel is off by O(1)
+        if bool(keep.any()):
+            close(img.cpu()[keep], want[0][keep], 5e-2, "images")   # two steps downstream of the kink effect above; a wrong kernel is off by O(1)
     finally:
         N.ARCHS.pop(name, None)
         nets.ARCHS.pop(name, None)

@@ -606,6 +606,8 @@ def test_fused_statistics_per_group_of_images(case, contraction):
     ("deconv", 8, 16, 64, 32, 3, 2, 1, 0.0),         # the layer above is a transposed conv (up-sampling): its backward-data is a strided conv
     ("deconv", 256, 8, 64, 32, 4, 2, 64, 0.2),       # ... pixel-major
     ("deconv", 4, 8, 128, 64, 5, 2, 4, 0.2),
+    ("deconv", 3, 8, 128, 3, 3, 2, 1, 0.0),          # M = 3 x 64 rows: the last tile's second wave lies past M (its parameter loads must stay inside); generic-K kernel (3 channels above)
+    ("conv", 3, 8, 64, 96, 3, 1, 1, 0.2),            # the same raggedness in the 32-channel-chunk kernels
     ("conv", 64, 8, 256, 512, 5, 2, 64, 0.2),        # batch 64: an under-filled grid, split over K -- the reduce pass leaves the sums
     ("conv", 64, 4, 256, 512, 5, 2, 64, 0.2),
 ], ids=lambda c: "-".join(str(v) for v in c))
