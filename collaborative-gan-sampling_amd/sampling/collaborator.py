@@ -65,6 +65,11 @@ class Refiner():
         self.why_generic = None         # why the last engine detection said no (None while the engine is taken)
 
     def set_env(self, discriminator, feature_to_data, func_loss):
+        if (getattr(self, "discriminator", None) is not discriminator or getattr(self, "feature_to_data", None) is not feature_to_data
+                or getattr(self, "func_loss", None) is not func_loss):
+            # other callables: the generic path's recorded programs belong to the old ones
+            self._generic_graphs.clear()
+            self._generic_seen.clear()
         self.discriminator = discriminator
         self.feature_to_data = feature_to_data
         self.func_loss = func_loss

@@ -229,6 +229,18 @@ def test_generic_path_replays_a_captured_hipgraph(path):
     assert torch.equal(img_w, img_w2) and not torch.equal(img_w, img_g)
     with torch.no_grad():
         ops.variables()[key].div_(1.01)
+    # set_env with OTHER callables drops the recorded programs (they belong to the old ones); the same objects again keep them
+    other = make()
+    for _ in range(3):
+        other.build_refiner(f0, real, mode, indices=idx)
+    assert len(other._generic_graphs) == 1
+    other.set_env(other.discriminator, other.feature_to_data, other.func_loss)
+    assert len(other._generic_graphs) == 1
+    scale = 0.5
+    other.set_env(lambda x: gan.discriminator(x, is_training=True, reuse=True) * scale, other.feature_to_data, other.func_loss)
+    assert len(other._generic_graphs) == 0 and not other._generic_seen
+    img_s = [other.build_refiner(f0, real, mode, indices=idx) for _ in range(3)]
+    assert len(other._generic_graphs) == 1 and torch.equal(img_s[0], img_s[2]) and not torch.equal(other.default_logit, ref.default_logit)
     # a callable that synchronises with the host cannot be captured: eager launches in the same process, and the refiner says why
     bad = Refiner(int(g["K"][0]), float(g["rate"][0]))
 
