@@ -245,3 +245,64 @@ def test_many_block_launch_equals_its_small_batch_pieces(B, H, Cin, Cout, k, con
     dz = rnd(tuple(z.shape), 6).to(d)
     dxx = K.deconv2d_bwd_data(dz, wt, (H, H), 2, 2)
     assert torch.allclose(dxx, pieces(lambda g: K.deconv2d_bwd_data(g, wt, (H, H), 2, 2), dz), rtol=0, atol=2e-5 * dxx.abs().max().item())
+
+
+def nstat_cases(seed, n):
+    """Random (layer above the norm, batch, gradient map, channels, kernel, stride, images per statistics group, leak) for the norm-backward
+    sums fused into a backward-data launch: channel counts on and off the 32-channel vector path, ragged last tiles (M % 128 != 0), whole
+    batch / per sample / groups of samples, batches that take the pixel-major order and that are split over K."""
+    rs = np.random.RandomState(seed)
+    out = []
+    while len(out) < n:
+        op = str(rs.choice(["conv", "deconv"]))
+        B = int(rs.choice([1, 2, 3, 6, 16, 64, 128, 256]))
+        H = int(rs.choice([4, 6, 8, 12, 16]))
+        C = int(rs.choice([4, 8, 32, 64, 96, 128]))
+        Cab = int(rs.choice([3, 32, 36, 64, 128, 256]))
+        k, s = int(rs.choice([3, 4, 5])), int(rs.choice([1, 2]))
+        if op == "deconv" and s == 1:
+            s = 2
+        grp = int(rs.choice([g for g in (1, 2, 64, B) if B % g == 0]))
+        leak = float(rs.choice([0.0, 0.2, 1.0]))
+        if B * H * H * max(C, Cab) * (s * s if op == "deconv" else 1) > 6_000_000:
+            continue
+        out.append((op, B, H, C, Cab, k, s, grp, leak))
+    return out
+
+
+@pytest.mark.parametrize("case", nstat_cases(4000 + SEED, max(12, N_CASES // 2)), ids=lambda c: "-".join(str(v) for v in c))
+def test_fuzz_norm_backward_sums_in_the_backward_data_epilogue(case):
+    """cgs_conv_stat_layout(*_BWD_DATA) + cgs_*_bwd_data_nstats + cgs_norm_lrelu_bwd_from_partials on random shapes: wherever the library offers
+    the fusion, the norm's input gradient from the fused sums equals the separate-pass kernels' (1e-5) -- which the oracle pins -- and the
+    gradient map itself is the plain backward-data's."""
+    from cgs_amd import kernels as K, lib
+    op, B, H, C, Cab, k, s_, grp, leak = case
+    d = dev()
+    if op == "conv":
+        Ho = -(-H // s_)
+        lay = K.conv_stat_layout(lib.CONV_BWD_DATA, B, H, H, C, 0, 0, Cab, k, k, s_, s_, grp)
+    else:
+        Ho = H * s_
+        lay = K.conv_stat_layout(lib.DECONV_BWD_DATA, B, H, H, C, Ho, Ho, Cab, k, k, s_, s_, grp)
+    if lay is None:
+        pytest.skip("the fusion is not offered for this call (kernel family, channel count, or a group that does not own whole 64-row pieces)")
+    groups = B // grp
+    x = rnd((B, H, H, C), 1).to(d)
+    gamma, beta = (rnd((C,), 4, 0.2) + 1).to(d), rnd((C,), 5, 0.1).to(d)
+    _, mean, invstd = K.instnorm_lrelu_fwd(x.view(groups, -1, C), gamma, beta, leak)
+    g = rnd((B, Ho, Ho, Cab), 3).to(d)
+    part = torch.full((lay[0], 2, C), float("nan"), device=d)
+    ns = K.NormBwdStats(x, mean, invstd, gamma, beta, leak, grp, part, lay)
+    if op == "conv":
+        w = rnd((k, k, C, Cab), 2, 0.05).to(d)
+        dy, dy_plain = K.conv2d_bwd_data(g, w, (H, H), s_, s_, nstat=ns), K.conv2d_bwd_data(g, w, (H, H), s_, s_)
+    else:
+        w = rnd((k, k, Cab, C), 2, 0.05).to(d)
+        dy, dy_plain = K.deconv2d_bwd_data(g, w, (H, H), s_, s_, nstat=ns), K.deconv2d_bwd_data(g, w, (H, H), s_, s_)
+    close(dy, dy_plain, 2e-6)
+    rows, rps, nseg, stride = lay
+    used = sorted({sg * stride + gi * rps + i for gi in range(groups) for sg in range(nseg) for i in range(rps)})
+    assert torch.isfinite(part[torch.tensor(used, device=d)]).all()              # every row a group owns was written
+    got = K.norm_lrelu_bwd_from_partials(dy.clone(), x, ns, groups)
+    want = K.instnorm_lrelu_bwd_data(dy.view(groups, -1, C).clone(), x.view(groups, -1, C), gamma, beta, mean, invstd, leak)
+    close(got.reshape(-1), want.reshape(-1), 1e-5)
