@@ -241,6 +241,19 @@ int cgs_refine_update(float* theta, float* m, const float* g, float rate, float 
     return CGS_OK;
 }
 
+// one sample's row: 16-byte copies where the row length and both rows' addresses allow it (F % 4 == 0 and 16-byte aligned bases: every row then
+// starts on a 16-byte boundary), single floats otherwise.  The scalar loop alone moved config 5's 33.5 MB of refined maps + 6.3 MB of images at 1.8 TB/s.
+__device__ __forceinline__ void copy_row(const float* __restrict__ src, float* __restrict__ dst, int F, bool vec4) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
+    if (vec4) {
+        const float4* s4 = (const float4*)src;
+        float4* d4 = (float4*)dst;
+        for (int i = t; i < (F >> 2); i += nt) d4[i] = s4[i];
+    } else {
+        for (int i = t; i < F; i += nt) dst[i] = src[i];
+    }
+}
+
 // pass 1: copy theta rows whose sample improves (reads best_logit, never writes it)
 __global__ __launch_bounds__(256) void refine_select_copy_kernel(const float* __restrict__ theta, const float* __restrict__ logit,
                                                                  const int32_t* __restrict__ forced, int step,
@@ -249,9 +262,7 @@ __global__ __launch_bounds__(256) void refine_select_copy_kernel(const float* __
     const int b = blockIdx.y;
     const bool upd = forced ? forced[b] == step : logit[b] > best_logit[b];
     if (!upd) return;
-    const float* src = theta + (size_t)b * F;
-    float* dst = best_theta + (size_t)b * F;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < F; i += gridDim.x * blockDim.x) dst[i] = src[i];
+    copy_row(theta + (size_t)b * F, best_theta + (size_t)b * F, F, (F & 3) == 0 && (((uintptr_t)theta | (uintptr_t)best_theta) & 15) == 0);
 }
 // pass 2: per-sample scalars
 __global__ void refine_select_scalar_kernel(const float* __restrict__ logit, const int32_t* __restrict__ forced, int step,
@@ -285,9 +296,9 @@ __global__ __launch_bounds__(256) void refine_select_copy2_kernel(const float* _
     const bool upd = forced ? forced[b] == step : lg > best_logit[b];
     if (!upd) return;                              // (nothing of this sample changes: no ticket needed)
     const int F = blockIdx.z ? F1 : F0;
-    const float* src = (blockIdx.z ? src1 : src0) + (size_t)b * F;
-    float* dst = (blockIdx.z ? dst1 : dst0) + (size_t)b * F;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < F; i += gridDim.x * blockDim.x) dst[i] = src[i];
+    const float* src = blockIdx.z ? src1 : src0;
+    float* dst = blockIdx.z ? dst1 : dst0;
+    copy_row(src + (size_t)b * F, dst + (size_t)b * F, F, (F & 3) == 0 && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0);
     if (!tickets) return;
     __syncthreads();                               // every thread of the block has read the predicate (it is the first thing a thread does)
     if (threadIdx.x == 0) {
