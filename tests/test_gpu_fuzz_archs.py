@@ -295,3 +295,60 @@ def test_a_wrong_lrelu_backward_slope_is_caught_on_every_seed(seed, monkeypatch)
     if LAST["degenerate"]:
         pytest.skip("this topology's gradient is identically zero (an instance norm over a 1x1 map): no slope can show in it")
     pytest.fail("the spoiled lrelu gradient passed the topology check")
+
+
+@pytest.mark.parametrize("seed", SEEDS[:max(4, N_ARCHS // 2)])
+def test_random_topology_on_the_generic_path_replays_and_agrees_with_the_engine(seed):
+    """Round 6: the generic Refiner path (callables the engine detection cannot see through: ops + autograd over the same kernels) is captured
+    into a hipGraph at its second call and replayed.  On random topologies -- instance / batch norms, residual blocks, per-layer kernels and
+    strides, fc and PatchGAN heads: graphs nobody hand-picked --: the first (eager), second (capturing) and third (replayed) call return
+    bit-identical results, and they agree with the fused ENGINE on the same feature (first-pass logits 1e-4; K-step logits 2e-3 per sample
+    except samples behind a rounding-level kink flip: two different fusions of the same arithmetic)."""
+    import warnings
+    from cgs_amd import nets, ops
+    from cgs_amd.model import GAN
+    from cgs_amd.sampling.collaborator import Refiner
+    A = random_arch(seed)
+    name = f"fuzzg{seed}"
+    N.ARCHS[name] = A
+    nets.ARCHS[name] = A
+    try:
+        B, Ksteps = int(np.random.RandomState(seed).choice([3, 8, 16])), 2
+        P = N.init_params(name, 7, True)
+        d = dev()
+        ops.reset_variables()
+        gan = GAN(name, batch_size=B, device=d, params=P)
+        z = torch.from_numpy(np.random.RandomState(seed + 1).uniform(-1, 1, (B, 8)).astype(np.float32)).to(d)
+        with torch.no_grad():
+            f0 = gan.input_to_feature(z).clone()
+        eng = gan.build_refiner(Ksteps, 0.1)
+        img_e = eng.build_refiner(f0, None, "deterministic")
+        assert eng.path == "engine"
+        gen = Refiner(Ksteps, 0.1)
+        gen.set_env(lambda x: gan.discriminator(x, is_training=True, reuse=True), lambda f: gan.feature_to_data(f), gan.loss_refine)
+        outs = []
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", RuntimeWarning)
+            for call in range(3):
+                img = gen.build_refiner(f0, None, "deterministic")
+                assert gen.path == "generic" and gen.graph_fallback is None and len(gen._generic_graphs) == (0 if call == 0 else 1)
+                outs.append([t.clone() for t in (img, gen.default_logit, gen.optimal_logit, gen.optimal_step, gen.optimal_feature)])
+        for a, b in zip(outs[0], outs[1]):
+            assert torch.equal(a, b)                        # (the capturing call returns the eager pass's results of the same kernels)
+        for a, b in zip(outs[0], outs[2]):
+            assert torch.equal(a, b)                        # replay == eager
+        close(outs[2][1], eng.default_logit, 1e-4, "default logit, generic vs engine")
+        # K steps later the two fusions may have taken different sides of a LeakyReLU kink at a rounding-level element (run_topology's excuse;
+        # seed 1002 is such a draw): per sample 2e-3, all but a few samples -- or, where a batch norm of D couples the samples, a loose bound
+        ol_g, ol_e = outs[2][2].cpu().double(), eng.optimal_logit.cpu().double()
+        per = (ol_g - ol_e).abs() / (ol_e.abs().max().item() + 1e-30)
+        off = per > max(2e-3, 1e-5 / (ol_e.abs().max().item() + 1e-30))
+        if bool(off.any()):
+            coupled = any(L[0] == "bn" for L in A["d"])
+            assert float(per.max()) < 5e-2 and (coupled or int(off.sum()) <= max(1, B // 4)), \
+                f"optimal logit, generic vs engine: max rel {float(per.max()):.3e} in samples {off.nonzero().flatten().tolist()}"
+        assert img_e.shape == outs[2][0].shape
+    finally:
+        N.ARCHS.pop(name, None)
+        nets.ARCHS.pop(name, None)
+        ops.reset_variables()
