@@ -290,7 +290,6 @@ __global__ __launch_bounds__(256) void bn_apply_bwd_kernel(const float* __restri
         ((float4*)dx)[i] = o;
     }
 }
-#undef BWD1
 
 // ------------------------------------------------------------------------------------------------
 // Small groups (<= 128 rows per group: the batch norm behind the fully connected layer of the reference's MNIST D, nsgan/GAN.py:66-67, at
@@ -414,6 +413,123 @@ static unsigned ew_blocks(size_t n) {
     return (unsigned)b;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Finalize + apply in ONE launch for norms whose statistics arrive as FEW partial rows (round 6): at the reference's batch size (64 images a
+// call, nsgan/main.py:32) a norm's tensor is 0.5-8 MB and its group owns 4-256 partial rows (one per 64 GEMM rows of the producing launch), so
+// the finalize kernel and the apply kernel are two dependent launches of ~5 us each whatever they do -- 6 of the ~40 launches of a refinement
+// step on the DCGAN nets.  Here every block re-derives the statistics of its 64 channels from the partial rows (<= 256 rows x 2 x 64 floats out
+// of L2: 16 row lanes sum their rows in double in index order, the 16 lane sums are added in index order -- deterministic) and applies them to its
+// chunk of rows; the block of the first chunk also writes the saved mean / invstd (forward).  Same formulas as bn_finalize_kernel + bn_apply_*.
+// Taken for groups of <= 16 partial rows and tensors of <= 2 MB (norm_fa_rows_per_block): beyond, the per-block re-derivation costs what the launch saved.
+// Layout of the partial rows as in bn_finalize_kernel: group g owns, for every segment sg < nseg, the rows sg * seg_stride + g * R ... + R - 1.
+// ------------------------------------------------------------------------------------------------
+#define NFA_MAX_ROWS 256
+template <bool BWD>
+__global__ __launch_bounds__(256) void norm_fa_kernel(const float* __restrict__ x, const float* dy, const float* __restrict__ part, int R, int nseg,
+                                                      int seg_stride, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                      float leak, float* out, float* __restrict__ mean_io, float* __restrict__ invstd_io, int M, int C,
+                                                      int rows_per_block) {
+    __shared__ double red[2][16][16][4];
+    __shared__ float4 bc[2][16];
+    const int tid = threadIdx.x, q = tid & 15, rl = tid >> 4;
+    const int c = blockIdx.x * 64 + q * 4;
+    const int grp = blockIdx.z;
+    const bool live = c < C;
+    double a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
+    if (live) {
+        const float* pg = part + (size_t)grp * R * 2 * C;
+        for (int r = rl; r < nseg * R; r += 16) {          // (fixed order per row lane: deterministic)
+            const int sg = r / R, g = r - sg * R;
+            const float* row = pg + ((size_t)sg * seg_stride + g) * 2 * C;
+            const float4 u = *(const float4*)(row + c), v = *(const float4*)(row + C + c);
+            a[0] += u.x; a[1] += u.y; a[2] += u.z; a[3] += u.w;
+            b[0] += v.x; b[1] += v.y; b[2] += v.z; b[3] += v.w;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { red[0][rl][q][e] = a[e]; red[1][rl][q][e] = b[e]; }
+    __syncthreads();
+    if (rl == 0 && live) {
+        float o0[4], o1[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            double sa = 0.0, sb = 0.0;
+            for (int i = 0; i < 16; ++i) { sa += red[0][i][q][e]; sb += red[1][i][q][e]; }
+            if (!BWD) {
+                const double mean = sa / M;
+                double var = sb / M - mean * mean;
+                if (var < 0.0) var = 0.0;
+                o0[e] = (float)mean; o1[e] = (float)(1.0 / sqrt(var + (double)eps));
+            } else {
+                o0[e] = (float)(sa / M); o1[e] = (float)(sb / M);
+            }
+        }
+        bc[0][q] = make_float4(o0[0], o0[1], o0[2], o0[3]); bc[1][q] = make_float4(o1[0], o1[1], o1[2], o1[3]);
+        if (!BWD && blockIdx.y == 0) {
+            *(float4*)(mean_io + (size_t)grp * C + c) = bc[0][q];
+            *(float4*)(invstd_io + (size_t)grp * C + c) = bc[1][q];
+        }
+    }
+    __syncthreads();
+    if (!live) return;
+    const float4 s0 = bc[0][q], s1 = bc[1][q];
+    const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    const size_t base = (size_t)grp * M * C + c;
+    if (!BWD) {      // y = lrelu(scale * x + shift): the affine exactly as bn_finalize_kernel<0> forms it
+        const float4 g = *(const float4*)(gamma + c), bt = *(const float4*)(beta + c);
+        float4 sc, sh;
+        sc.x = g.x * s1.x; sc.y = g.y * s1.y; sc.z = g.z * s1.z; sc.w = g.w * s1.w;
+        sh.x = bt.x - s0.x * sc.x; sh.y = bt.y - s0.y * sc.y; sh.z = bt.z - s0.z * sc.z; sh.w = bt.w - s0.w * sc.w;
+        for (int r = r0 + rl; r < r1; r += 16) {
+            const float4 v = *(const float4*)(x + base + (size_t)r * C);
+            float4 o;
+            o.x = fmaf(v.x, sc.x, sh.x); o.y = fmaf(v.y, sc.y, sh.y); o.z = fmaf(v.z, sc.z, sh.z); o.w = fmaf(v.w, sc.w, sh.w);
+            o.x = o.x > 0.f ? o.x : leak * o.x; o.y = o.y > 0.f ? o.y : leak * o.y;
+            o.z = o.z > 0.f ? o.z : leak * o.z; o.w = o.w > 0.f ? o.w : leak * o.w;
+            *(float4*)(out + base + (size_t)r * C) = o;
+        }
+    } else {         // dx = gamma * invstd * (dy' - m1 - xhat * m2)   (dy / dx may be the same buffer: every thread reads its element before it writes it)
+        float4 mean, inv, sc, sh;
+        bn_affine4(mean_io + (size_t)grp * C, invstd_io + (size_t)grp * C, gamma, beta, c, mean, inv, sc, sh);
+        const float4 m1 = s0, m2 = s1;
+        for (int r = r0 + rl; r < r1; r += 16) {
+            const float4 xv = *(const float4*)(x + base + (size_t)r * C), dv = *(const float4*)(dy + base + (size_t)r * C);
+            float4 o;
+            BWD1(x) BWD1(y) BWD1(z) BWD1(w)
+            *(float4*)(out + base + (size_t)r * C) = o;
+        }
+    }
+}
+
+#undef BWD1
+
+// rows per block of norm_fa_kernel for a call, 0 = the two-launch form serves it (too many partial rows, or a tensor large enough that the
+// statistics' re-derivation per block and the plain row loop would cost more than the launch they save)
+static int norm_fa_rows_per_block(int groups, int rows_per_seg, int nseg, int M_group, int C) {
+#ifdef CGS_EXPERIMENT
+    if (getenv("CGS_NORM_FA") && atoi(getenv("CGS_NORM_FA")) == 0) return 0;
+#endif
+    // (limits from a same-process A/B over (rows, MB), profiles/r06_za_norm_fa_limits_ab.txt: every block re-derives the statistics, so the launch it saves
+    // is only a gain while that is a handful of loads -- <= 16 rows, <= 2 MB: dcgan32 at batch 64 -2.2 % per call, neutral elsewhere; with <= 64 rows / 4 MB
+    // -0.8 % there and +0.2 ... +0.4 % on dcgan64 at batch 64 and dcgan32 at batch 256)
+    long max_rows = 16;
+    size_t max_bytes = (size_t)2 << 20;
+#ifdef CGS_EXPERIMENT
+    if (getenv("CGS_NORM_FA_ROWS")) max_rows = atol(getenv("CGS_NORM_FA_ROWS"));
+    if (getenv("CGS_NORM_FA_MB")) max_bytes = (size_t)atol(getenv("CGS_NORM_FA_MB")) << 20;
+#endif
+    if ((long)rows_per_seg * nseg > max_rows || (long)rows_per_seg * nseg > NFA_MAX_ROWS || groups > 65535) return 0;
+    if ((size_t)groups * M_group * C * sizeof(float) > max_bytes) return 0;
+    const long cg = cgs_ceil_div(C, 64);
+    long chunks = 1024 / ((long)groups * cg);            // ~1024 blocks in all
+    if (chunks < 1) chunks = 1;
+    long rpb = cgs_ceil_div(M_group, (int)chunks);
+    if (rpb < 16) rpb = 16;
+    rpb = (rpb + 15) / 16 * 16;
+    if (cgs_ceil_div(M_group, (int)rpb) > 65535) return 0;
+    return (int)rpb;
+}
+
 int cgs_bn_train_lrelu_fwd(const float* x, const float* gamma, const float* beta, float eps, float leak, float* y,
                            float* mean, float* invstd, int M, int C, void* ws, size_t ws_bytes, void* stream) {
     if (M <= 0 || C <= 0 || (C & 3)) return cgs_set_error(CGS_EINVAL, "bn fwd: M=%d C=%d (C must be a multiple of 4)", M, C);
@@ -441,6 +557,12 @@ int cgs_bn_train_lrelu_fwd_from_partials(const float* x, const float* part, int 
     if (M <= 0 || C <= 0 || (C & 3) || G <= 0 || !part) return cgs_set_error(CGS_EINVAL, "bn fwd from partials: M=%d C=%d G=%d", M, C, G);
     if (ws_bytes < cgs_bn_ws_bytes(M, C)) return cgs_set_error(CGS_EWORKSPACE, "bn fwd: workspace %zu < %zu", ws_bytes, cgs_bn_ws_bytes(M, C));
     hipStream_t s = (hipStream_t)stream;
+    if (const int rpb = norm_fa_rows_per_block(1, G, 1, M, C)) {          // few partial rows, small tensor: finalize + apply in one launch
+        hipLaunchKernelGGL(norm_fa_kernel<false>, dim3(cgs_ceil_div(C, 64), cgs_ceil_div(M, rpb), 1), dim3(256), 0, s, x, nullptr, part, G, 1, 0, gamma, beta, eps,
+                           leak, y, mean, invstd, M, C, rpb);
+        CGS_CHECK_LAUNCH("bn_train_lrelu_fwd_from_partials");
+        return CGS_OK;
+    }
     float* stat = (float*)ws + (size_t)BN_MAX_BLOCKS * 2 * C;
     if (G >= 1024 && !((uintptr_t)ws & 7)) {      // (the workspace's own partial area is unused on this path: BN_MAX_BLOCKS * 2 * C floats >= 16 * 2 * C doubles)
         double* slices = (double*)ws;
@@ -665,6 +787,12 @@ int cgs_groupnorm_lrelu_fwd_from_partials(const float* x, const float* part, int
     if (ws_bytes < (size_t)groups * 4 * C * sizeof(float))
         return cgs_set_error(CGS_EWORKSPACE, "groupnorm fwd from partials: workspace %zu < %zu", ws_bytes, (size_t)groups * 4 * C * sizeof(float));
     hipStream_t s = (hipStream_t)stream;
+    if (const int rpb = norm_fa_rows_per_block(groups, rows_per_seg, nseg, M_group, C)) {
+        hipLaunchKernelGGL(norm_fa_kernel<false>, dim3(cgs_ceil_div(C, 64), cgs_ceil_div(M_group, rpb), groups), dim3(256), 0, s, x, nullptr, part, rows_per_seg, nseg,
+                           seg_stride, gamma, beta, eps, leak, y, mean, invstd, M_group, C, rpb);
+        CGS_CHECK_LAUNCH("groupnorm_lrelu_fwd_from_partials");
+        return CGS_OK;
+    }
     float* stat = (float*)ws;                                          // [groups][4][C]
     hipLaunchKernelGGL(bn_finalize_kernel<0>, dim3(cgs_ceil_div(C, BNF_CH), groups), dim3(256), 0, s, part, rows_per_seg, M_group, C, gamma, beta, eps, stat,
                        mean, invstd, nseg, seg_stride);
@@ -687,6 +815,12 @@ int cgs_norm_lrelu_bwd_from_partials(const float* dy, const float* x, const floa
     const size_t need = (size_t)groups * 2 * C * sizeof(float) + (sliced ? (size_t)BNF_SLICES * 2 * C * sizeof(double) : 0);
     if (!ws || ws_bytes < need) return cgs_set_error(CGS_EWORKSPACE, "norm bwd from partials: workspace %zu < %zu", ws_bytes, need);
     hipStream_t s = (hipStream_t)stream;
+    if (const int rpb = norm_fa_rows_per_block(groups, rows_per_seg, nseg, M_group, C)) {
+        hipLaunchKernelGGL(norm_fa_kernel<true>, dim3(cgs_ceil_div(C, 64), cgs_ceil_div(M_group, rpb), groups), dim3(256), 0, s, x, dy, part, rows_per_seg, nseg,
+                           seg_stride, gamma, beta, 0.f, leak, dx, (float*)mean, (float*)invstd, M_group, C, rpb);
+        CGS_CHECK_LAUNCH("norm_lrelu_bwd_from_partials");
+        return CGS_OK;
+    }
     float* stat2;
     if (sliced) {
         double* slices = (double*)ws;
